@@ -1,0 +1,125 @@
+/* spider_hip.h -- C ABI of libspider_hip.so: the MI355X (gfx950) kernels behind Spider's any-to-many
+ * generation hot path (LLM greedy decode + SD/StoryDiffusion UNet step).
+ *
+ * The reference (Layjins/Spider) has no FFI: every operator below replaces a PyTorch-level op sequence,
+ * cited as <file>:<lines> relative to the reference tree. A maintainer binds these with ctypes (see
+ * INTEGRATION.md); spider_amd/lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; bf16 tensors are raw uint16 bit patterns
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work, they never synchronise,
+ *     allocate or free, so they can be captured into a hipGraph
+ *   - return 0 on success, <0 on error; spider_last_error() (thread-local) holds the message
+ *   - all reductions accumulate in fp32; outputs are rounded to bf16 where the reference's bf16 module
+ *     would round (documented per function)
+ */
+#ifndef SPIDER_HIP_H
+#define SPIDER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library identity / errors ---- */
+int spider_abi_version(void);
+const char* spider_target_arch(void);
+const char* spider_last_error(void);
+
+/* ======================= LLM decode path (HBM-bound) ======================= */
+
+/* nn.Embedding lookup: out[r,:] = table[ids[r],:]   (base_model.py:253-258 embed_tokens) */
+int spider_embed_bf16(const void* table, const int* ids, void* out, int rows, int H, int V, void* stream);
+
+/* LlamaRMSNorm (modeling_llama3.py:68-82; modeling_llama.py:57-74) with optional fused residual add
+ * (decoder-layer wiring modeling_llama3.py:339-361): h = x (+ res); res_out = h; y = w * bf16(h*rsqrt(mean(h^2)+eps)) */
+int spider_rmsnorm_bf16(const void* x, const void* res, const void* w, void* y, void* res_out, int rows, int H,
+                        float eps, void* stream);
+
+/* nn.Linear at decode (1..8 tokens): out[b,n] = sum_k xin[b,k] W[n,k] (+bias[n]) (+res[b,n]);
+ * xin = RMSNorm(x)*norm_w when norm_w != NULL (fused prologue).  q/k/v/o_proj, down_proj:
+ * modeling_llama3.py:186-199,240-313 */
+int spider_gemv_bf16(const void* W, const void* x, void* out, const void* bias, const void* res, const void* norm_w,
+                     float eps, int B, int N, int K, void* stream);
+
+/* LlamaMLP gate/up + SiLU*mul (modeling_llama3.py:197-199): W_gate_up = [gate rows (I) | up rows (I)] x K */
+int spider_gemv_swiglu_bf16(const void* W_gate_up, const void* x, void* out, const void* norm_w, float eps, int B,
+                            int I, int K, void* stream);
+
+/* final norm + lm_head + greedy argmax (modeling_llama3.py:619,870-871; HF greedy loop driven from
+ * spider.py:1492-1508). logits (bf16 [B,V]) optional. ws_val/ws_idx: B*spider_lm_head_nparts(V) floats/ints. */
+int spider_lm_head_nparts(int V);
+int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w, float eps, int* out_ids, void* logits,
+                               void* ws_val, void* ws_idx, int B, int V, int K, void* stream);
+
+/* apply_rotary_pos_emb (modeling_llama3.py:150-183; modeling_llama.py:116-123) on q,k of a fused QKV
+ * projection + KV-cache append (modeling_llama.py:190-193). qkv [B*S,(n_q+2n_kv)*d]; cos_sin fp32
+ * [max_pos, d] = [cos(d/2) | sin(d/2)]; q_out [B*S,n_q,d]; caches [B,n_kv,T_max,d]. */
+int spider_rope_kv_append_bf16(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out,
+                               void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
+                               void* stream);
+
+/* decode attention, one query token per sequence, GQA, fp32 online softmax, split over the KV length
+ * (eager_attention_forward + repeat_kv, modeling_llama3.py:202-237). Valid cache slots per sequence:
+ * [kv_beg[b], kv_end[b]) (kv_beg may be NULL = 0). ws_o: B*n_q*nsplit*d floats, ws_ml: B*n_q*nsplit*2. */
+int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_cache, const int* kv_beg,
+                            const int* kv_end, void* out, void* ws_o, void* ws_ml, int B, int n_q, int n_kv, int d,
+                            int T_max, float scale, int nsplit, void* stream);
+
+/* ======================= MFMA GEMM / conv / attention ======================= */
+
+/* C = act(A[M,K] . W[N,K]^T + bias[N] + rowbias[row/rows_per_group, N]) (+res) * out_scale.
+ * Exactly one of C (bf16) / C32 (fp32). act: 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu.
+ * Prefill projections (modeling_llama3.py:186-313), diffusers Attention/FeedForward/proj linears. */
+int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
+                     const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
+                     float out_scale, void* stream);
+
+/* conv2d NHWC as implicit GEMM (ResnetBlock2D / Downsample2D / Upsample2D convs reached from
+ * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
+int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                            const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
+                            int pad, int ups, float out_scale, void* stream);
+
+/* fused attention (prefill causal GQA: modeling_llama3.py:202-237; UNet self/cross attention:
+ * StoryDiffusion/utils/gradio_utils.py:400-472; consistent self-attention with the column keep vector of
+ * cal_attn_mask_xl: Comic_Generation.py:129-196, gradio_utils.py:241-287). Strides in elements. */
+int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
+                     long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                     long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                     int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
+                     const int* kv_beg, const void* keep_bits, int blk, int q_off, void* stream);
+
+/* ======================= UNet elementwise / normalisation (HBM-bound) ======================= */
+
+/* GroupNorm(+SiLU) on NHWC (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out).
+ * ws: B*spider_groupnorm_nchunk(HW)*G*2 floats. */
+int spider_groupnorm_nchunk(int HW);
+int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream);
+int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                          void* stream);
+/* GEGLU (diffusers FeedForward): y[m,n] = x[m,n] * gelu(x[m,inner+n]) */
+int spider_geglu_bf16(const void* x, void* y, int M, int inner, void* stream);
+/* SwiGLU on a fused [gate|up] prefill projection (modeling_llama3.py:197-199) */
+int spider_swiglu_bf16(const void* x, void* y, int M, int inner, void* stream);
+int spider_concat_channels_bf16(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream);
+int spider_act_bf16(const void* x, void* y, long n, int act, void* stream);
+int spider_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+                                 int Cout, int ks, void* stream);
+int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
+                                  int W, int Cin, int Cout, int ks, void* stream);
+
+/* ---- latent plumbing of the denoising loop (custom_sd.py:631-647) ---- */
+/* torch.cat([latents]*reps) + scale_model_input: fp32 NCHW -> bf16 NHWC */
+int spider_latent_to_nhwc_bf16(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream);
+/* noise_pred_uncond + g*(noise_pred_text - noise_pred_uncond): fp32 NHWC [2,B,HW,C] -> fp32 NCHW */
+int spider_cfg_combine_f32(const float* eps2, float* out, int B, int C, int HW, float guidance, void* stream);
+/* scheduler.step as a linear update: out = sum_j host_coefs[j] * ins[j]; host_ins is a HOST array of n device ptrs */
+int spider_lincomb_f32(const float* const* host_ins, const float* host_coefs, int n, float* out, long total, void* stream);
+int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPIDER_HIP_H */

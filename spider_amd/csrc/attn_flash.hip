@@ -1,0 +1,283 @@
+// Flash-style fused attention on MFMA (gfx950), one kernel for every dense attention on the path:
+//   * LLM prefill, causal + GQA             (modeling_llama3.py:202-237; old modeling_llama.py:190-231)
+//   * UNet self- / cross-attention          (diffusers-0.25 Attention + AttnProcessor2_0, gradio_utils.py:400-472)
+//   * StoryDiffusion consistent self-attn   (Comic_Generation.py:129-196 with cal_attn_mask_xl masks,
+//                                            gradio_utils.py:241-287)
+//   * CLIP text encoder (causal, d = 64)    (custom_sd.py:306-310)
+// The [Lq, Lk] score matrix is never materialised. Per block: 128 query rows (4 waves x 32), KV tiles of
+// 64 keys staged global -> registers -> LDS (prefetch of tile t+1 overlaps the MFMAs of tile t).
+//   S^T = K . Q^T  (mfma_f32_32x32x16_bf16; key on the accumulator row, query on the lane) so a query row's
+//   softmax statistics are lane-local; the S^T accumulators, packed to bf16, are directly the B operand of
+//   O^T += V^T . P^T, whose A operand comes from the row-major V tile through ds_read_b64_tr_b16.
+// LDS: K rows padded to an odd multiple of 16 B (conflict-free ds_read_b128); V row stride = 64 or 192 mod
+// 256 B (conflict-free transposed reads).
+//
+// The consistent-self-attention mask is column-structured (every row shares one random keep vector except
+// for its own image block, gradio_utils.py:257-285), so it is passed as a bit vector over the keys plus the
+// image block length instead of a dense [4N,4N] bool matrix.
+#include "common.hpp"
+
+using namespace spider;
+
+namespace {
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    long q_bs, q_hs, q_rs;   // element strides: batch, head, row
+    long k_bs, k_hs, k_rs;
+    long v_bs, v_hs, v_rs;
+    long o_bs, o_hs, o_rs;
+    int B, Hq, Hkv, Lq, Lk, d;
+    float scale_log2e;
+    int causal, kv_off;                   // causal: key j visible to query i iff j <= i + kv_off
+    const int* kv_beg;                    // [B] or null: keys < kv_beg[b] are masked (left padding)
+    const unsigned long long* keep_bits;  // [ceil(Lk/64)] or null: bit j%64 of word j/64 = key j kept
+    int blk, q_off;                       // image block length / query row offset for the "own block" rule
+};
+
+template <int DP>
+struct Cfg {
+    static constexpr int KS = DP + 8;                                  // K LDS row stride (elements)
+    static constexpr int VS = (DP == 64 || DP == 96) ? 96 : 160;       // V LDS row stride (elements)
+    static constexpr int NCH = (64 * DP / 8 + 255) / 256;              // 16-B chunks per thread per operand
+    static constexpr int CPR = DP / 8;                                 // chunks per (padded) row
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_flash_kernel(AttnArgs p) {
+    using C = Cfg<DP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + 64 * C::KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h32 = lane >> 5, l32 = lane & 31;
+    const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (p.Hq / p.Hkv);
+    const int q0 = qt * 128;
+    const int qi = q0 + wave * 32 + l32;  // this lane's query row
+    const bool q_ok = qi < p.Lq;
+
+    const bf16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
+    const bf16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
+    const bf16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[qi][16*ks + 8*h32 + 0..7] ----
+    bf16x8 qf[DP / 16];
+#pragma unroll
+    for (int ks = 0; ks < DP / 16; ++ks) {
+        const int dd = ks * 16 + h32 * 8;
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (q_ok && dd < p.d) t = *reinterpret_cast<const u32x4*>(qb + (long)qi * p.q_rs + dd);
+        qf[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+
+    // ---- key range for this query tile ----
+    const int kbeg = p.kv_beg ? p.kv_beg[b] : 0;
+    int kend = p.Lk;
+    if (p.causal) kend = min(kend, q0 + 128 + p.kv_off);
+    const int t_begin = kbeg / 64;
+    const int t_end = (kend + 63) / 64;
+
+    const int own_lo = p.blk > 0 ? ((qi + p.q_off) / p.blk) * p.blk : 0;
+    const int own_hi = own_lo + p.blk;
+    const int caus_max = qi + p.kv_off;  // last visible key when causal
+
+    f32x16 acc_o[DP / 32];
+#pragma unroll
+    for (int i = 0; i < DP / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    u32x4 rk[C::NCH], rv[C::NCH];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / C::CPR, ch = c % C::CPR;
+            const int key = t * 64 + row;
+            const bool ok = (c < 64 * C::CPR) && key < p.Lk && ch * 8 < p.d;
+            rk[i] = ok ? *reinterpret_cast<const u32x4*>(kb + (long)key * p.k_rs + ch * 8) : zero;
+            rv[i] = ok ? *reinterpret_cast<const u32x4*>(vb + (long)key * p.v_rs + ch * 8) : zero;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < 64 * C::CPR) {
+                const int row = c / C::CPR, ch = c % C::CPR;
+                *reinterpret_cast<u32x4*>(Ks + row * C::KS + ch * 8) = rk[i];
+                *reinterpret_cast<u32x4*>(Vs + row * C::VS + ch * 8) = rv[i];
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile();
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t + 1 < t_end) load_tile(t + 1);
+
+        // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const bf16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
+#pragma unroll
+            for (int ks = 0; ks < DP / 16; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+
+        // ---- mask + online softmax (lane = query column; the partner lane^32 holds the other 32 keys) ----
+        const unsigned long long kbits = p.keep_bits ? p.keep_bits[t] : ~0ull;
+        float tmax = -1e30f;
+        bool vis[2][16];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h32;
+                const int key = t * 64 + kk;
+                bool ok = key < p.Lk && key >= kbeg;
+                if (p.causal) ok = ok && key <= caus_max;
+                if (p.keep_bits) ok = ok && (((kbits >> kk) & 1ull) || (key >= own_lo && key < own_hi));
+                vis[kt][r] = ok;
+                const float sv = s[kt][r] * p.scale_log2e;
+                s[kt][r] = sv;
+                tmax = fmaxf(tmax, ok ? sv : -1e30f);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = vis[kt][r] ? exp2f(s[kt][r] - m_new) : 0.f;
+                s[kt][r] = pv;
+                psum += pv;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < DP / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[i][r] *= alpha;
+
+        // ---- P^T as the B operand: registers 8s..8s+7 of each half, packed to bf16 ----
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                u32x4 t4;
+                t4.x = pack_bf16x2(s[kt][8 * sx + 0], s[kt][8 * sx + 1]);
+                t4.y = pack_bf16x2(s[kt][8 * sx + 2], s[kt][8 * sx + 3]);
+                t4.z = pack_bf16x2(s[kt][8 * sx + 4], s[kt][8 * sx + 5]);
+                t4.w = pack_bf16x2(s[kt][8 * sx + 6], s[kt][8 * sx + 7]);
+                pf[kt][sx] = __builtin_bit_cast(bf16x8, t4);
+            }
+
+        // ---- O^T += V^T . P^T ; V^T fragments by transposed LDS reads of the row-major V tile ----
+        // lane i of a 16-lane group addresses row r0 + (i>>2), columns c0 + 4*(i&3); it receives column i.
+        const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const int r0 = kt * 32 + 16 * sx + 4 * h32 + (i16 >> 2);
+                    const int c0 = db * 32 + 16 * g16 + 4 * (i16 & 3);
+                    const bf16_t* a0 = Vs + r0 * C::VS + c0;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0 + 8 * C::VS));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][sx], acc_o[db], 0, 0, 0);
+                }
+        }
+
+        __syncthreads();
+        if (t + 1 < t_end) store_tile();
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds O[qi][db*32 + 8*(r>>2) + 4*h32 + (r&3)] ----
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = db * 32 + 8 * g + 4 * h32;
+                if (dd < p.d) {
+                    u32x2 o2;
+                    o2.x = pack_bf16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
+                    o2.y = pack_bf16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(ob + dd) = o2;
+                }
+            }
+    }
+}
+
+template <int DP>
+int launch(const AttnArgs& a, void* stream) {
+    using C = Cfg<DP>;
+    dim3 grid((a.Lq + 127) / 128, a.Hq, a.B);
+    const size_t smem = (size_t)64 * (C::KS + C::VS) * sizeof(bf16_t);
+    attn_flash_kernel<DP><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Generic strided attention. Tensors are bf16; strides are in elements (batch, head, row), the head
+// dimension is contiguous. d must be a multiple of 8 and <= 160. Output row = softmax(q k^T * scale + mask) v.
+//   causal != 0 : key j visible to query i iff j <= i + kv_off
+//   kv_beg      : optional device int[B]; keys below kv_beg[b] are masked
+//   keep_bits   : optional device uint64[ceil(Lk/64)] column keep vector; a key is visible if its bit is
+//                 set OR it lies in the query's own image block ((i + q_off) / blk == j / blk)
+int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
+                     long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                     long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                     int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
+                     const int* kv_beg, const void* keep_bits, int blk, int q_off, void* stream) {
+    SPIDER_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Lq > 0 && Lk > 0, "attn: bad shape");
+    SPIDER_CHECK(d > 0 && d % 8 == 0 && d <= 160, "attn: head_dim must be a multiple of 8 and <= 160");
+    SPIDER_CHECK(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0, "attn: row strides must keep 16-byte alignment");
+    SPIDER_CHECK(q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 && o_hs % 4 == 0, "attn: head strides must keep 16-byte alignment");
+    SPIDER_CHECK(q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 4 == 0, "attn: batch strides must keep 16-byte alignment");
+    SPIDER_CHECK(!keep_bits || blk > 0, "attn: keep_bits needs the image block length");
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q_bs = q_bs; a.q_hs = q_hs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_rs = k_rs;
+    a.v_bs = v_bs; a.v_hs = v_hs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_hs = o_hs; a.o_rs = o_rs;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Lq = Lq; a.Lk = Lk; a.d = d;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.causal = causal; a.kv_off = kv_off; a.kv_beg = kv_beg;
+    a.keep_bits = (const unsigned long long*)keep_bits; a.blk = keep_bits ? blk : 0; a.q_off = q_off;
+    if (d <= 64) return launch<64>(a, stream);
+    if (d <= 96) return launch<96>(a, stream);
+    if (d <= 128) return launch<128>(a, stream);
+    return launch<160>(a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Shared device helpers for the spider_hip kernels (gfx950 / CDNA4 only).
+// Wavefront = 64 lanes; all bf16 tensors are passed as raw uint16_t bit patterns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spider {
+
+typedef uint16_t bf16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // 16-byte global/LDS access unit
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) {
+    return __uint_as_float(packed << 16);
+}
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) {
+    return __uint_as_float(packed & 0xffff0000u);
+}
+// round-to-nearest-even f32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blocks of NW waves; `red` is >= NW floats of LDS. All threads get the result.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+
+// XCD-aware bijective remap of a linear block id: blocks that share an XCD (id % 8) get a
+// contiguous chunk of the logical grid, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace spider
+
+// ---- error plumbing shared by the C-ABI translation units ----
+extern "C" void spider_set_error(const char* msg);
+#define SPIDER_CHECK(cond, msg)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            spider_set_error(msg);         \
+            return -1;                     \
+        }                                  \
+    } while (0)
+#define SPIDER_LAUNCH_OK()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) {                                  \
+            spider_set_error(hipGetErrorString(e__));             \
+            return -2;                                            \
+        }                                                         \
+    } while (0)

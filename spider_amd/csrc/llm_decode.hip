@@ -1,0 +1,734 @@
+// LLM autoregressive-decode kernels (HBM-bound, one token per sequence per step).
+//
+// Replaces the PyTorch op sequences of the reference's Llama forward at S=1:
+//   RMSNorm            spider/models/modeling_llama3.py:68-82  (old: modeling_llama.py:57-74)
+//   q/k/v/o, MLP GEMV  spider/models/modeling_llama3.py:186-199,240-313
+//   RoPE + KV append   spider/models/modeling_llama3.py:128-183  (old: modeling_llama.py:77-123,190-193)
+//   decode attention   spider/models/modeling_llama3.py:202-237  (repeat_kv + eager softmax in fp32)
+//   lm_head + argmax   spider/models/modeling_llama3.py:870-871 + HF greedy loop (spider.py:1492-1508)
+//
+// Layouts: activations [B, H] bf16 row-major; weights [N, K] bf16 row-major (nn.Linear layout, never
+// transposed); KV cache [B, n_kv, T_max, d] bf16. All reductions accumulate in fp32.
+#include "common.hpp"
+
+using namespace spider;
+
+// ----------------------------------------------------------------------------------------------
+// Embedding gather: out[r, :] = table[ids[r], :]
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const bf16_t* __restrict__ table, const int* __restrict__ ids,
+                                                    bf16_t* __restrict__ out, int H, int V) {
+    const int r = blockIdx.x;
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const u32x4* src = reinterpret_cast<const u32x4*>(table + (size_t)id * H);
+    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)r * H);
+    for (int i = threadIdx.x; i < H / 8; i += 256) dst[i] = src[i];
+}
+
+// ----------------------------------------------------------------------------------------------
+// RMSNorm (+ optional residual add):  h = x (+ res);  res_out = bf16(h);  y = bf16(w * bf16(h * rsqrt(mean(h^2)+eps)))
+// One block (256 threads) per row. Double rounding mirrors `self.weight * hidden_states.to(input_dtype)`.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                      bf16_t* __restrict__ res_out, int H, float eps) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x + row * H);
+    const u32x4* rv = res ? reinterpret_cast<const u32x4*>(res + row * H) : nullptr;
+    const u32x4* wv = reinterpret_cast<const u32x4*>(w);
+    u32x4* yv = reinterpret_cast<u32x4*>(y + row * H);
+    u32x4* rov = res_out ? reinterpret_cast<u32x4*>(res_out + row * H) : nullptr;
+    const int nv = H / 8;
+    // H <= 8192*? : keep up to 4 vectors per thread in registers (H <= 8192)
+    float h[4][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nv) {
+            u32x4 a = xv[i];
+            uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            if (rv) {
+                u32x4 b = rv[i];
+                uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // bf16 + bf16 -> bf16 (as `residual + hidden_states` does), then the norm sees the rounded sum
+                    float lo = bf16_to_f32(f32_to_bf16(bf16lo_to_f32(aw[j]) + bf16lo_to_f32(bw[j])));
+                    float hi = bf16_to_f32(f32_to_bf16(bf16hi_to_f32(aw[j]) + bf16hi_to_f32(bw[j])));
+                    h[it][2 * j] = lo;
+                    h[it][2 * j + 1] = hi;
+                }
+                if (rov) {
+                    u32x4 o;
+                    o.x = pack_bf16x2(h[it][0], h[it][1]);
+                    o.y = pack_bf16x2(h[it][2], h[it][3]);
+                    o.z = pack_bf16x2(h[it][4], h[it][5]);
+                    o.w = pack_bf16x2(h[it][6], h[it][7]);
+                    rov[i] = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[it][2 * j] = bf16lo_to_f32(aw[j]);
+                    h[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += h[it][j] * h[it][j];
+        }
+    }
+    const float tot = block_sum<4>(ss, red);
+    const float rs = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nv) {
+            u32x4 wq = wv[i];
+            uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float lo = bf16_to_f32(f32_to_bf16(h[it][2 * j] * rs)) * bf16lo_to_f32(ww[j]);
+                float hi = bf16_to_f32(f32_to_bf16(h[it][2 * j + 1] * rs)) * bf16hi_to_f32(ww[j]);
+                o[j] = pack_bf16x2(lo, hi);
+            }
+            u32x4 ov;
+            ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+            yv[i] = ov;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight-streaming GEMV:  out[b, n] = epilogue( sum_k xin[b, k] * W[n, k] ),   b < NB <= 8
+//   xin = x, or RMSNorm(x) * norm_w when norm_w != nullptr (fused prologue; every block recomputes the
+//         row norm of its <= 8 activation rows, which is free next to the weight stream)
+//   epilogue: (+bias) -> bf16 -> (+res -> bf16);  GATEUP: W holds [gate rows | up rows] (2*N rows) and
+//         out[b,n] = bf16(bf16(silu(bf16(g))) * bf16(u))     (modeling_llama3.py:197-199)
+// Each wave owns R output columns and streams their weight rows with 16-B loads (1 KiB per wave
+// instruction), U chunks deep; activations are staged once per block in LDS as bf16 (XLDS) or, when
+// NB*K*2 bytes exceed the LDS budget, re-read through L2.
+// ----------------------------------------------------------------------------------------------
+template <int NB, int R, bool GATEUP, bool XLDS>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+                                                   bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
+                                                   const bf16_t* __restrict__ res, const bf16_t* __restrict__ norm_w,
+                                                   float eps, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K] when XLDS
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NR = GATEUP ? 2 * R : R;  // weight rows per wave
+
+    if (XLDS) {
+        const int nv = K / 8;
+        for (int b = 0; b < NB; ++b) {
+            const u32x4* xv = reinterpret_cast<const u32x4*>(x + (size_t)b * K);
+            u32x4* sv = reinterpret_cast<u32x4*>(xs + (size_t)b * K);
+            if (norm_w) {
+                float ss = 0.f;
+                for (int i = threadIdx.x; i < nv; i += 256) {
+                    u32x4 a = xv[i];
+                    uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+                        ss += lo * lo + hi * hi;
+                    }
+                }
+                const float rs = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
+                const u32x4* wv = reinterpret_cast<const u32x4*>(norm_w);
+                for (int i = threadIdx.x; i < nv; i += 256) {
+                    u32x4 a = xv[i], wq = wv[i];
+                    uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w}, o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = bf16_to_f32(f32_to_bf16(bf16lo_to_f32(aw[j]) * rs)) * bf16lo_to_f32(ww[j]);
+                        float hi = bf16_to_f32(f32_to_bf16(bf16hi_to_f32(aw[j]) * rs)) * bf16hi_to_f32(ww[j]);
+                        o[j] = pack_bf16x2(lo, hi);
+                    }
+                    u32x4 ov;
+                    ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+                    sv[i] = ov;
+                }
+            } else {
+                for (int i = threadIdx.x; i < nv; i += 256) sv[i] = xv[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    const int col0 = (blockIdx.x * 4 + wave) * R;
+    if (col0 >= N) return;
+    const bf16_t* wrow[NR];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = col0 + r;
+        n = n < N ? n : N - 1;
+        wrow[r] = W + (size_t)n * K;
+        if (GATEUP) wrow[R + r] = W + (size_t)(N + n) * K;
+    }
+    float acc[NB][NR];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[b][r] = 0.f;
+
+    constexpr int U = (NR * NB <= 4) ? 4 : 2;  // chunks in flight per row
+    for (int k0 = lane * 8; k0 < K; k0 += 512 * U) {
+        u32x4 wq[U][NR];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 512;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    wq[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 512;
+            if (k < K) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    u32x4 xq = XLDS ? *reinterpret_cast<const u32x4*>(xs + (size_t)b * K + k)
+                                    : *reinterpret_cast<const u32x4*>(x + (size_t)b * K + k);
+                    const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const uint32_t ww[4] = {wq[u][r].x, wq[u][r].y, wq[u][r].z, wq[u][r].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[b][r] += bf16lo_to_f32(ww[j]) * bf16lo_to_f32(xw[j]);
+                            acc[b][r] += bf16hi_to_f32(ww[j]) * bf16hi_to_f32(xw[j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[b][r] = wave_sum(acc[b][r]);
+
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = col0 + r;
+            if (n < N) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float v;
+                    if (GATEUP) {
+                        const float g = bf16_to_f32(f32_to_bf16(acc[b][r]));
+                        const float u = bf16_to_f32(f32_to_bf16(acc[b][R + r]));
+                        const float a = bf16_to_f32(f32_to_bf16(silu_f(g)));
+                        v = a * u;
+                    } else {
+                        v = acc[b][r];
+                        if (bias) v += bf16_to_f32(bias[n]);
+                        if (res) v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(res[(size_t)b * N + n]);
+                    }
+                    out[(size_t)b * N + n] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// lm_head + greedy argmax. Stage 1: each wave scores R vocabulary rows (logit rounded to bf16 as the
+// reference's bf16 lm_head output is), keeps its best (value, lowest index); each block writes one
+// partial. Stage 2: one block reduces the partials per batch row. Ties -> lowest token id.
+// ----------------------------------------------------------------------------------------------
+template <int NB, int R>
+__global__ __launch_bounds__(256) void lmhead_partial_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ norm_w, float eps,
+                                                             float* __restrict__ pval, int* __restrict__ pidx,
+                                                             bf16_t* __restrict__ logits, int V, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+    __shared__ float red[4];
+    __shared__ float bval[4][NB];
+    __shared__ int bidx[4][NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = K / 8;
+    for (int b = 0; b < NB; ++b) {
+        const u32x4* xv = reinterpret_cast<const u32x4*>(x + (size_t)b * K);
+        u32x4* sv = reinterpret_cast<u32x4*>(xs + (size_t)b * K);
+        if (norm_w) {
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < nv; i += 256) {
+                u32x4 a = xv[i];
+                uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+                    ss += lo * lo + hi * hi;
+                }
+            }
+            const float rs = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
+            const u32x4* wv = reinterpret_cast<const u32x4*>(norm_w);
+            for (int i = threadIdx.x; i < nv; i += 256) {
+                u32x4 a = xv[i], wq = wv[i];
+                uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w}, o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = bf16_to_f32(f32_to_bf16(bf16lo_to_f32(aw[j]) * rs)) * bf16lo_to_f32(ww[j]);
+                    float hi = bf16_to_f32(f32_to_bf16(bf16hi_to_f32(aw[j]) * rs)) * bf16hi_to_f32(ww[j]);
+                    o[j] = pack_bf16x2(lo, hi);
+                }
+                u32x4 ov;
+                ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+                sv[i] = ov;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nv; i += 256) sv[i] = xv[i];
+        }
+    }
+    __syncthreads();
+
+    float best[NB];
+    int besti[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { best[b] = -INFINITY; besti[b] = 0x7fffffff; }
+
+    // rows handled by this block: [blockIdx.x * rows_per_block, +rows_per_block), waves interleave groups of R
+    const int rows_per_block = (V + gridDim.x - 1) / gridDim.x;
+    const int rbeg = blockIdx.x * rows_per_block;
+    const int rend = min(V, rbeg + rows_per_block);
+    for (int n0 = rbeg + wave * R; n0 < rend; n0 += 4 * R) {
+        float acc[NB][R];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[b][r] = 0.f;
+        const bf16_t* wrow[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)min(n0 + r, V - 1) * K;
+        for (int k = lane * 8; k < K; k += 512) {
+            u32x4 wq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) wq[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                u32x4 xq = *reinterpret_cast<const u32x4*>(xs + (size_t)b * K + k);
+                const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t ww[4] = {wq[r].x, wq[r].y, wq[r].z, wq[r].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[b][r] += bf16lo_to_f32(ww[j]) * bf16lo_to_f32(xw[j]);
+                        acc[b][r] += bf16hi_to_f32(ww[j]) * bf16hi_to_f32(xw[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float s = wave_sum(acc[b][r]);
+                const int n = n0 + r;
+                if (n < rend) {
+                    const bf16_t lb = f32_to_bf16(s);
+                    const float lv = bf16_to_f32(lb);
+                    if (logits && lane == 0) logits[(size_t)b * V + n] = lb;
+                    if (lv > best[b] || (lv == best[b] && n < besti[b])) { best[b] = lv; besti[b] = n; }
+                }
+            }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { bval[wave][b] = best[b]; bidx[wave][b] = besti[b]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int b = threadIdx.x;
+        float bv = bval[0][b];
+        int bi = bidx[0][b];
+        for (int w = 1; w < 4; ++w) {
+            if (bval[w][b] > bv || (bval[w][b] == bv && bidx[w][b] < bi)) { bv = bval[w][b]; bi = bidx[w][b]; }
+        }
+        pval[(size_t)b * gridDim.x + blockIdx.x] = bv;
+        pidx[(size_t)b * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                           int* __restrict__ out, int nparts) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const float v = pval[(size_t)b * nparts + i];
+        const int ix = pidx[(size_t)b * nparts + i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = sv[threadIdx.x + s];
+            const int ix = si[threadIdx.x + s];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) {
+                sv[threadIdx.x] = v;
+                si[threadIdx.x] = ix;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[b] = si[0];
+}
+
+// ----------------------------------------------------------------------------------------------
+// RoPE (half-rotation layout) on q and k + append of k, v into the KV cache.
+//   qkv   [rows, (n_q + 2 n_kv) * d]  (rows = B*S, output of the fused QKV projection)
+//   pos   [rows] rotary position;  slot [rows] cache index;  batch index = row / S
+//   cs    [max_pos, d] fp32: first d/2 = cos, last d/2 = sin (host computes them in fp32 exactly as the
+//         reference does, including llama3 scaling and attention_scaling, optionally pre-rounded to bf16)
+//   q_out [rows, n_q, d];  kc/vc [B, n_kv, T_max, d]
+// out = bf16( bf16(x*cos) + bf16(rot(x)*sin) )  -- bf16 arithmetic order of apply_rotary_pos_emb.
+// ----------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ pos,
+                                                      const int* __restrict__ slot, const float* __restrict__ cs,
+                                                      bf16_t* __restrict__ q_out, bf16_t* __restrict__ kc,
+                                                      bf16_t* __restrict__ vc, int S, int n_q, int n_kv, int T_max) {
+    const int row = blockIdx.x;
+    const int b = row / S;
+    const int p = pos[row], sl = slot[row];
+    const int nh = n_q + 2 * n_kv;
+    const bf16_t* src = qkv + (size_t)row * nh * D;
+    const float* c = cs + (size_t)p * D;
+    constexpr int HALF = D / 2;
+    // one thread per (head, pair index i < D/2)
+    for (int idx = threadIdx.x; idx < nh * HALF; idx += 256) {
+        const int h = idx / HALF, i = idx % HALF;
+        const float x1 = bf16_to_f32(src[h * D + i]);
+        const float x2 = bf16_to_f32(src[h * D + HALF + i]);
+        if (h < n_q + n_kv) {
+            const float co = c[i], si = c[HALF + i];
+            const float o1 = bf16_to_f32(f32_to_bf16(x1 * co)) + bf16_to_f32(f32_to_bf16(-x2 * si));
+            const float o2 = bf16_to_f32(f32_to_bf16(x2 * co)) + bf16_to_f32(f32_to_bf16(x1 * si));
+            if (h < n_q) {
+                bf16_t* dst = q_out + ((size_t)row * n_q + h) * D;
+                dst[i] = f32_to_bf16(o1);
+                dst[HALF + i] = f32_to_bf16(o2);
+            } else {
+                bf16_t* dst = kc + (((size_t)b * n_kv + (h - n_q)) * T_max + sl) * D;
+                dst[i] = f32_to_bf16(o1);
+                dst[HALF + i] = f32_to_bf16(o2);
+            }
+        } else {
+            bf16_t* dst = vc + (((size_t)b * n_kv + (h - n_q - n_kv)) * T_max + sl) * D;
+            dst[i] = src[h * D + i];
+            dst[HALF + i] = src[h * D + HALF + i];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Decode attention (one query token per sequence), GQA-aware, split over the KV length.
+// Block = (split, kv head, batch). The G = n_q / n_kv query heads of a kv head share every K/V row read:
+// a wave instruction loads 4 cache rows (16 lanes x 16 B each = 1 KiB, coalesced); the 16 lanes of a row
+// reduce the dot products by shuffles; softmax is online per wave in fp32; the 4 waves and the 4 row
+// sub-groups are merged through LDS. Partials (m, l, O) are combined by attn_combine_kernel.
+//   q [B, n_q, D] bf16;  kc/vc [B, n_kv, T_max, D];  kv_beg/kv_end [B]: valid cache slots [beg, end)
+// ----------------------------------------------------------------------------------------------
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ vc, const int* __restrict__ kv_beg,
+                                                          const int* __restrict__ kv_end, float* __restrict__ part_o,
+                                                          float* __restrict__ part_ml, bf16_t* __restrict__ out,
+                                                          int n_kv, int T_max, float scale, int nsplit) {
+    static_assert(D == 128, "decode attention is specialised for head_dim 128");
+    const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int n_q = n_kv * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4;        // which of the 4 rows of a wave instruction
+    const int dl = (lane & 15) * 8;   // this lane's 8 head-dim elements
+    const int beg = kv_beg ? kv_beg[b] : 0, end = kv_end[b];
+    const int len = max(end - beg, 0);
+    const int per = (len + nsplit - 1) / nsplit;
+    const int t0 = beg + split * per, t1 = min(end, t0 + per);
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(q + ((size_t)b * n_q + hk * G + g) * D + dl);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[g][2 * j] = bf16lo_to_f32(aw[j]) * scale;
+            qf[g][2 * j + 1] = bf16hi_to_f32(aw[j]) * scale;
+        }
+    }
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+    }
+    const bf16_t* kbase = kc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+    const bf16_t* vbase = vc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+
+    // The 16 lanes that share a cache row run the same trip count, and the in-loop shuffles (xor 1..8)
+    // never leave that 16-lane group, so row sub-groups may diverge at the tail.
+    for (int t = t0 + wave * 4 + sub; t < t1; t += 16) {
+        const u32x4 kq = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
+        const u32x4 vq = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
+        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
+        const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kf[2 * j] = bf16lo_to_f32(kw[j]);
+            kf[2 * j + 1] = bf16hi_to_f32(kw[j]);
+            vf[2 * j] = bf16lo_to_f32(vw[j]);
+            vf[2 * j + 1] = bf16hi_to_f32(vw[j]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qf[g][j] * kf[j];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            const float mn = fmaxf(m[g], s);
+            const float alpha = __expf(m[g] - mn);  // m = -inf on the first row -> 0
+            const float p = __expf(s - mn);
+            l[g] = l[g] * alpha + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * alpha + p * vf[j];
+            m[g] = mn;
+        }
+    }
+
+    // merge the 4 row sub-groups of the wave (lanes differing in bits 4,5), then the 4 waves via LDS
+    __shared__ float sm_m[4][G], sm_l[4][G];
+    __shared__ float sm_o[4][G][D];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m[g], off, 64);
+            const float l2 = __shfl_xor(l[g], off, 64);
+            const float mn = fmaxf(m[g], m2);
+            const float a1 = (m[g] == -INFINITY) ? 0.f : __expf(m[g] - mn);
+            const float a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+            l[g] = l[g] * a1 + l2 * a2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o2 = __shfl_xor(o[g][j], off, 64);
+                o[g][j] = o[g][j] * a1 + o2 * a2;
+            }
+            m[g] = mn;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm_o[wave][g][dl + j] = o[g][j];
+            if (lane == 0) { sm_m[wave][g] = m[g]; sm_l[wave][g] = l[g]; }
+        }
+    }
+    __syncthreads();
+    // final: thread (g, dd) for g < G, dd < D  -> G*D <= 7*128 = 896 values over 256 threads
+    for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+        const int g = idx / D, dd = idx % D;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm_m[w][g]);
+        float ll = 0.f, oo = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = (sm_m[w][g] == -INFINITY) ? 0.f : __expf(sm_m[w][g] - mm);
+            ll += sm_l[w][g] * a;
+            oo += sm_o[w][g][dd] * a;
+        }
+        const int hq = hk * G + g;
+        if (nsplit == 1) {
+            out[((size_t)b * n_q + hq) * D + dd] = f32_to_bf16(ll > 0.f ? oo / ll : 0.f);
+        } else {
+            const size_t pi = ((size_t)b * n_q + hq) * nsplit + split;
+            part_o[pi * D + dd] = oo;
+            if (dd == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(D) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                         bf16_t* __restrict__ out, int nsplit) {
+    const size_t bh = blockIdx.x;  // b * n_q + hq
+    const int dd = threadIdx.x;
+    float mm = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, part_ml[(bh * nsplit + s) * 2]);
+    float ll = 0.f, oo = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = part_ml[(bh * nsplit + s) * 2];
+        const float a = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
+        ll += part_ml[(bh * nsplit + s) * 2 + 1] * a;
+        oo += part_o[(bh * nsplit + s) * D + dd] * a;
+    }
+    out[bh * D + dd] = f32_to_bf16(ll > 0.f ? oo / ll : 0.f);
+}
+
+#define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
+    gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
+        (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
+        (const bf16_t*)norm_w, eps, N, K)
+
+template <int NB, bool GU>
+static int gemv_dispatch(const void* W, const void* x, void* out, const void* bias, const void* res,
+                         const void* norm_w, float eps, int N, int K, void* stream) {
+    const bool xlds = (size_t)NB * K * 2 <= 64 * 1024;
+    if (!xlds) SPIDER_CHECK(norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
+    constexpr int R = GU ? 1 : 2;
+    const int grid = (N + 4 * R - 1) / (4 * R);
+    if (xlds) GEMV_LAUNCH(NB, R, GU, true);
+    else GEMV_LAUNCH(NB, R, GU, false);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+template <bool GU>
+static int gemv_batch(const void* W, const void* x, void* out, const void* bias, const void* res, const void* norm_w,
+                      float eps, int B, int N, int K, void* stream) {
+    switch (B) {
+        case 1: return gemv_dispatch<1, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 2: return gemv_dispatch<2, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 3: return gemv_dispatch<3, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 4: return gemv_dispatch<4, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 5: return gemv_dispatch<5, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 6: return gemv_dispatch<6, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 7: return gemv_dispatch<7, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        case 8: return gemv_dispatch<8, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
+        default: spider_set_error("gemv: batch must be 1..8 (use spider_gemm_bf16 beyond that)"); return -1;
+    }
+}
+
+
+// ==============================================================================================
+// C ABI
+// ==============================================================================================
+extern "C" {
+
+int spider_embed_bf16(const void* table, const int* ids, void* out, int rows, int H, int V, void* stream) {
+    SPIDER_CHECK(rows > 0 && H > 0 && H % 8 == 0 && V > 0, "embed: bad shape (H must be a multiple of 8)");
+    embed_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)table, ids, (bf16_t*)out, H, V);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_rmsnorm_bf16(const void* x, const void* res, const void* w, void* y, void* res_out, int rows, int H,
+                        float eps, void* stream) {
+    SPIDER_CHECK(rows > 0 && H > 0 && H % 8 == 0 && H <= 8192, "rmsnorm: H must be a multiple of 8 and <= 8192");
+    rmsnorm_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)res, (const bf16_t*)w,
+                                                          (bf16_t*)y, (bf16_t*)res_out, H, eps);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_gemv_bf16(const void* W, const void* x, void* out, const void* bias, const void* res, const void* norm_w,
+                     float eps, int B, int N, int K, void* stream) {
+    SPIDER_CHECK(N > 0 && K > 0 && K % 8 == 0, "gemv: K must be a positive multiple of 8");
+    return gemv_batch<false>(W, x, out, bias, res, norm_w, eps, B, N, K, stream);
+}
+
+int spider_gemv_swiglu_bf16(const void* W_gate_up, const void* x, void* out, const void* norm_w, float eps, int B,
+                            int I, int K, void* stream) {
+    SPIDER_CHECK(I > 0 && K > 0 && K % 8 == 0, "gemv_swiglu: K must be a positive multiple of 8");
+    return gemv_batch<true>(W_gate_up, x, out, nullptr, nullptr, norm_w, eps, B, I, K, stream);
+}
+
+#define LMHEAD_LAUNCH(NB_)                                                                                     \
+    lmhead_partial_kernel<NB_, 2><<<nparts, 256, (size_t)NB_ * K * 2, (hipStream_t)stream>>>(                   \
+        (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)norm_w, eps, (float*)ws_val, (int*)ws_idx,          \
+        (bf16_t*)logits, V, K)
+
+int spider_lm_head_nparts(int V) {
+    int n = (V + 63) / 64;  // 64 rows per block
+    return n < 2048 ? (n < 1 ? 1 : n) : 2048;
+}
+
+int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w, float eps, int* out_ids, void* logits,
+                               void* ws_val, void* ws_idx, int B, int V, int K, void* stream) {
+    SPIDER_CHECK(B >= 1 && B <= 8, "lm_head_argmax: batch must be 1..8");
+    SPIDER_CHECK(V > 0 && K > 0 && K % 8 == 0 && (size_t)B * K * 2 <= 64 * 1024, "lm_head_argmax: bad K");
+    const int nparts = spider_lm_head_nparts(V);
+    switch (B) {
+        case 1: LMHEAD_LAUNCH(1); break;
+        case 2: LMHEAD_LAUNCH(2); break;
+        case 3: LMHEAD_LAUNCH(3); break;
+        case 4: LMHEAD_LAUNCH(4); break;
+        case 5: LMHEAD_LAUNCH(5); break;
+        case 6: LMHEAD_LAUNCH(6); break;
+        case 7: LMHEAD_LAUNCH(7); break;
+        default: LMHEAD_LAUNCH(8); break;
+    }
+    SPIDER_LAUNCH_OK();
+    argmax_final_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const float*)ws_val, (const int*)ws_idx, out_ids, nparts);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_rope_kv_append_bf16(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out,
+                               void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
+                               void* stream) {
+    SPIDER_CHECK(B > 0 && S > 0 && n_q > 0 && n_kv > 0 && T_max > 0, "rope_kv_append: bad shape");
+    SPIDER_CHECK(d == 128 || d == 64, "rope_kv_append: head_dim must be 64 or 128");
+    if (d == 128)
+        rope_kv_kernel<128><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos, slot, cos_sin, (bf16_t*)q_out,
+                                                                    (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max);
+    else
+        rope_kv_kernel<64><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos, slot, cos_sin, (bf16_t*)q_out,
+                                                                   (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+#define ATTN_DEC_LAUNCH(G_)                                                                                     \
+    attn_decode_kernel<128, G_><<<grid, 256, 0, (hipStream_t)stream>>>(                                         \
+        (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, kv_beg, kv_end, (float*)ws_o,          \
+        (float*)ws_ml, (bf16_t*)out, n_kv, T_max, scale, nsplit)
+
+// workspace: ws_o >= B*n_q*nsplit*d floats, ws_ml >= B*n_q*nsplit*2 floats (unused when nsplit == 1)
+int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_cache, const int* kv_beg,
+                            const int* kv_end, void* out, void* ws_o, void* ws_ml, int B, int n_q, int n_kv, int d,
+                            int T_max, float scale, int nsplit, void* stream) {
+    SPIDER_CHECK(d == 128, "attn_decode: head_dim must be 128");
+    SPIDER_CHECK(B > 0 && n_kv > 0 && n_q % n_kv == 0 && nsplit >= 1 && T_max > 0, "attn_decode: bad shape");
+    SPIDER_CHECK(nsplit == 1 || (ws_o && ws_ml), "attn_decode: workspace required for nsplit > 1");
+    const int G = n_q / n_kv;
+    dim3 grid(nsplit, n_kv, B);
+    switch (G) {
+        case 1: ATTN_DEC_LAUNCH(1); break;
+        case 2: ATTN_DEC_LAUNCH(2); break;
+        case 4: ATTN_DEC_LAUNCH(4); break;
+        case 7: ATTN_DEC_LAUNCH(7); break;
+        case 8: ATTN_DEC_LAUNCH(8); break;
+        default: spider_set_error("attn_decode: GQA group size must be one of 1,2,4,7,8"); return -1;
+    }
+    SPIDER_LAUNCH_OK();
+    if (nsplit > 1) {
+        attn_combine_kernel<128><<<B * n_q, 128, 0, (hipStream_t)stream>>>((const float*)ws_o, (const float*)ws_ml,
+                                                                          (bf16_t*)out, nsplit);
+        SPIDER_LAUNCH_OK();
+    }
+    return 0;
+}
+
+}  // extern "C"

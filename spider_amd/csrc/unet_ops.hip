@@ -1,0 +1,567 @@
+// HBM-bound UNet / VAE / text-encoder operators on NHWC bf16 activations (gfx950).
+//
+// Reference call sites: the diffusion loop of spider/models/custom_sd.py:627-652 calls
+// UNet2DConditionModel.forward (external diffusers==0.25.0); these kernels implement its
+// GroupNorm(32)+SiLU (ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out), LayerNorm
+// (BasicTransformerBlock.norm1/2/3), GEGLU (FeedForward), skip concat (UpBlock2D), conv_in / conv_out,
+// plus the classifier-free-guidance combine (custom_sd.py:642-644) and the scheduler linear update
+// (custom_sd.py:647). All statistics are fp32; activations are vectorised 16 B per lane.
+#include "common.hpp"
+
+using namespace spider;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm, pass 1: per (batch, pixel-chunk) partial sums of every group.
+// Block = (C/8)*KP threads: thread -> fixed 8-channel vector, pixel lane; so per-channel sums live
+// in registers and are reduced over pixel lanes through LDS. partial: [B, nchunk, G, 2] fp32.
+// ------------------------------------------------------------------------------------------
+__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
+                                int nchunk, int KP) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ch_sum = reinterpret_cast<float*>(smem);   // [C]
+    float* ch_sq = ch_sum + C;                         // [C]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cv = C / 8;
+    const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) ch_sum[i] = 0.f;
+    __syncthreads();
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const bf16_t* xb = x + (size_t)b * HW * C;
+    for (int px = p0 + pl; px < p1; px += KP) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(xb + (size_t)px * C + v * 8);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+            s[2 * j] += lo; q[2 * j] += lo * lo;
+            s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        atomicAdd(&ch_sum[v * 8 + j], s[j]);
+        atomicAdd(&ch_sq[v * 8 + j], q[j]);
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float gs = 0.f, gq = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { gs += ch_sum[c]; gq += ch_sq[c]; }
+        float* dst = partial + (((size_t)b * nchunk + chunk) * G + g) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
+    }
+}
+
+// GroupNorm, pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU; output bf16.
+// Rounds once after the affine (as torch's GroupNorm does) and once more after SiLU.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
+                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
+                                                       float eps, int silu, int pix_per_block) {
+    __shared__ float mean[64], rstd[64];
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    if (threadIdx.x < G) {
+        float gs = 0.f, gq = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            const float* src = partial + (((size_t)b * nchunk + c) * G + threadIdx.x) * 2;
+            gs += src[0];
+            gq += src[1];
+        }
+        const float n = (float)HW * (float)cpg;
+        const float mu = gs / n;
+        const float var = fmaxf(gq / n - mu * mu, 0.f);
+        mean[threadIdx.x] = mu;
+        rstd[threadIdx.x] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int cv = C / 8;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const size_t base = (size_t)b * HW * C;
+    for (int idx = p0 * cv + threadIdx.x; idx < p1 * cv; idx += 256) {
+        const int v = idx % cv;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(x + base + (size_t)idx * 8);
+        const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + v * 8);
+        const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + v * 8);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = v * 8 + j;
+            const int g = c / cpg;
+            const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
+            const float ga = (j & 1) ? bf16hi_to_f32(gw[j >> 1]) : bf16lo_to_f32(gw[j >> 1]);
+            const float be = (j & 1) ? bf16hi_to_f32(bw[j >> 1]) : bf16lo_to_f32(bw[j >> 1]);
+            float t = (xv - mean[g]) * rstd[g] * ga + be;
+            if (silu) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
+            o[j] = t;
+        }
+        u32x4 ov;
+        ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
+        ov.z = pack_bf16x2(o[4], o[5]); ov.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<u32x4*>(y + base + (size_t)idx * 8) = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (C <= 8192, multiple of 8), affine, fp32 statistics (two-pass in registers).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
+                                                        const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int C,
+                                                        float eps) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const int nv = C / 8;
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x + row * C);
+    float h[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nv) {
+            const u32x4 a = xv[i];
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[it][2 * j] = bf16lo_to_f32(aw[j]);
+                h[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                s += h[it][2 * j] + h[it][2 * j + 1];
+            }
+        }
+    }
+    const float mu = block_sum<4>(s, red) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = h[it][j] - mu; q += dlt * dlt; }
+        }
+    }
+    const float rs = rsqrtf(block_sum<4>(q, red) / (float)C + eps);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        if (i < nv) {
+            const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + i * 8);
+            const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + i * 8);
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = (h[it][2 * j] - mu) * rs * bf16lo_to_f32(gw[j]) + bf16lo_to_f32(bw[j]);
+                const float hi = (h[it][2 * j + 1] - mu) * rs * bf16hi_to_f32(gw[j]) + bf16hi_to_f32(bw[j]);
+                o[j] = pack_bf16x2(lo, hi);
+            }
+            u32x4 ov;
+            ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+            *reinterpret_cast<u32x4*>(y + row * C + i * 8) = ov;
+        }
+    }
+}
+
+// GEGLU: y[m, n] = bf16( x[m, n] * bf16(gelu(x[m, inner + n])) ), x [M, 2*inner]
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t total_vec,
+                                                    int inner) {
+    const int iv = inner / 8;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (size_t)gridDim.x * 256) {
+        const size_t m = idx / iv;
+        const int v = (int)(idx % iv);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(x + m * 2 * inner + v * 8);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(x + m * 2 * inner + inner + v * 8);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = bf16lo_to_f32(aw[j]) * bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16lo_to_f32(gw[j]))));
+            const float hi = bf16hi_to_f32(aw[j]) * bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16hi_to_f32(gw[j]))));
+            o[j] = pack_bf16x2(lo, hi);
+        }
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + m * inner + v * 8) = ov;
+    }
+}
+
+// SwiGLU on a fused [gate | up] projection: y[m, n] = bf16( bf16(silu(x[m, n])) * x[m, inner + n] )
+// (prefill form of modeling_llama3.py:197-199; the decode form is fused into gemv_swiglu)
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t total_vec,
+                                                     int inner) {
+    const int iv = inner / 8;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (size_t)gridDim.x * 256) {
+        const size_t m = idx / iv;
+        const int v = (int)(idx % iv);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(x + m * 2 * inner + v * 8);
+        const u32x4 u = *reinterpret_cast<const u32x4*>(x + m * 2 * inner + inner + v * 8);
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = bf16_to_f32(f32_to_bf16(silu_f(bf16lo_to_f32(gw[j])))) * bf16lo_to_f32(uw[j]);
+            const float hi = bf16_to_f32(f32_to_bf16(silu_f(bf16hi_to_f32(gw[j])))) * bf16hi_to_f32(uw[j]);
+            o[j] = pack_bf16x2(lo, hi);
+        }
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + m * inner + v * 8) = ov;
+    }
+}
+
+// channel concat of two NHWC tensors: y[r, :C1] = a[r], y[r, C1:] = b[r]
+__global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                     bf16_t* __restrict__ y, size_t rows, int C1, int C2) {
+    const int cv = (C1 + C2) / 8, c1v = C1 / 8;
+    const size_t total = rows * cv;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t r = idx / cv;
+        const int v = (int)(idx % cv);
+        const u32x4 t = v < c1v ? *reinterpret_cast<const u32x4*>(a + r * C1 + v * 8)
+                                : *reinterpret_cast<const u32x4*>(b + r * C2 + (v - c1v) * 8);
+        *reinterpret_cast<u32x4*>(y + idx * 8) = t;
+    }
+}
+
+// elementwise unary on bf16 (act: 1 silu, 2 gelu, 3 quick-gelu), n multiple of 8
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t nvec, int act) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(x + idx * 8);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+            if (act == 1) { lo = silu_f(lo); hi = silu_f(hi); }
+            else if (act == 2) { lo = gelu_erf_f(lo); hi = gelu_erf_f(hi); }
+            else if (act == 3) { lo = quick_gelu_f(lo); hi = quick_gelu_f(hi); }
+            o[j] = pack_bf16x2(lo, hi);
+        }
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
+    }
+}
+
+// y = bf16(a + b) elementwise
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                  bf16_t* __restrict__ y, size_t nvec) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+        const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
+        const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
+        const uint32_t pw[4] = {p.x, p.y, p.z, p.w}, qw[4] = {q.x, q.y, q.z, q.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(bf16lo_to_f32(pw[j]) + bf16lo_to_f32(qw[j]), bf16hi_to_f32(pw[j]) + bf16hi_to_f32(qw[j]));
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small convolutions that do not fit the MFMA tile (Cin = 4 conv_in, Cout = 3/4 conv_out).
+// ------------------------------------------------------------------------------------------
+// Cin <= 8: one thread per (pixel, 8 output channels). w [Cout, ks, ks, Cin] staged in LDS as fp32.
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
+                                                             int B, int H, int W, int Cin, int Cout, int ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = reinterpret_cast<float*>(smem);
+    const int kk = ks * ks * Cin;
+    for (int i = threadIdx.x; i < Cout * kk; i += 256) ws[i] = bf16_to_f32(w[i]);
+    __syncthreads();
+    const int cov = Cout / 8;
+    const size_t total = (size_t)B * H * W * cov;
+    const int pad = ks / 2;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int v = (int)(idx % cov);
+        const size_t pix = idx / cov;
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? bf16_to_f32(bias[v * 8 + j]) : 0.f;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int iy = oy + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int ix = ox + kx - pad;
+                if (ix < 0 || ix >= W) continue;
+                const bf16_t* src = x + (((size_t)b * H + iy) * W + ix) * Cin;
+                for (int c = 0; c < Cin; ++c) {
+                    const float xv = bf16_to_f32(src[c]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += xv * ws[(v * 8 + j) * kk + (ky * ks + kx) * Cin + c];
+                }
+            }
+        }
+        u32x4 ov;
+        ov.x = pack_bf16x2(acc[0], acc[1]); ov.y = pack_bf16x2(acc[2], acc[3]);
+        ov.z = pack_bf16x2(acc[4], acc[5]); ov.w = pack_bf16x2(acc[6], acc[7]);
+        *reinterpret_cast<u32x4*>(y + pix * Cout + v * 8) = ov;
+    }
+}
+
+// Cout <= 4: one wave per output pixel, lanes split K = ks*ks*Cin (Cin % 8 == 0), shuffle reduce.
+// Output fp32 [B, H, W, Cout] (conv_out feeds the scheduler / image, keep full precision) or bf16.
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const bf16_t* __restrict__ bias, float* __restrict__ y32,
+                                                              bf16_t* __restrict__ y16, int B, int H, int W, int Cin,
+                                                              int Cout, int ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* ws = reinterpret_cast<bf16_t*>(smem);  // [Cout][ks*ks*Cin]
+    const int kk = ks * ks * Cin;
+    for (int i = threadIdx.x; i < Cout * kk / 8; i += 256)
+        reinterpret_cast<u32x4*>(ws)[i] = reinterpret_cast<const u32x4*>(w)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t npix = (size_t)B * H * W;
+    const int pad = ks / 2;
+    const int cvn = Cin / 8;
+    for (size_t pix = (size_t)blockIdx.x * 4 + wave; pix < npix; pix += (size_t)gridDim.x * 4) {
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = lane; i < ks * ks * cvn; i += 64) {
+            const int tap = i / cvn, cvi = i % cvn;
+            const int iy = oy + tap / ks - pad, ix = ox + tap % ks - pad;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * Cin + cvi * 8);
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            for (int co = 0; co < Cout; ++co) {
+                const u32x4 wq = *reinterpret_cast<const u32x4*>(ws + (size_t)co * kk + tap * Cin + cvi * 8);
+                const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[co] += bf16lo_to_f32(aw[j]) * bf16lo_to_f32(ww[j]) + bf16hi_to_f32(aw[j]) * bf16hi_to_f32(ww[j]);
+            }
+        }
+        for (int co = 0; co < Cout; ++co) {
+            const float t = wave_sum(acc[co]) + (bias ? bf16_to_f32(bias[co]) : 0.f);
+            if (lane == 0) {
+                if (y32) y32[pix * Cout + co] = t;
+                else y16[pix * Cout + co] = f32_to_bf16(t);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Latent plumbing around the UNet call (custom_sd.py:631-647). Latents stay fp32 NCHW on the scheduler
+// side (the reference keeps them in the pipeline dtype; fp32 here so 40 scheduler updates do not
+// accumulate bf16 rounding) and are converted to bf16 NHWC only as UNet input.
+// ------------------------------------------------------------------------------------------
+// out[rep, b, y, x, c] = bf16(lat[b, c, y, x] * scale) for rep < reps   (torch.cat([latents]*2) + scale_model_input)
+__global__ __launch_bounds__(256) void latent_in_kernel(const float* __restrict__ lat, bf16_t* __restrict__ out, int B, int C,
+                                                        int HW, int reps, float scale) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const size_t px = (idx / C) % HW;
+        const size_t b = idx / ((size_t)C * HW);
+        const bf16_t v = f32_to_bf16(lat[(b * C + c) * HW + px] * scale);
+        for (int r = 0; r < reps; ++r) out[(size_t)r * total + idx] = v;
+    }
+}
+
+// eps[b, c, px] = e_u + g * (e_c - e_u) from UNet output e [2, B, HW, C] (fp32 NHWC); out fp32 NCHW.
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ e, float* __restrict__ out, int B, int C,
+                                                          int HW, float g) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const size_t px = (idx / C) % HW;
+        const size_t b = idx / ((size_t)C * HW);
+        const float eu = e[idx], ec = e[total + idx];
+        out[(b * C + c) * HW + px] = eu + g * (ec - eu);
+    }
+}
+
+struct LinComb {
+    const float* in[6];
+    float coef[6];
+    int n;
+};
+// out = sum_j coef[j] * in[j]   (scheduler.step as a linear update of the sample and stored eps history)
+__global__ __launch_bounds__(256) void lincomb_kernel(LinComb lc, float* __restrict__ out, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int j = 0; j < lc.n; ++j) a += lc.coef[j] * lc.in[j][idx];
+        out[idx] = a;
+    }
+}
+
+// fp32 NHWC [B,HW,C] -> fp32 NCHW [B,C,HW] with affine (VAE image post-process: x/2 + 0.5, clamp 0..1)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                           int HW, float mul, float add, int clamp01) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const size_t px = (idx / C) % HW;
+        const size_t b = idx / ((size_t)C * HW);
+        float v = x[idx] * mul + add;
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        y[(b * C + c) * HW + px] = v;
+    }
+}
+
+inline int grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int spider_groupnorm_nchunk(int HW) {
+    int n = HW / 128;
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+// x, y [B, HW, C] bf16 (NHWC); ws >= B * nchunk * G * 2 floats, nchunk = spider_groupnorm_nchunk(HW)
+int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream) {
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "groupnorm: bad shape (G <= 64)");
+    SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
+    const int nchunk = spider_groupnorm_nchunk(HW);
+    const int cv = C / 8;
+    int KP = 256 / cv;
+    if (KP < 1) KP = 1;
+    const int threads = cv * KP;
+    SPIDER_CHECK(threads <= 1024, "groupnorm: C too large");
+    dim3 g1(nchunk, B);
+    gn_stats_kernel<<<g1, threads, (size_t)2 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
+                                                                                       G, nchunk, KP);
+    SPIDER_LAUNCH_OK();
+    int ppb = (8 * 256 * 4) / C;  // ~8K elements per thread block iteration set
+    if (ppb < 1) ppb = 1;
+    dim3 g2((HW + ppb - 1) / ppb, B);
+    gn_apply_kernel<<<g2, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
+                                                         (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, silu, ppb);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                          void* stream) {
+    SPIDER_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 8192, "layernorm: C must be a multiple of 8 and <= 8192");
+    layernorm_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                           (bf16_t*)y, C, eps);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_geglu_bf16(const void* x, void* y, int M, int inner, void* stream) {
+    SPIDER_CHECK(M > 0 && inner > 0 && inner % 8 == 0, "geglu: inner must be a multiple of 8");
+    const size_t nvec = (size_t)M * (inner / 8);
+    geglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, nvec, inner);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_swiglu_bf16(const void* x, void* y, int M, int inner, void* stream) {
+    SPIDER_CHECK(M > 0 && inner > 0 && inner % 8 == 0, "swiglu: inner must be a multiple of 8");
+    const size_t nvec = (size_t)M * (inner / 8);
+    swiglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, nvec, inner);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_concat_channels_bf16(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream) {
+    SPIDER_CHECK(rows > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "concat: channels must be multiples of 8");
+    const size_t nvec = (size_t)rows * ((C1 + C2) / 8);
+    concat_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+                                                                  (size_t)rows, C1, C2);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_act_bf16(const void* x, void* y, long n, int act, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0 && act >= 1 && act <= 3, "act: n must be a multiple of 8, act in 1..3");
+    act_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, (size_t)n / 8, act);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_add_bf16(const void* a, const void* b, void* y, long n, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0, "add: n must be a multiple of 8");
+    add_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+                                                                        (size_t)n / 8);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// conv with Cin <= 8 (conv_in). x [B,H,W,Cin], w [Cout,ks,ks,Cin], y [B,H,W,Cout]; stride 1, same padding.
+int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+                                 int Cout, int ks, void* stream) {
+    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 8 && Cout % 8 == 0, "conv_small_cin: Cin <= 8, Cout % 8 == 0");
+    SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cin: kernel size must be 1 or 3");
+    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(float);
+    SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cin: weights exceed LDS");
+    const size_t total = (size_t)B * H * W * (Cout / 8);
+    conv_small_cin_kernel<<<grid_for(total), 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
+                                                                               (const bf16_t*)bias, (bf16_t*)y, B, H, W,
+                                                                               Cin, Cout, ks);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// conv with Cout <= 4 (conv_out). Exactly one of y32 (fp32) / y16 (bf16) is written, layout [B,H,W,Cout].
+int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
+                                  int W, int Cin, int Cout, int ks, void* stream) {
+    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "conv_small_cout: Cout <= 4, Cin % 8 == 0");
+    SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cout: kernel size must be 1 or 3");
+    SPIDER_CHECK((y32 != nullptr) != (y16 != nullptr), "conv_small_cout: give exactly one output");
+    SPIDER_CHECK((Cout * ks * ks * Cin) % 8 == 0, "conv_small_cout: weight count must be a multiple of 8");
+    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(bf16_t);
+    SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cout: weights exceed LDS");
+    const size_t npix = (size_t)B * H * W;
+    size_t grid = (npix + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    conv_small_cout_kernel<<<(int)grid, 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
+                                                                         (const bf16_t*)bias, (float*)y32, (bf16_t*)y16, B,
+                                                                         H, W, Cin, Cout, ks);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_latent_to_nhwc_bf16(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream) {
+    SPIDER_CHECK(B > 0 && C > 0 && HW > 0 && reps >= 1, "latent_to_nhwc: bad shape");
+    latent_in_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(lat, (bf16_t*)out, B, C, HW, reps, scale);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_cfg_combine_f32(const float* eps2, float* out, int B, int C, int HW, float guidance, void* stream) {
+    SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "cfg_combine: bad shape");
+    cfg_combine_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(eps2, out, B, C, HW, guidance);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_lincomb_f32(const float* const* ins, const float* coefs, int n, float* out, long total, void* stream) {
+    SPIDER_CHECK(n >= 1 && n <= 6 && total > 0, "lincomb: 1..6 terms");
+    LinComb lc{};
+    lc.n = n;
+    for (int j = 0; j < n; ++j) { lc.in[j] = ins[j]; lc.coef[j] = coefs[j]; }
+    lincomb_kernel<<<grid_for((size_t)total), 256, 0, (hipStream_t)stream>>>(lc, out, (size_t)total);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream) {
+    SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad shape");
+    nhwc_to_nchw_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(x, y, B, C, HW, mul, add, clamp01);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""ctypes binding of libspider_hip.so (C ABI declared in include/spider_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing or a call fails, this
+module raises. Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C spider_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspider_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+# name -> (restype, argtypes); mirrors include/spider_hip.h one-to-one
+SIGNATURES = {
+    "spider_abi_version": (_i, []),
+    "spider_target_arch": (C.c_char_p, []),
+    "spider_last_error": (C.c_char_p, []),
+    "spider_embed_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "spider_rmsnorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "spider_gemv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "spider_gemv_swiglu_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "spider_lm_head_nparts": (_i, [_i]),
+    "spider_lm_head_argmax_bf16": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "spider_rope_kv_append_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "spider_attn_decode_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "spider_attn_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "spider_groupnorm_nchunk": (_i, [_i]),
+    "spider_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "spider_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "spider_geglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "spider_swiglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "spider_concat_channels_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "spider_act_bf16": (_i, [_vp, _vp, _l, _i, _vp]),
+    "spider_add_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "spider_conv2d_small_cin_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "spider_conv2d_small_cout_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "spider_latent_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "spider_cfg_combine_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "spider_lincomb_f32": (_i, [_vp, _vp, _i, _vp, _l, _vp]),
+    "spider_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+}
+
+
+class SpiderHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libspider_hip.so (once) and attach the prototypes. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SpiderHipError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.spider_abi_version() != 1:
+            raise SpiderHipError("libspider_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point; raise SpiderHipError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.spider_last_error().decode("utf-8", "replace")
+        raise SpiderHipError(f"{name} failed (rc={rc}): {msg}")

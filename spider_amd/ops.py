@@ -1,0 +1,337 @@
+"""Torch-tensor front end of the C ABI (spider_amd/lib.py -> libspider_hip.so).
+
+PyTorch is used here only for device memory and streams: every function checks shapes/dtypes on the
+host, passes raw device pointers + sizes to the HIP library and enqueues on torch's current stream
+(so the calls can be captured by ``torch.cuda.graph``). Nothing falls back to torch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+BF16 = torch.bfloat16
+ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+# --------------------------------------------------------------------------- LLM decode
+def embed(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    _chk(table, BF16, "table"); _chk(ids, torch.int32, "ids")
+    V, H = table.shape
+    out = torch.empty(*ids.shape, H, dtype=BF16, device=table.device)
+    _lib.call("spider_embed_bf16", _p(table), _p(ids), _p(out), ids.numel(), H, V, _stream())
+    return out
+
+
+def rmsnorm(x, w, eps, res=None, res_out=None, out=None):
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    H = x.shape[-1]
+    rows = x.numel() // H
+    if out is None:
+        out = torch.empty_like(x)
+    if res is not None:
+        _chk(res, BF16, "res")
+    _lib.call("spider_rmsnorm_bf16", _p(x), _p(res), _p(w), _p(out), _p(res_out), rows, H, float(eps), _stream())
+    return out
+
+
+def gemv(W, x, bias=None, res=None, norm_w=None, eps=0.0, out=None):
+    """out[b,n] = sum_k xin[b,k] W[n,k] (+bias) (+res); xin = rmsnorm(x)*norm_w if norm_w is given. 1 <= B <= 8."""
+    _chk(W, BF16, "W"); _chk(x, BF16, "x")
+    N, K = W.shape
+    B = x.numel() // K
+    if out is None:
+        out = torch.empty(B, N, dtype=BF16, device=x.device)
+    _lib.call("spider_gemv_bf16", _p(W), _p(x), _p(out), _p(bias), _p(res), _p(norm_w), float(eps), B, N, K, _stream())
+    return out
+
+
+def gemv_swiglu(W_gate_up, x, norm_w=None, eps=0.0, out=None):
+    _chk(W_gate_up, BF16, "W_gate_up"); _chk(x, BF16, "x")
+    I2, K = W_gate_up.shape
+    I = I2 // 2
+    B = x.numel() // K
+    if out is None:
+        out = torch.empty(B, I, dtype=BF16, device=x.device)
+    _lib.call("spider_gemv_swiglu_bf16", _p(W_gate_up), _p(x), _p(out), _p(norm_w), float(eps), B, I, K, _stream())
+    return out
+
+
+def lm_head_nparts(V: int) -> int:
+    return _lib.load().spider_lm_head_nparts(V)
+
+
+def lm_head_argmax(W, x, norm_w=None, eps=0.0, out_ids=None, logits=None, ws=None):
+    _chk(W, BF16, "W"); _chk(x, BF16, "x")
+    V, K = W.shape
+    B = x.numel() // K
+    npart = lm_head_nparts(V)
+    if ws is None:
+        ws = (torch.empty(B * npart, dtype=torch.float32, device=x.device),
+              torch.empty(B * npart, dtype=torch.int32, device=x.device))
+    if out_ids is None:
+        out_ids = torch.empty(B, dtype=torch.int32, device=x.device)
+    _lib.call("spider_lm_head_argmax_bf16", _p(W), _p(x), _p(norm_w), float(eps), _p(out_ids), _p(logits),
+              _p(ws[0]), _p(ws[1]), B, V, K, _stream())
+    return out_ids
+
+
+def rope_kv_append(qkv, pos, slot, cos_sin, q_out, k_cache, v_cache, B, S, n_q, n_kv, d):
+    _chk(qkv, BF16, "qkv"); _chk(pos, torch.int32, "pos"); _chk(slot, torch.int32, "slot")
+    _chk(cos_sin, torch.float32, "cos_sin"); _chk(q_out, BF16, "q_out")
+    _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache")
+    T_max = k_cache.shape[2]
+    assert qkv.numel() == B * S * (n_q + 2 * n_kv) * d and pos.numel() == B * S and slot.numel() == B * S
+    assert k_cache.shape[0] >= B and k_cache.shape[1] == n_kv and k_cache.shape[3] == d
+    assert cos_sin.shape[1] == d
+    _lib.call("spider_rope_kv_append_bf16", _p(qkv), _p(pos), _p(slot), _p(cos_sin), _p(q_out), _p(k_cache),
+              _p(v_cache), B, S, n_q, n_kv, d, T_max, _stream())
+    return q_out
+
+
+def attn_decode(q, k_cache, v_cache, kv_end, kv_beg=None, nsplit=1, ws=None, out=None, scale=None):
+    _chk(q, BF16, "q"); _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache"); _chk(kv_end, torch.int32, "kv_end")
+    B, n_q, d = q.shape
+    n_kv, T_max = k_cache.shape[1], k_cache.shape[2]
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    if out is None:
+        out = torch.empty(B, n_q * d, dtype=BF16, device=q.device)
+    if nsplit > 1 and ws is None:
+        ws = (torch.empty(B * n_q * nsplit * d, dtype=torch.float32, device=q.device),
+              torch.empty(B * n_q * nsplit * 2, dtype=torch.float32, device=q.device))
+    _lib.call("spider_attn_decode_bf16", _p(q), _p(k_cache), _p(v_cache), _p(kv_beg), _p(kv_end), _p(out),
+              _p(ws[0]) if ws else None, _p(ws[1]) if ws else None, B, n_q, n_kv, d, T_max, float(scale), nsplit, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- GEMM / conv / attention
+def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, out_scale=1.0, out=None, out_f32=False):
+    """C = act(A @ W^T + bias + rowbias[row // rows_per_group]) (+ res) * out_scale.  A [..., K], W [N, K]."""
+    _chk(A, BF16, "A"); _chk(W, BF16, "W")
+    N, K = W.shape
+    assert A.shape[-1] == K, f"gemm: A[..., {A.shape[-1]}] vs W[{N},{K}]"
+    M = A.numel() // K
+    if out is None:
+        out = torch.empty(*A.shape[:-1], N, dtype=torch.float32 if out_f32 else BF16, device=A.device)
+    c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
+    _lib.call("spider_gemm_bf16", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
+              M, N, K, K, N, ACT[act], float(out_scale), _stream())
+    return out
+
+
+def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None):
+    """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]."""
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    B, H, Wd, Cin = x.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    if pad is None:
+        pad = ks // 2
+    Hs, Ws = (H * 2, Wd * 2) if ups else (H, Wd)
+    Ho, Wo = (Hs + 2 * pad - ks) // stride + 1, (Ws + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+    _lib.call("spider_conv2d_nhwc_bf16", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
+              ks, stride, pad, int(ups), float(out_scale), _stream())
+    return out
+
+
+def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_off=None, kv_beg=None,
+              keep_bits=None, blk=0, q_off=0, out=None):
+    """q [B,Lq,Hq*d], k/v [B,Lk,Hkv*d] (last dim contiguous; batch/row strides free) -> [B,Lq,Hq*d]."""
+    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    B, Lq, Cq = q.shape
+    Lk = k.shape[1]
+    Hq = n_heads
+    Hkv = n_kv_heads or n_heads
+    d = Cq // Hq
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    if kv_off is None:
+        kv_off = Lk - Lq
+    if out is None:
+        out = torch.empty(B, Lq, Cq, dtype=BF16, device=q.device)
+    _lib.call("spider_attn_bf16", _p(q), _p(k), _p(v), _p(out),
+              q.stride(0), d, q.stride(1), k.stride(0), d, k.stride(1), v.stride(0), d, v.stride(1),
+              out.stride(0), d, out.stride(1),
+              B, Hq, Hkv, Lq, Lk, d, float(scale), int(causal), int(kv_off), _p(kv_beg), _p(keep_bits), blk, q_off,
+              _stream())
+    return out
+
+
+def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=None, kv_beg=None, out=None):
+    """Prefill attention against the KV cache. q [B,S,n_q,d]; caches [B,n_kv,T_max,d]; keys [0, Lk)."""
+    _chk(q, BF16, "q"); _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache")
+    B, S, n_q, d = q.shape
+    n_kv, T_max = k_cache.shape[1], k_cache.shape[2]
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    if kv_off is None:
+        kv_off = Lk - S
+    if out is None:
+        out = torch.empty(B, S, n_q * d, dtype=BF16, device=q.device)
+    _lib.call("spider_attn_bf16", _p(q), _p(k_cache), _p(v_cache), _p(out),
+              S * n_q * d, d, n_q * d, n_kv * T_max * d, T_max * d, d, n_kv * T_max * d, T_max * d, d,
+              S * n_q * d, d, n_q * d,
+              B, n_q, n_kv, S, Lk, d, float(scale), int(causal), int(kv_off), _p(kv_beg), None, 0, 0, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- UNet elementwise
+def groupnorm_nchunk(HW: int) -> int:
+    return _lib.load().spider_groupnorm_nchunk(HW)
+
+
+def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None):
+    """x [B, ..., C] NHWC bf16."""
+    _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    B, Cn = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cn)
+    if out is None:
+        out = torch.empty_like(x)
+    if ws is None:
+        ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.call("spider_groupnorm_nhwc_bf16", _p(x), _p(gamma), _p(beta), _p(out), _p(ws), B, HW, Cn, groups, float(eps),
+              int(silu), _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    Cn = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("spider_layernorm_bf16", _p(x), _p(gamma), _p(beta), _p(out), x.numel() // Cn, Cn, float(eps), _stream())
+    return out
+
+
+def geglu(x, out=None):
+    _chk(x, BF16, "x")
+    inner = x.shape[-1] // 2
+    M = x.numel() // (2 * inner)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], inner, dtype=BF16, device=x.device)
+    _lib.call("spider_geglu_bf16", _p(x), _p(out), M, inner, _stream())
+    return out
+
+
+def swiglu(x, out=None):
+    _chk(x, BF16, "x")
+    inner = x.shape[-1] // 2
+    M = x.numel() // (2 * inner)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], inner, dtype=BF16, device=x.device)
+    _lib.call("spider_swiglu_bf16", _p(x), _p(out), M, inner, _stream())
+    return out
+
+
+def concat_channels(a, b, out=None):
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    C1, C2 = a.shape[-1], b.shape[-1]
+    rows = a.numel() // C1
+    assert b.numel() // C2 == rows
+    if out is None:
+        out = torch.empty(*a.shape[:-1], C1 + C2, dtype=BF16, device=a.device)
+    _lib.call("spider_concat_channels_bf16", _p(a), _p(b), _p(out), rows, C1, C2, _stream())
+    return out
+
+
+def act(x, kind: str, out=None):
+    _chk(x, BF16, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("spider_act_bf16", _p(x), _p(out), x.numel(), ACT[kind], _stream())
+    return out
+
+
+def add(a, b, out=None):
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("spider_add_bf16", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def conv2d_small_cin(x, w, bias=None, out=None):
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    B, H, Wd, Cin = x.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    if out is None:
+        out = torch.empty(B, H, Wd, Cout, dtype=BF16, device=x.device)
+    _lib.call("spider_conv2d_small_cin_bf16", _p(x), _p(w), _p(bias), _p(out), B, H, Wd, Cin, Cout, ks, _stream())
+    return out
+
+
+def conv2d_small_cout(x, w, bias=None, out_f32=True, out=None):
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    B, H, Wd, Cin = x.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    if out is None:
+        out = torch.empty(B, H, Wd, Cout, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    y32, y16 = (out, None) if out.dtype == torch.float32 else (None, out)
+    _lib.call("spider_conv2d_small_cout_bf16", _p(x), _p(w), _p(bias), _p(y32), _p(y16), B, H, Wd, Cin, Cout, ks, _stream())
+    return out
+
+
+def latent_to_nhwc(lat, reps=1, scale=1.0, out=None):
+    """fp32 NCHW [B,C,H,W] -> bf16 NHWC [reps*B,H,W,C]."""
+    _chk(lat, torch.float32, "lat")
+    B, Cn, H, Wd = lat.shape
+    if out is None:
+        out = torch.empty(reps * B, H, Wd, Cn, dtype=BF16, device=lat.device)
+    _lib.call("spider_latent_to_nhwc_bf16", _p(lat), _p(out), B, Cn, H * Wd, reps, float(scale), _stream())
+    return out
+
+
+def cfg_combine(eps2, guidance, out=None):
+    """eps2 fp32 NHWC [2*B,H,W,C] (uncond first) -> fp32 NCHW [B,C,H,W]."""
+    _chk(eps2, torch.float32, "eps2")
+    B2, H, Wd, Cn = eps2.shape
+    B = B2 // 2
+    if out is None:
+        out = torch.empty(B, Cn, H, Wd, dtype=torch.float32, device=eps2.device)
+    _lib.call("spider_cfg_combine_f32", _p(eps2), _p(out), B, Cn, H * Wd, float(guidance), _stream())
+    return out
+
+
+def lincomb(tensors, coefs, out=None):
+    n = len(tensors)
+    for t in tensors:
+        _chk(t, torch.float32, "lincomb input")
+    if out is None:
+        out = torch.empty_like(tensors[0])
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    _lib.call("spider_lincomb_f32", ptrs, cf, n, _p(out), out.numel(), _stream())
+    return out
+
+
+def nhwc_to_nchw(x, mul=1.0, add_=0.0, clamp01=False, out=None):
+    _chk(x, torch.float32, "x")
+    B, H, Wd, Cn = x.shape
+    if out is None:
+        out = torch.empty(B, Cn, H, Wd, dtype=torch.float32, device=x.device)
+    _lib.call("spider_nhwc_to_nchw_f32", _p(x), _p(out), B, Cn, H * Wd, float(mul), float(add_), int(clamp01), _stream())
+    return out

@@ -1,0 +1,209 @@
+"""CPU: pins the oracle (oracle/*.py) against the golden vectors generated from the reference's own code
+(tests/golden/make_golden.py) and against transformers' tiny models for the parts the in-tree
+modeling_llama.py does not cover (GQA, llama3 rope scaling, qkv bias)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import routing as orouting
+from oracle import story as ostory
+from oracle.llama import LlamaCfg, LlamaOracle, apply_rope, rmsnorm, rope_table, swiglu_mlp
+
+
+def _load_llama(golden_dir, seed):
+    z = np.load(os.path.join(golden_dir, f"llama_ref_seed{seed}.npz"))
+    cfg = LlamaCfg(**json.loads(str(z["cfg"])))
+    w = {}
+    for i, n in enumerate(z["names"]):
+        w[str(n)] = torch.from_numpy(z[f"w{i}"]).view(torch.bfloat16).float()
+    return z, cfg, w
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_llama_forward_and_greedy_match_reference(golden_dir, seed):
+    z, cfg, w = _load_llama(golden_dir, seed)
+    m = LlamaOracle(cfg, w)
+    ids = torch.from_numpy(z["ids"])
+    pos = torch.arange(ids.shape[1])[None].expand(ids.shape[0], -1)
+    logits, _, hid = m.forward(ids, pos, None, None, all_hidden=True)
+    assert torch.allclose(logits, torch.from_numpy(z["logits0"]), atol=2e-4, rtol=1e-4)
+    ref_h = torch.from_numpy(z["hiddens"])
+    for l in range(cfg.layers + 1):
+        assert torch.allclose(hid[l], ref_h[l], atol=2e-4, rtol=1e-4), f"hidden state {l}"
+    gen, step_logits = m.greedy(ids, 16, return_logits=True)
+    assert torch.equal(gen, torch.from_numpy(z["tokens"]))  # bit-exact token ids
+    assert torch.allclose(step_logits, torch.from_numpy(z["step_logits"]), atol=5e-4, rtol=1e-4)
+
+
+def test_llama_ops_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "llama_ops_ref.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    assert torch.allclose(rmsnorm(t("rms_x"), t("rms_w"), float(z["rms_eps"])), t("rms_y"), atol=1e-6)
+    cfg = LlamaCfg(head_dim=16, rope_theta=10000.0)
+    cs = rope_table(cfg, 64)
+    assert torch.allclose(apply_rope(t("rope_q"), cs, t("rope_pos")), t("rope_qe"), atol=1e-5)
+    assert torch.allclose(apply_rope(t("rope_k"), cs, t("rope_pos")), t("rope_ke"), atol=1e-5)
+    assert torch.allclose(swiglu_mlp(t("mlp_x"), t("mlp_wg"), t("mlp_wu"), t("mlp_wd")), t("mlp_y"), atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["llama3_gqa", "qwen2_bias"])
+def test_llama_oracle_matches_transformers_tiny(kind):
+    """GQA + llama3 rope scaling / Qwen2 qkv bias live in `transformers` (pinned 4.43.1 / 4.50.0 by the reference's
+    requirements files; 5.x here) -- cross-check the restatement against the installed implementation."""
+    import transformers
+    if kind == "llama3_gqa":
+        rs = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                  original_max_position_embeddings=64)
+        cfg = LlamaCfg(64, 2, 4, 2, 16, 128, 101, 500000.0, rs, 1e-5, False, 256)
+        try:
+            hf = transformers.LlamaConfig(vocab_size=101, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                          num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5,
+                                          max_position_embeddings=256, rope_theta=500000.0, rope_scaling=dict(rs),
+                                          attention_bias=False, tie_word_embeddings=False)
+        except Exception as e:  # pragma: no cover
+            pytest.skip(f"transformers config API changed: {e}")
+        model = transformers.LlamaForCausalLM(hf)
+    else:
+        cfg = LlamaCfg(64, 2, 4, 2, 16, 128, 101, 1000000.0, None, 1e-6, True, 256)
+        hf = transformers.Qwen2Config(vocab_size=101, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                      num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-6,
+                                      max_position_embeddings=256, rope_theta=1000000.0, tie_word_embeddings=False)
+        model = transformers.Qwen2ForCausalLM(hf)
+    model = model.float().eval()
+    w = LlamaOracle.random_weights(cfg, seed=3, std=0.3)
+    missing, unexpected = model.load_state_dict(w, strict=False)
+    assert not unexpected and not [k for k in missing if "rotary" not in k], (missing, unexpected)
+    # confirm the installed model really uses the rope parameters we think it does
+    ids = torch.randint(3, 101, (2, 90), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = model(input_ids=ids).logits
+    m = LlamaOracle(cfg, w)
+    pos = torch.arange(90)[None].expand(2, -1)
+    got, _, _ = m.forward(ids, pos, None, None)
+    assert torch.allclose(got, ref, atol=3e-4, rtol=1e-4), float((got - ref).abs().max())
+    with torch.no_grad():
+        gen_ref = model.generate(ids, max_new_tokens=8, do_sample=False, num_beams=1, use_cache=True,
+                                 pad_token_id=0, eos_token_id=None)[:, 90:]
+    assert torch.equal(m.greedy(ids, 8), gen_ref)
+
+
+def test_left_padded_greedy_equals_unpadded():
+    cfg = LlamaCfg(64, 2, 4, 2, 16, 128, 101, 10000.0, None, 1e-6, True, 256)
+    m = LlamaOracle(cfg, LlamaOracle.random_weights(cfg, seed=5, std=0.3))
+    ids = torch.randint(3, 101, (1, 9), generator=torch.Generator().manual_seed(2))
+    a = m.greedy(ids, 6)
+    padded = torch.cat([torch.zeros(1, 4, dtype=torch.long), ids], 1)
+    am = torch.cat([torch.zeros(1, 4, dtype=torch.long), torch.ones(1, 9, dtype=torch.long)], 1)
+    b = m.greedy(padded, 6, attn_mask=am)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------- routing
+def test_routing_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "routing_ref.json")))
+    assert len(ref["cases"]) >= 60
+    for c in ref["cases"]:
+        text = c["text"]
+        assert orouting.get_llm_text_modality(text, ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX"]) == c["modality"]
+        for m_, r in c["res"].items():
+            assert orouting.get_llm_text_res(text, m_) == r
+        answers, ptext, calls, _ = orouting.route(text)
+        assert answers == c["answers"]
+        assert ptext == c["predictions_text"]
+        assert [list(x) for x in calls] == c["calls"]
+    for s in ref["story"]:
+        gp, pa, sn = orouting.extract_story_elements(s["text"])
+        assert (gp, pa, sn) == (s["general_prompt"], s["prompt_array"], s["style_name"]), s["text"]
+
+
+def test_routing_known_answers():
+    # spider_decoder_infer.py:139-142 and spider_decoder.py:284-295
+    answers, ptext, _, _ = orouting.route("<IMAGE>apple</IMAGE><VIDEO>dog</VIDEO><AUDIO>cat</AUDIO>")
+    assert answers == ["<IMAGE>apple</IMAGE><VIDEO>dog</VIDEO><AUDIO>cat</AUDIO>"]
+    assert ptext == {'IMAGE': ['apple'], 'VIDEO': ['dog'], 'AUDIO': ['cat'], 'MASK': [], 'BOX': [], 'IMAGESTORY': [],
+                     'IMAGESTORY_prompts': []}
+    assert orouting.get_llm_text_res("<MASK>apple</MASK>", "MASK") == ["apple"]
+    assert orouting.get_llm_text_modality("<IMAGE>a</IMAGE><VIDEO>b</VIDEO><AUDIO>c</AUDIO>",
+                                          ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX"]) == ["IMAGE", "VIDEO", "AUDIO"]
+
+
+# ------------------------------------------------------------------------------------------- StoryDiffusion
+def _aw(z, prefix, heads):
+    t = lambda k: torch.from_numpy(z[f"{prefix}_{k}"])
+    return ostory.AttnWeights(t("to_q.weight"), t("to_k.weight"), t("to_v.weight"), t("to_out.0.weight"),
+                              t("to_out.0.bias"), heads)
+
+
+def test_story_masks_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "story_ref.npz"))
+    for i in range(3):
+        h, w = [int(v) for v in z[f"mask{i}_hw"]]
+        m1, m4 = ostory.cal_attn_mask_xl(5, 4, 0.5, 0.5, h, w, torch.from_numpy(z[f"mask{i}_rand1024"]),
+                                         torch.from_numpy(z[f"mask{i}_rand4096"]))
+        assert torch.equal(m1, torch.from_numpy(z[f"mask{i}_m1024"]))
+        assert torch.equal(m4, torch.from_numpy(z[f"mask{i}_m4096"]))
+    # worked 5x5 example of gradio_utils.py:241-295: keep = [1,0,1,1,0], id rows limited to first 4 groups
+    u = torch.tensor([0.4, 0.9, 0.1, 0.2, 0.8])
+    m1, _ = ostory.cal_attn_mask_xl(5, 4, 0.5, 0.5, 32, 32, u, torch.rand(20))
+    exp = torch.tensor([[1, 0, 1, 1, 0], [1, 1, 1, 1, 0], [1, 0, 1, 1, 0], [1, 0, 1, 1, 0], [1, 0, 1, 1, 1]]).bool()
+    assert torch.equal(m1, exp)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_story_processor_calls_match_reference(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "story_ref.npz"))
+    N, C, heads, hh, ww = [int(v) for v in z[f"proc{tag}_cfg"]]
+    aw = _aw(z, f"proc{tag}", heads)
+    hs = torch.from_numpy(z[f"proc{tag}_hs"])
+    mask = torch.from_numpy(z[f"proc{tag}_mask"])
+    assert torch.allclose(ostory.call1(aw, hs, None, mask), torch.from_numpy(z[f"proc{tag}_y1"]), atol=2e-5)
+    assert torch.allclose(ostory.call2(aw, hs, None, None), torch.from_numpy(z[f"proc{tag}_y2"]), atol=2e-5)
+
+
+def test_story_write_sequence_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "story_ref.npz"))
+    C, heads, hh, ww = [int(v) for v in z["seq_cfg"]]
+    aw_a, aw_b = _aw(z, "seq_sa", heads), _aw(z, "seq_sb", heads)
+    coins = [c for row in z["seq_coins"] for c in row if c >= 0]
+    it = iter(coins)
+    st = ostory.StoryState(total_count=2, height=hh, width=ww, coin=lambda: float(next(it)))
+    # masks are injected per step from the recorded keep rows (row 0 of the reference masks == keep | own block 0)
+    step_masks = []
+    n1, n4 = (hh // 32) * (ww // 32), (hh // 16) * (ww // 16)
+    pa, pb = ostory.ProcessorOracle(), ostory.ProcessorOracle()
+
+    def set_masks(step):
+        k1 = torch.from_numpy(z["seq_keep1024"][step]).clone(); k4 = torch.from_numpy(z["seq_keep4096"][step]).clone()
+        # row 0 has its own block forced True; rebuild the full masks from the other rows' rule
+        # (a column in block 0 was kept iff row 1's entry is True)
+        def rebuild(k, n):
+            b = k[None].repeat(5, 1)
+            return b
+        return k1, k4
+
+    outs_a, outs_b = [], []
+    for step in range(7):
+        # rebuild full masks exactly: use u = 0 where kept else 1 for blocks 1..3; block 0 needs row 1 -> not recorded,
+        # so compare only through the processor outputs with masks reconstructed from the keep rows of rows != own.
+        k1, k4 = set_masks(step)
+        # reference mask row r (block i): keep | own(i). Row 0 gives keep for blocks 1..4 exactly; for block 0 use
+        # the recorded row (own block forced True) -- the write-phase slice [:4N,:4N] of row-blocks 1..3 needs the
+        # true keep of block 0, which equals what any row of block 1 shows. It is stored in the fixture generator as
+        # row 0 only, so regenerate through torch's RNG instead (same container image -> same stream).
+        pass
+    # Regenerate the reference stream deterministically instead (CPU torch.rand after manual_seed(2047)):
+    torch.manual_seed(2047)
+    st.uniforms = lambda n: torch.rand((1, n), dtype=torch.float32).reshape(-1)
+    st.regen_masks()
+    g = None
+    for step in range(7):
+        assert torch.equal(st.mask1024[0], torch.from_numpy(z["seq_keep1024"][step]))
+        assert torch.equal(st.mask4096[0], torch.from_numpy(z["seq_keep4096"][step]))
+        ya = pa(st, aw_a, torch.from_numpy(z["seq_xa"][step]))
+        yb = pb(st, aw_b, torch.from_numpy(z["seq_xb"][step]))
+        assert torch.allclose(ya, torch.from_numpy(z["seq_ya"][step]), atol=2e-5), step
+        assert torch.allclose(yb, torch.from_numpy(z["seq_yb"][step]), atol=2e-5), step
+    assert st.cur_step == 7
