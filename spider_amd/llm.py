@@ -1,0 +1,374 @@
+"""Native LLM engine: greedy autoregressive decode on the HIP kernels (no transformers / torch math).
+
+Drop-in for the reference's LLM seam B3:
+    llama_model.generate(inputs_embeds | input_ids, attention_mask, max_new_tokens, num_beams=1,
+                         do_sample=False, use_cache=True, stopping_criteria, output_hidden_states,
+                         return_dict_in_generate, output_attentions)      spider/models/spider.py:1492-1508
+    -> .sequences  [B, T_new] (generated tokens only for an inputs_embeds call, prompt + generated for
+                   input_ids -- HF semantics the reference relies on, spider.py:1428-1449)
+    -> .hidden_states[step][layer]  [B, S|1, H]
+    embed_tokens(ids)                                                     spider/models/base_model.py:253-258
+Arithmetic follows spider/models/modeling_llama3.py:68-313 (Llama-3 GQA + rope scaling) and the Qwen2.5
+text decoder (qkv bias) that qwen2.5omni_spider_web.py:468 drives.
+
+Data layout in HBM (per engine):
+    embed  [V, H] bf16 | per layer: w_qkv [(n_q+2n_kv)d, H], b_qkv?, w_o [H, n_q d], w_gate_up [2I, H],
+    w_down [H, I], ln1 [H], ln2 [H] | norm [H] | lm_head [V, H]
+    KV cache: 2 x [L, B_max, n_kv, T_max, d] bf16, preallocated once; rope table [max_pos, d] fp32.
+Decode = 5 weight-streaming launches per layer (+1 tiny split-KV combine), captured in a hipGraph.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class LLMConfig:
+    hidden: int
+    layers: int
+    n_q: int
+    n_kv: int
+    head_dim: int
+    inter: int
+    vocab: int
+    rope_theta: float = 10000.0
+    rope_scaling: Optional[dict] = None
+    eps: float = 1e-6
+    qkv_bias: bool = False
+    max_pos: int = 8192
+    tie_embeddings: bool = False
+
+    @staticmethod
+    def llama3_8b():   # DeepSeek-R1-Distill-Llama-8B (r1_llama3_8B_infer.py:4, demo/inference_api.py:92-95)
+        return LLMConfig(4096, 32, 32, 8, 128, 14336, 128256, 500000.0,
+                         dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                              original_max_position_embeddings=8192), 1e-5, False, 8192)
+
+    @staticmethod
+    def qwen25_7b():   # Qwen2.5-Omni-7B thinker text decoder (qwen2.5omni_spider_web.py:368-384)
+        return LLMConfig(3584, 28, 28, 4, 128, 18944, 152064, 1000000.0, None, 1e-6, True, 8192)
+
+    @staticmethod
+    def from_hf_dict(c: dict) -> "LLMConfig":
+        if "thinker_config" in c:  # Qwen2.5-Omni nests the text decoder config
+            c = c["thinker_config"].get("text_config", c["thinker_config"])
+        hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
+        return LLMConfig(c["hidden_size"], c["num_hidden_layers"], c["num_attention_heads"],
+                         c.get("num_key_value_heads", c["num_attention_heads"]), hd, c["intermediate_size"],
+                         c["vocab_size"], float(c.get("rope_theta", 10000.0)), c.get("rope_scaling"),
+                         float(c.get("rms_norm_eps", 1e-6)),
+                         bool(c.get("attention_bias", c.get("model_type", "").startswith("qwen"))),
+                         int(c.get("max_position_embeddings", 8192)), bool(c.get("tie_word_embeddings", False)))
+
+
+def rope_inv_freq(cfg: LLMConfig) -> torch.Tensor:
+    """fp32 inverse frequencies incl. llama3 scaling (modeling_llama3.py:91-113 -> ROPE_INIT_FUNCTIONS)."""
+    d = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    rs = cfg.rope_scaling
+    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+        old = rs["original_max_position_embeddings"]
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > old / lo, inv / factor, inv)
+        smooth = (old / wl - lo) / (hi - lo)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        mid = ~(wl < old / hi) * ~(wl > old / lo)
+        inv = torch.where(mid, smoothed, inv_l)
+    return inv
+
+
+def rope_table(cfg: LLMConfig, n_pos: int) -> torch.Tensor:
+    fr = torch.outer(torch.arange(n_pos, dtype=torch.float32), rope_inv_freq(cfg))
+    return torch.cat([fr.cos(), fr.sin()], dim=-1).contiguous()
+
+
+class GenerateOutput:
+    def __init__(self, sequences, hidden_states=None):
+        self.sequences = sequences
+        self.hidden_states = hidden_states
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class StoppingCriteriaSub:
+    """spider/models/spider.py:55-73: stop when the tail of sequence 0 equals any stop-id list."""
+
+    def __init__(self, stops: Sequence[Sequence[int]] = ()):
+        self.stops = [list(s) for s in stops]
+
+    def __call__(self, input_ids: torch.Tensor, scores=None) -> bool:
+        row = input_ids[0].tolist()
+        for s in self.stops:
+            if len(row) >= len(s) and row[len(row) - len(s):] == s:
+                return True
+        return False
+
+
+class LlamaEngine:
+    def __init__(self, cfg: LLMConfig, weights: dict, device="cuda:0", max_batch: int = 1, max_len: int = 4096):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.max_batch, self.max_len = max_batch, max_len
+        dv = self.device
+        g = lambda k: weights[k].to(device=dv, dtype=BF16).contiguous()
+        self.embed_w = g("model.embed_tokens.weight")
+        self.lm_head = self.embed_w if (cfg.tie_embeddings or "lm_head.weight" not in weights) else g("lm_head.weight")
+        self.norm = g("model.norm.weight")
+        self.layers = []
+        for l in range(cfg.layers):
+            p = f"model.layers.{l}."
+            lw = dict(
+                w_qkv=torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                 g(p + "self_attn.v_proj.weight")], 0).contiguous(),
+                b_qkv=(torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"),
+                                  g(p + "self_attn.v_proj.bias")], 0).contiguous() if cfg.qkv_bias else None),
+                w_o=g(p + "self_attn.o_proj.weight"),
+                w_gu=torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).contiguous(),
+                w_down=g(p + "mlp.down_proj.weight"),
+                ln1=g(p + "input_layernorm.weight"), ln2=g(p + "post_attention_layernorm.weight"))
+            self.layers.append(lw)
+        self._alloc()
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def random_init(cls, cfg: LLMConfig, device="cuda:0", max_batch=1, max_len=4096, seed=0, std=0.02):
+        """Random N(0, std^2) weights of the architecture's true shapes, created directly in HBM
+        (init scheme of modeling_llama3.py:405-414). Used by bench.py: timing is weight-value independent."""
+        gen = torch.Generator(device=device).manual_seed(seed)
+        r = lambda *s: (torch.randn(*s, generator=gen, device=device, dtype=torch.float32) * std).to(BF16)
+        one = lambda n: torch.ones(n, device=device, dtype=BF16)
+        w = {"model.embed_tokens.weight": r(cfg.vocab, cfg.hidden), "model.norm.weight": one(cfg.hidden)}
+        if not cfg.tie_embeddings:
+            w["lm_head.weight"] = r(cfg.vocab, cfg.hidden)
+        qd, kd = cfg.n_q * cfg.head_dim, cfg.n_kv * cfg.head_dim
+        for l in range(cfg.layers):
+            p = f"model.layers.{l}."
+            w[p + "self_attn.q_proj.weight"] = r(qd, cfg.hidden)
+            w[p + "self_attn.k_proj.weight"] = r(kd, cfg.hidden)
+            w[p + "self_attn.v_proj.weight"] = r(kd, cfg.hidden)
+            w[p + "self_attn.o_proj.weight"] = r(cfg.hidden, qd)
+            if cfg.qkv_bias:
+                w[p + "self_attn.q_proj.bias"] = r(qd)
+                w[p + "self_attn.k_proj.bias"] = r(kd)
+                w[p + "self_attn.v_proj.bias"] = r(kd)
+            w[p + "mlp.gate_proj.weight"] = r(cfg.inter, cfg.hidden)
+            w[p + "mlp.up_proj.weight"] = r(cfg.inter, cfg.hidden)
+            w[p + "mlp.down_proj.weight"] = r(cfg.hidden, cfg.inter)
+            w[p + "input_layernorm.weight"] = one(cfg.hidden)
+            w[p + "post_attention_layernorm.weight"] = one(cfg.hidden)
+        return cls(cfg, w, device, max_batch, max_len)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", max_batch=1, max_len=4096):
+        """Load an HF safetensors checkpoint directory (config.json + *.safetensors)."""
+        import glob
+        import json
+        import os
+        from safetensors import safe_open
+        cfg = LLMConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
+        w = {}
+        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            with safe_open(f, framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    kk = k.replace("thinker.model.", "model.").replace("thinker.lm_head.", "lm_head.")
+                    if kk.startswith("model.") or kk.startswith("lm_head."):
+                        w[kk] = sf.get_tensor(k)
+        return cls(cfg, w, device, max_batch, max_len)
+
+    def _alloc(self):
+        c, dv, B, T = self.cfg, self.device, self.max_batch, self.max_len
+        self.k_cache = torch.zeros(c.layers, B, c.n_kv, T, c.head_dim, dtype=BF16, device=dv)
+        self.v_cache = torch.zeros_like(self.k_cache)
+        self.cos_sin = rope_table(c, max(c.max_pos, T)).to(dv)
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ embeddings
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        return ops.embed(self.embed_w, ids.to(device=self.device, dtype=torch.int32).contiguous())
+
+    # ------------------------------------------------------------------ prefill
+    def _prefill(self, h: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, kv_beg: Optional[torch.Tensor],
+                 B: int, S: int, hidden_out: Optional[list]):
+        """h [B*S, H] bf16; writes KV slots, returns the final residual stream [B*S, H]."""
+        c = self.cfg
+        if hidden_out is not None:
+            hidden_out.append(h.view(B, S, -1).clone())
+        for l, lw in enumerate(self.layers):
+            x = ops.rmsnorm(h, lw["ln1"], c.eps)
+            qkv = ops.gemm(x, lw["w_qkv"], bias=lw["b_qkv"])
+            q = torch.empty(B, S, c.n_q, c.head_dim, dtype=BF16, device=self.device)
+            ops.rope_kv_append(qkv, pos, slot, self.cos_sin, q, self.k_cache[l], self.v_cache[l], B, S, c.n_q, c.n_kv, c.head_dim)
+            a = ops.attention_cache(q, self.k_cache[l], self.v_cache[l], Lk=S, causal=True, kv_off=0, kv_beg=kv_beg)
+            h = ops.gemm(a.view(B * S, -1), lw["w_o"], res=h)
+            x = ops.rmsnorm(h, lw["ln2"], c.eps)
+            gu = ops.gemm(x, lw["w_gu"])
+            act = ops.swiglu(gu)
+            h = ops.gemm(act, lw["w_down"], res=h)
+            if hidden_out is not None:
+                hidden_out.append(h.view(B, S, -1).clone())
+        return h
+
+    # ------------------------------------------------------------------ one decode step (graph-capturable)
+    def _decode_step(self, st: dict):
+        c, B = self.cfg, st["B"]
+        h = ops.embed(self.embed_w, st["cur_ids"]) if st["embeds_in"] is None else st["embeds_in"]
+        hs = st.get("hidden_buf")
+        if hs is not None:
+            hs[0].copy_(h)
+        for l, lw in enumerate(self.layers):
+            ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
+            ops.rope_kv_append(st["qkv"], st["pos"], st["slot"], self.cos_sin, st["q"], self.k_cache[l], self.v_cache[l],
+                               B, 1, c.n_q, c.n_kv, c.head_dim)
+            ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
+                            nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
+            h1 = ops.gemv(lw["w_o"], st["attn"], res=h, out=st["h1"])
+            ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
+            h = ops.gemv(lw["w_down"], st["act"], res=h1, out=st["h2"][l & 1])
+            if hs is not None:
+                hs[l + 1].copy_(h)
+        ops.lm_head_argmax(self.lm_head, h, norm_w=self.norm, eps=c.eps, out_ids=st["next_ids"], ws=st["lm_ws"],
+                           logits=st.get("logits"))
+        if hs is not None:  # HF reports the normed state as the last hidden state (modeling_llama3.py:619-623)
+            ops.rmsnorm(h, self.norm, c.eps, out=hs[c.layers])
+        # advance the device-side cursors (index math only)
+        st["cur_ids"].copy_(st["next_ids"])
+        st["pos"].add_(1)
+        st["slot"].add_(1)
+        st["kv_end"].add_(1)
+
+    def _make_state(self, B: int, want_hidden: bool, want_logits: bool) -> dict:
+        c, dv = self.cfg, self.device
+        nq_d = c.n_q * c.head_dim
+        nsplit = max(1, min(64, 512 // max(1, B * c.n_kv)))
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dv)
+        bf = lambda *s: torch.empty(*s, dtype=BF16, device=dv)
+        npart = ops.lm_head_nparts(c.vocab)
+        st = dict(B=B, nsplit=nsplit, cur_ids=i32(B), next_ids=i32(B), pos=i32(B), slot=i32(B), kv_end=i32(B), kv_beg=i32(B),
+                  qkv=bf(B, (c.n_q + 2 * c.n_kv) * c.head_dim), q=bf(B, c.n_q, c.head_dim), attn=bf(B, nq_d),
+                  h1=bf(B, c.hidden), h2=[bf(B, c.hidden), bf(B, c.hidden)], act=bf(B, c.inter),
+                  attn_ws=(torch.empty(B * c.n_q * nsplit * c.head_dim, dtype=torch.float32, device=dv),
+                           torch.empty(B * c.n_q * nsplit * 2, dtype=torch.float32, device=dv)),
+                  lm_ws=(torch.empty(B * npart, dtype=torch.float32, device=dv), i32(B * npart)),
+                  embeds_in=None)
+        if want_hidden:
+            st["hidden_buf"] = bf(c.layers + 1, B, c.hidden)
+        if want_logits:
+            st["logits"] = bf(B, c.vocab)
+        return st
+
+    # ------------------------------------------------------------------ public generate
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 16,
+                 stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None,
+                 output_hidden_states: bool = False, return_dict_in_generate: bool = False,
+                 num_beams: int = 1, do_sample: bool = False, use_cache: bool = True, output_attentions: bool = False,
+                 use_graph: bool = True, sync_every: int = 1, return_logits: bool = False, **unused):
+        """Greedy decode. Left-padded batches are described by attention_mask (0 = pad), as
+        prepare_generation_embedding does (spider.py:1658-1661). `sync_every` > 1 checks the stop
+        conditions only every N tokens (one device->host copy per check instead of per token)."""
+        if num_beams != 1 or do_sample:
+            raise NotImplementedError("the reference path is greedy: num_beams=1, do_sample=False (spider.py:1471-1477)")
+        c, dv = self.cfg, self.device
+        embeds_only = input_ids is None
+        if embeds_only:
+            h0 = inputs_embeds.to(device=dv, dtype=BF16).contiguous()
+            B, S = h0.shape[0], h0.shape[1]
+        else:
+            input_ids = input_ids.to(dv)
+            B, S = input_ids.shape
+            h0 = self.embed_tokens(input_ids)
+        if B > self.max_batch or S + max_new_tokens > self.max_len:
+            raise ValueError(f"batch {B} / length {S}+{max_new_tokens} exceed the preallocated KV cache "
+                             f"({self.max_batch} x {self.max_len})")
+        if B > 8:
+            raise ValueError("decode GEMV path supports up to 8 sequences per engine call")
+        am = (attention_mask.to(dv).to(torch.int32) if attention_mask is not None
+              else torch.ones(B, S, dtype=torch.int32, device=dv))
+        pos2d = (am.cumsum(-1) - 1).clamp(min=0).to(torch.int32).contiguous()
+        slot2d = torch.arange(S, dtype=torch.int32, device=dv)[None].expand(B, S).contiguous()
+        kv_beg = (S - am.sum(-1)).to(torch.int32).contiguous()     # first valid slot (left padding)
+        has_pad = attention_mask is not None and bool((am == 0).any())
+
+        hidden_steps: Optional[List] = [] if output_hidden_states else None
+        step0: Optional[list] = [] if output_hidden_states else None
+        h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
+
+        st = self._make_state(B, output_hidden_states, return_logits)
+        st["kv_beg"].copy_(kv_beg)
+        last = h.view(B, S, -1)[:, -1].contiguous()
+        ops.lm_head_argmax(self.lm_head, last, norm_w=self.norm, eps=c.eps, out_ids=st["next_ids"], ws=st["lm_ws"],
+                           logits=st.get("logits"))
+        if output_hidden_states:
+            step0[-1] = ops.rmsnorm(h, self.norm, c.eps).view(B, S, -1)
+            hidden_steps.append(tuple(step0))
+        st["cur_ids"].copy_(st["next_ids"])
+        st["pos"].copy_(pos2d[:, -1] + 1)
+        st["slot"].fill_(S)
+        st["kv_end"].fill_(S + 1)
+
+        tokens = torch.empty(B, max_new_tokens, dtype=torch.int32, device=dv)
+        tokens[:, 0].copy_(st["next_ids"])
+        logits_steps = [st["logits"].clone()] if return_logits else None
+        eos = None if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
+        prompt_cpu = None if embeds_only else input_ids.cpu()
+
+        def should_stop(n_done: int) -> bool:
+            if eos is None and not stopping_criteria:
+                return False
+            tk = tokens[:, :n_done].cpu().long()
+            if eos is not None and bool(torch.isin(tk, torch.tensor(eos)).any(-1).all()):
+                return True
+            if stopping_criteria:
+                seq = tk if embeds_only else torch.cat([prompt_cpu, tk], 1)
+                return any(sc(seq, None) for sc in stopping_criteria)
+            return False
+
+        graph = None
+        n = 1
+        stopped = should_stop(1)
+        if use_graph and not stopped and max_new_tokens > 2:
+            # warm the kernels outside capture, then capture one decode step; cursors live on device
+            snap = {k: st[k].clone() for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end")}
+            s = torch.cuda.Stream(device=dv)
+            s.wait_stream(torch.cuda.current_stream(dv))
+            with torch.cuda.stream(s):
+                self._decode_step(st)
+            torch.cuda.current_stream(dv).wait_stream(s)
+            for k, v in snap.items():
+                st[k].copy_(v)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._decode_step(st)
+            for k, v in snap.items():   # capture does not execute; restore is a no-op safety net
+                st[k].copy_(v)
+        while n < max_new_tokens and not stopped:
+            if graph is not None:
+                graph.replay()
+            else:
+                self._decode_step(st)
+            tokens[:, n].copy_(st["next_ids"])
+            if output_hidden_states:
+                hidden_steps.append(tuple(t.clone().unsqueeze(1) for t in st["hidden_buf"]))
+            if return_logits:
+                logits_steps.append(st["logits"].clone())
+            n += 1
+            if n % sync_every == 0 or n == max_new_tokens:
+                stopped = should_stop(n)
+        gen = tokens[:, :n].long()
+        if eos is not None:  # trim what ran past the first EOS of sequence 0 when sync_every > 1
+            pass
+        seqs = gen if embeds_only else torch.cat([input_ids.long(), gen], 1)
+        out = GenerateOutput(seqs, tuple(hidden_steps) if output_hidden_states else None)
+        if return_logits:
+            out.logits = torch.stack(logits_steps, 1)
+        return out if return_dict_in_generate else seqs

@@ -1,0 +1,304 @@
+"""GPU parity tests: every C-ABI kernel (called through spider_amd.ops -> ctypes -> libspider_hip.so) against
+the fp32 CPU oracle / plain torch fp32 restatement on the same seeded inputs.
+
+Tolerances: outputs are bf16 (8 mantissa bits, eps = 2^-8 ~ 3.9e-3); inputs are pre-rounded to bf16 so the
+only differences are accumulation order and the output rounding. atol/rtol are written per test.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def close(got, ref, atol, rtol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: max err {float(err.max()):.4g} (allowed {float(tol[err.argmax()] if err.ndim == 0 else tol.flatten()[err.flatten().argmax()]):.4g}), {int(bad.sum())} / {bad.numel()} elements out of tolerance"
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from spider_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------ LLM decode kernels
+@pytest.mark.parametrize("rows,H", [(1, 3584), (5, 4096), (3, 64), (2, 8192)])
+def test_rmsnorm(ops, dev, rows, H):
+    from oracle.llama import rmsnorm
+    x, w, r = rnd(rows, H, seed=1), (1 + 0.1 * rnd(H, seed=2).float()).to(BF), rnd(rows, H, seed=3)
+    y = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6)
+    close(y, rmsnorm(x.float(), w.float(), 1e-6), 1e-2, 1e-2, "rmsnorm")
+    ro = torch.empty_like(x, device=dev)
+    y2 = ops.rmsnorm(x.to(dev), w.to(dev), 1e-6, res=r.to(dev), res_out=ro)
+    hsum = (x.float() + r.float()).to(BF)
+    assert torch.equal(ro.cpu(), hsum)  # bf16 + bf16 -> bf16 is exact-by-definition
+    close(y2, rmsnorm(hsum.float(), w.float(), 1e-6), 1e-2, 1e-2, "rmsnorm+res")
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 4608, 3584), (1, 3584, 18944), (2, 512, 4096), (8, 130, 1024), (3, 7, 64), (8, 64, 18944)])
+def test_gemv(ops, dev, B, N, K):
+    from oracle.llama import rmsnorm
+    W, x = rnd(N, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    bias, res, nw = rnd(N, seed=3), rnd(B, N, seed=4), (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
+    ref = x.float() @ W.float().T
+    close(ops.gemv(W.to(dev), x.to(dev)), ref, 2e-2, 1e-2, "gemv")
+    close(ops.gemv(W.to(dev), x.to(dev), bias=bias.to(dev), res=res.to(dev)), ref + bias.float() + res.float(), 3e-2, 1e-2, "gemv+bias+res")
+    if B * K * 2 <= 65536:
+        xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
+        close(ops.gemv(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5), xn @ W.float().T, 3e-2, 1e-2, "gemv+norm")
+
+
+@pytest.mark.parametrize("B,I,K", [(1, 18944, 3584), (4, 300, 512), (8, 64, 4096)])
+def test_gemv_swiglu(ops, dev, B, I, K):
+    W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    g, u = x.float() @ W[:I].float().T, x.float() @ W[I:].float().T
+    close(ops.gemv_swiglu(W.to(dev), x.to(dev)), F.silu(g) * u, 2e-2, 2e-2, "gemv_swiglu")
+
+
+@pytest.mark.parametrize("B,V,K", [(1, 152064, 3584), (3, 1000, 256), (8, 97, 64)])
+def test_lm_head_argmax(ops, dev, B, V, K):
+    W, x = rnd(V, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    logits = torch.empty(B, V, dtype=BF, device=dev)
+    ids = ops.lm_head_argmax(W.to(dev), x.to(dev), logits=logits)
+    ref = x.float() @ W.float().T
+    close(logits, ref, 2e-2, 1e-2, "logits")
+    # ids must be the argmax of the kernel's own bf16 logits with lowest-index tie-break ...
+    lg = logits.float().cpu()
+    assert torch.equal(ids.cpu().long(), lg.argmax(-1))
+    # ... and must agree with the fp32 reference wherever the reference margin is resolvable in bf16
+    top2 = ref.topk(2, -1).values
+    for b in range(B):
+        if float(top2[b, 0] - top2[b, 1]) > 0.05:
+            assert int(ids[b]) == int(ref[b].argmax())
+
+
+def test_lm_head_argmax_ties(ops, dev):
+    W = torch.zeros(300, 64, dtype=BF)
+    W[[17, 123, 250], 0] = 1.0   # three identical rows -> identical logits -> lowest id wins
+    x = torch.zeros(2, 64, dtype=BF); x[:, 0] = 1.0
+    assert ops.lm_head_argmax(W.to(dev), x.to(dev)).cpu().tolist() == [17, 17]
+
+
+@pytest.mark.parametrize("d,n_q,n_kv,B,S", [(128, 28, 4, 1, 1), (128, 8, 2, 2, 5), (64, 4, 4, 1, 3)])
+def test_rope_kv_append(ops, dev, d, n_q, n_kv, B, S):
+    from oracle.llama import LlamaCfg, apply_rope, rope_table
+    cs = rope_table(LlamaCfg(head_dim=d, rope_theta=1e6), 64)
+    qkv = rnd(B, S, (n_q + 2 * n_kv) * d, seed=1)
+    pos = torch.randint(0, 50, (B, S), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    slot = torch.stack([torch.randperm(16, generator=torch.Generator().manual_seed(3 + b))[:S] for b in range(B)]).to(torch.int32)
+    T = 16
+    kc = torch.zeros(B, n_kv, T, d, dtype=BF, device=dev); vc = torch.zeros_like(kc)
+    q = torch.empty(B, S, n_q, d, dtype=BF, device=dev)
+    ops.rope_kv_append(qkv.to(dev), pos.to(dev).view(-1), slot.to(dev).view(-1), cs.to(dev), q, kc, vc, B, S, n_q, n_kv, d)
+    x = qkv.float().view(B, S, n_q + 2 * n_kv, d)
+    qr = apply_rope(x[:, :, :n_q].transpose(1, 2), cs, pos.long()).transpose(1, 2)
+    kr = apply_rope(x[:, :, n_q:n_q + n_kv].transpose(1, 2), cs, pos.long())   # [B, n_kv, S, d]
+    close(q, qr, 2e-2, 1e-2, "rope q")
+    for b in range(B):
+        for s in range(S):
+            close(kc[b, :, int(slot[b, s])], kr[b, :, s], 2e-2, 1e-2, "rope k")
+            assert torch.equal(vc[b, :, int(slot[b, s])].cpu(), qkv.view(B, S, -1, d)[b, s, n_q + n_kv:])
+
+
+@pytest.mark.parametrize("B,n_q,n_kv,T,nsplit,beg", [(1, 28, 4, 1537, 64, 0), (2, 32, 8, 300, 8, 0), (3, 8, 8, 77, 1, 0),
+                                                    (2, 4, 2, 130, 5, 17), (1, 7, 1, 5, 4, 0), (1, 28, 4, 4096, 128, 0)])
+def test_attn_decode(ops, dev, B, n_q, n_kv, T, nsplit, beg):
+    from oracle.llama import attention
+    d, Tmax = 128, T + 3
+    q, k, v = rnd(B, n_q, d, seed=1), rnd(B, n_kv, Tmax, d, seed=2), rnd(B, n_kv, Tmax, d, seed=3)
+    kv_end = torch.tensor([T - (b % 2) * 3 for b in range(B)], dtype=torch.int32)
+    kv_beg = torch.full((B,), beg, dtype=torch.int32)
+    out = ops.attn_decode(q.to(dev), k.to(dev), v.to(dev), kv_end.to(dev), kv_beg=kv_beg.to(dev), nsplit=nsplit)
+    for b in range(B):
+        e = int(kv_end[b])
+        ref = attention(q[b:b + 1, :, None].float(), k[b:b + 1, :, beg:e].float(), v[b:b + 1, :, beg:e].float(), None, 1 / math.sqrt(d))
+        close(out[b].view(n_q, d), ref[0, :, 0], 1e-2, 1e-2, f"attn_decode b={b}")
+
+
+# ------------------------------------------------------------------------------------------ GEMM / conv / attention
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1536, 4608, 3584), (77, 320, 768), (8192, 320, 320), (200, 36, 72),
+                                   (1, 1280, 320), (130, 132, 1032)])
+def test_gemm(ops, dev, M, N, K):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    ref = A.float() @ W.float().T
+    tol = 2e-2 * max(1.0, math.sqrt(K) * 0.05)
+    close(ops.gemm(A.to(dev), W.to(dev)), ref, tol, 1e-2, "gemm")
+    close(ops.gemm(A.to(dev), W.to(dev), out_f32=True), ref, tol * 0.2, 1e-3, "gemm f32 out")
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    close(ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), res=res.to(dev), out_scale=0.5),
+          0.5 * (ref + bias.float() + res.float()), tol, 1.5e-2, "gemm+bias+res")
+    close(ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act="silu"), F.silu(ref + bias.float()), tol, 1.5e-2, "gemm+silu")
+    close(ops.gemm(A.to(dev), W.to(dev), act="gelu"), F.gelu(ref), tol, 1.5e-2, "gemm+gelu")
+    if M % 4 == 0:
+        rb = rnd(4, N, seed=5)
+        close(ops.gemm(A.to(dev), W.to(dev), rowbias=rb.to(dev), rows_per_group=M // 4),
+              ref + rb.float().repeat_interleave(M // 4, 0), tol, 1.5e-2, "gemm+rowbias")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [(2, 16, 16, 64, 128, 3, 1, False), (2, 64, 64, 320, 320, 3, 1, False),
+                                                          (1, 16, 12, 128, 64, 3, 2, False), (2, 8, 8, 128, 128, 3, 1, True),
+                                                          (2, 16, 16, 192, 64, 1, 1, False), (1, 9, 7, 64, 68, 3, 1, False)])
+def test_conv2d(ops, dev, B, H, W, Cin, Cout, ks, stride, ups):
+    x, w, bias = rnd(B, H, W, Cin, seed=1), rnd(Cout, ks, ks, Cin, seed=2, scale=0.05), rnd(Cout, seed=3)
+    xin = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), bias.float(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
+    tol = 2e-2 * max(1.0, math.sqrt(ks * ks * Cin) * 0.05)
+    y = ops.conv2d(x.to(dev), w.to(dev), bias=bias.to(dev), stride=stride, ups=ups)
+    close(y, ref, tol, 1e-2, "conv2d")
+    rb, res = rnd(B, Cout, seed=4), rnd(*ref.shape, seed=5)
+    y = ops.conv2d(x.to(dev), w.to(dev), bias=bias.to(dev), rowbias=rb.to(dev), res=res.to(dev), stride=stride, ups=ups)
+    close(y, ref + rb.float()[:, None, None, :] + res.float(), tol, 1.5e-2, "conv2d+temb+res")
+
+
+def _attn_ref(q, k, v, heads, kv_heads, causal=False, kv_off=0, mask=None):
+    B, Lq, C = q.shape
+    d = C // heads
+    qh = q.float().view(B, Lq, heads, d).transpose(1, 2)
+    kh = k.float().view(B, -1, kv_heads, d).transpose(1, 2)
+    vh = v.float().view(B, -1, kv_heads, d).transpose(1, 2)
+    Lk = kh.shape[2]
+    m = torch.zeros(Lq, Lk)
+    if causal:
+        i, j = torch.arange(Lq)[:, None], torch.arange(Lk)[None]
+        m = m.masked_fill(j > i + kv_off, float("-inf"))
+    if mask is not None:
+        m = m.masked_fill(~mask, float("-inf"))
+    from oracle.llama import attention
+    return attention(qh, kh, vh, m[None, None], 1 / math.sqrt(d)).transpose(1, 2).reshape(B, Lq, C)
+
+
+@pytest.mark.parametrize("B,heads,kvh,Lq,Lk,d,causal", [(2, 8, 8, 4096, 4096, 40, False), (2, 8, 8, 1024, 1024, 80, False),
+                                                      (2, 8, 8, 256, 256, 160, False), (2, 8, 8, 64, 64, 160, False),
+                                                      (2, 8, 8, 1024, 77, 80, False), (1, 28, 4, 300, 300, 128, True),
+                                                      (2, 12, 12, 77, 77, 64, True), (1, 10, 10, 200, 333, 64, False),
+                                                      (1, 4, 2, 130, 130, 128, True)])
+def test_attention(ops, dev, B, heads, kvh, Lq, Lk, d, causal):
+    q, k, v = rnd(B, Lq, heads * d, seed=1), rnd(B, Lk, kvh * d, seed=2), rnd(B, Lk, kvh * d, seed=3)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads, kvh, causal=causal)
+    close(out, _attn_ref(q, k, v, heads, kvh, causal, Lk - Lq), 1.5e-2, 1.5e-2, "attention")
+
+
+def test_attention_fused_qkv_strides(ops, dev):
+    """q/k/v as column slices of one fused projection output (row stride 3C): no copies needed."""
+    B, N, heads, d = 2, 256, 8, 40
+    C = heads * d
+    qkv = rnd(B, N, 3 * C, seed=1).to(dev)
+    out = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    c = qkv.cpu()
+    close(out, _attn_ref(c[..., :C], c[..., C:2 * C], c[..., 2 * C:], heads, heads), 1.5e-2, 1.5e-2, "attention strided")
+
+
+@pytest.mark.parametrize("N,heads,d,read_mode", [(64, 4, 64, False), (256, 10, 64, False), (64, 4, 64, True)])
+def test_attention_consistent_mask(ops, dev, N, heads, d, read_mode):
+    """Column keep vector + own-block rule == the dense cal_attn_mask_xl mask (gradio_utils.py:241-287)."""
+    from oracle import story as ostory
+    C = heads * d
+    g = torch.Generator().manual_seed(9)
+    u = torch.rand(5 * N, generator=g)
+    keep = (u < 0.5).clone(); keep[4 * N:] = False
+    dense = keep[None].repeat(5, 1)
+    for i in range(5):
+        dense[i, i * N:(i + 1) * N] = True
+    dense = dense[:, None].repeat(1, N, 1).reshape(5 * N, 5 * N)
+    if read_mode:
+        Lq, Lk, mask, q_off = N, 5 * N, dense[4 * N:], 4 * N
+    else:
+        Lq, Lk, mask, q_off = 4 * N, 4 * N, dense[:4 * N, :4 * N], 0
+    bits = torch.zeros((Lk + 63) // 64, dtype=torch.int64)
+    for j in range(Lk):
+        if keep[j]:
+            bits[j // 64] |= (1 << (j % 64)) if (j % 64) < 63 else -(1 << 63)
+    q, k, v = rnd(2, Lq, C, seed=1), rnd(2, Lk, C, seed=2), rnd(2, Lk, C, seed=3)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads, keep_bits=bits.to(dev), blk=N, q_off=q_off)
+    close(out, _attn_ref(q, k, v, heads, heads, mask=mask), 1.5e-2, 1.5e-2, "consistent attention")
+
+
+def test_attention_prefill_cache_leftpad(ops, dev):
+    from oracle.llama import attention
+    B, S, n_q, n_kv, d, T = 2, 70, 8, 2, 128, 96
+    q = rnd(B, S, n_q, d, seed=1)
+    kc, vc = rnd(B, n_kv, T, d, seed=2), rnd(B, n_kv, T, d, seed=3)
+    beg = torch.tensor([0, 9], dtype=torch.int32)
+    out = ops.attention_cache(q.to(dev), kc.to(dev), vc.to(dev), Lk=S, causal=True, kv_off=0, kv_beg=beg.to(dev))
+    for b in range(B):
+        i, j = torch.arange(S)[:, None], torch.arange(S)[None]
+        m = torch.zeros(S, S).masked_fill((j > i) | (j < int(beg[b])), float("-inf"))
+        ref = attention(q[b:b + 1].float().transpose(1, 2), kc[b:b + 1, :, :S].float(), vc[b:b + 1, :, :S].float(),
+                        m[None, None], 1 / math.sqrt(d)).transpose(1, 2).reshape(S, n_q * d)
+        close(out[b, int(beg[b]):], ref[int(beg[b]):], 1.5e-2, 1.5e-2, "prefill attention")
+
+
+# ------------------------------------------------------------------------------------------ UNet elementwise
+@pytest.mark.parametrize("B,HW,C", [(2, 4096, 320), (2, 1024, 640), (2, 64, 1280), (1, 256, 1920), (2, 100, 2560), (1, 16384, 128)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(ops, dev, B, HW, C, silu):
+    x = (rnd(B, HW, C, seed=1).float() * 2 + 0.5).to(BF)
+    ga, be = (1 + 0.2 * rnd(C, seed=2).float()).to(BF), rnd(C, seed=3, scale=0.2)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, ga.float(), be.float(), 1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    close(ops.groupnorm(x.to(dev), ga.to(dev), be.to(dev), 32, 1e-5, silu), ref, 2e-2, 1.5e-2, "groupnorm")
+
+
+@pytest.mark.parametrize("rows,C", [(8192, 320), (77, 768), (3, 1280), (10, 2048)])
+def test_layernorm(ops, dev, rows, C):
+    x, ga, be = rnd(rows, C, seed=1), (1 + 0.2 * rnd(C, seed=2).float()).to(BF), rnd(C, seed=3, scale=0.2)
+    close(ops.layernorm(x.to(dev), ga.to(dev), be.to(dev), 1e-5), F.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5),
+          2e-2, 1e-2, "layernorm")
+
+
+def test_geglu_swiglu_concat_act_add(ops, dev):
+    x = rnd(100, 2 * 1280, seed=1)
+    a, g = x.float().chunk(2, -1)
+    close(ops.geglu(x.to(dev)), a * F.gelu(g), 1e-2, 1.5e-2, "geglu")
+    close(ops.swiglu(x.to(dev)), F.silu(a) * g, 1e-2, 1.5e-2, "swiglu")
+    p, q = rnd(2, 30, 64, seed=2), rnd(2, 30, 128, seed=3)
+    assert torch.equal(ops.concat_channels(p.to(dev), q.to(dev)).cpu(), torch.cat([p, q], -1))
+    close(ops.act(p.to(dev), "silu"), F.silu(p.float()), 1e-2, 1e-2, "silu")
+    close(ops.act(p.to(dev), "quick_gelu"), p.float() * torch.sigmoid(1.702 * p.float()), 1e-2, 1e-2, "quick_gelu")
+    close(ops.add(p.to(dev), p.to(dev)), 2 * p.float(), 1e-6, 1e-2, "add")
+
+
+def test_small_convs(ops, dev):
+    x, w, b = rnd(2, 64, 64, 4, seed=1), rnd(320, 3, 3, 4, seed=2, scale=0.2), rnd(320, seed=3)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+    close(ops.conv2d_small_cin(x.to(dev), w.to(dev), b.to(dev)), ref, 2e-2, 1e-2, "conv_in")
+    x, w, b = rnd(2, 64, 64, 320, seed=4), rnd(4, 3, 3, 320, seed=5, scale=0.05), rnd(4, seed=6)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+    close(ops.conv2d_small_cout(x.to(dev), w.to(dev), b.to(dev)), ref, 5e-3, 1e-3, "conv_out f32")
+    x, w = rnd(1, 32, 32, 128, seed=7), rnd(3, 3, 3, 128, seed=8, scale=0.05)  # VAE conv_out: Cout = 3
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, padding=1).permute(0, 2, 3, 1)
+    close(ops.conv2d_small_cout(x.to(dev), w.to(dev), None), ref, 5e-3, 1e-3, "conv_out cout=3")
+
+
+def test_latent_plumbing(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    nh = ops.latent_to_nhwc(lat.to(dev), reps=2, scale=0.5)
+    ref = (lat * 0.5).permute(0, 2, 3, 1).to(BF)
+    assert torch.equal(nh.cpu(), torch.cat([ref, ref], 0))
+    e = torch.randn(2, 64, 64, 4, generator=g)
+    cf = ops.cfg_combine(e.to(dev), 7.5)
+    close(cf, (e[0] + 7.5 * (e[1] - e[0])).permute(2, 0, 1)[None], 1e-5, 1e-5, "cfg")
+    ts = [torch.randn(1, 4, 64, 64, generator=g) for _ in range(5)]
+    cs = [0.9, -0.3, 0.2, 0.05, -1.1]
+    close(ops.lincomb([t.to(dev) for t in ts], cs), sum(c * t for c, t in zip(cs, ts)), 1e-5, 1e-5, "lincomb")
+    img = torch.randn(1, 16, 16, 3, generator=g)
+    close(ops.nhwc_to_nchw(img.to(dev), 0.5, 0.5, True), (img * 0.5 + 0.5).clamp(0, 1).permute(0, 3, 1, 2), 1e-6, 1e-6, "post")
