@@ -10,6 +10,11 @@ import ctypes as C
 import os
 import threading
 
+# torch must be imported (and with it the HIP runtime it bundles, in the global symbol scope) BEFORE the
+# kernel library is dlopen'ed: both then talk to ONE HIP runtime, so torch's streams, graphs and device
+# pointers are valid inside libspider_hip.so.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspider_hip.so")
 

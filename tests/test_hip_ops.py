@@ -20,11 +20,14 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(BF)
 
 
-def close(got, ref, atol, rtol, what=""):
+def close(got, ref, atol, rtol, what="", rel_to_std=False):
+    """|got - ref| <= atol (* std(ref) if rel_to_std) + rtol * |ref| elementwise."""
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     err = (got - ref).abs()
+    if rel_to_std:
+        atol = atol * float(ref.std()) if ref.numel() > 1 else atol
     tol = atol + rtol * ref.abs()
     bad = err > tol
     assert not bool(bad.any()), f"{what}: max err {float(err.max()):.4g} (allowed {float(tol[err.argmax()] if err.ndim == 0 else tol.flatten()[err.flatten().argmax()]):.4g}), {int(bad.sum())} / {bad.numel()} elements out of tolerance"
@@ -56,18 +59,22 @@ def test_gemv(ops, dev, B, N, K):
     W, x = rnd(N, K, seed=1, scale=0.05), rnd(B, K, seed=2)
     bias, res, nw = rnd(N, seed=3), rnd(B, N, seed=4), (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
     ref = x.float() @ W.float().T
-    close(ops.gemv(W.to(dev), x.to(dev)), ref, 2e-2, 1e-2, "gemv")
-    close(ops.gemv(W.to(dev), x.to(dev), bias=bias.to(dev), res=res.to(dev)), ref + bias.float() + res.float(), 3e-2, 1e-2, "gemv+bias+res")
+    close(ops.gemv(W.to(dev), x.to(dev)), ref, 1e-2, 1e-2, "gemv", rel_to_std=True)
+    close(ops.gemv(W.to(dev), x.to(dev), bias=bias.to(dev), res=res.to(dev)), ref + bias.float() + res.float(), 1.5e-2, 1e-2,
+          "gemv+bias+res", rel_to_std=True)
     if B * K * 2 <= 65536:
+        # the fused prologue rounds the normalised activations to bf16 exactly like the separate rmsnorm kernel;
+        # each of the K products then carries a 2^-9 relative error -> ~2^-9 * std(out) * few sigma overall
         xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
-        close(ops.gemv(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5), xn @ W.float().T, 3e-2, 1e-2, "gemv+norm")
+        close(ops.gemv(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5), xn @ W.float().T, 2e-2, 1e-2, "gemv+norm",
+              rel_to_std=True)
 
 
 @pytest.mark.parametrize("B,I,K", [(1, 18944, 3584), (4, 300, 512), (8, 64, 4096)])
 def test_gemv_swiglu(ops, dev, B, I, K):
     W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(B, K, seed=2)
     g, u = x.float() @ W[:I].float().T, x.float() @ W[I:].float().T
-    close(ops.gemv_swiglu(W.to(dev), x.to(dev)), F.silu(g) * u, 2e-2, 2e-2, "gemv_swiglu")
+    close(ops.gemv_swiglu(W.to(dev), x.to(dev)), F.silu(g) * u, 1.5e-2, 2e-2, "gemv_swiglu", rel_to_std=True)
 
 
 @pytest.mark.parametrize("B,V,K", [(1, 152064, 3584), (3, 1000, 256), (8, 97, 64)])
@@ -76,7 +83,7 @@ def test_lm_head_argmax(ops, dev, B, V, K):
     logits = torch.empty(B, V, dtype=BF, device=dev)
     ids = ops.lm_head_argmax(W.to(dev), x.to(dev), logits=logits)
     ref = x.float() @ W.float().T
-    close(logits, ref, 2e-2, 1e-2, "logits")
+    close(logits, ref, 1e-2, 1e-2, "logits", rel_to_std=True)
     # ids must be the argmax of the kernel's own bf16 logits with lowest-index tie-break ...
     lg = logits.float().cpu()
     assert torch.equal(ids.cpu().long(), lg.argmax(-1))

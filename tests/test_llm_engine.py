@@ -67,7 +67,11 @@ def test_engine_matches_oracle_d128(dev, seed):
     _, _, hid = oracle.forward(ids, pos, None, None, all_hidden=True)
     for l in range(ocfg.layers + 1):
         got = out.hidden_states[0][l].float().cpu()
-        assert torch.allclose(got, hid[l], atol=0.05, rtol=0.03), (l, float((got - hid[l]).abs().max()))
+        # bf16 residual stream vs fp32 oracle: relative RMS error < 2 % and no element off by > 6 % of the tensor scale
+        # (each of the ~10 bf16 roundings per layer contributes ~2^-9 relative; measured 0.4-1.3 %)
+        rel = float((got - hid[l]).norm() / hid[l].norm())
+        assert rel < 2e-2, (l, rel)
+        assert float((got - hid[l]).abs().max()) < 0.06 * float(hid[l].abs().max()), l
 
 
 def test_engine_inputs_embeds_returns_generated_only_and_graph_equals_eager(dev):
