@@ -1,0 +1,107 @@
+"""Scheduler coefficient logic (host side) for the denoising loop, custom_sd.py:608,647.
+
+The reference takes its scheduler class from the checkpoint (diffusers==0.25.0): PNDMScheduler with
+skip_prk_steps for SD-v1.5 (40 steps -> 41 UNet calls), DDIMScheduler for StoryDiffusion
+(Comic_Generation.py:316-317). Every `scheduler.step` of both is a linear combination of the current sample
+and (stored) noise predictions; this module only produces the coefficients, the update itself is ONE
+spider_lincomb_f32 launch on fp32 latents in HBM.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from . import ops
+
+
+def _alphas_cumprod(beta_start=0.00085, beta_end=0.012, n=1000) -> torch.Tensor:
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, 0)
+
+
+class PNDMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, **unused):
+        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps)
+        self.final_alpha = self.ac[0]
+        self.n_train, self.offset = num_train_timesteps, steps_offset
+
+    def set_timesteps(self, n: int):
+        self.n = n
+        ratio = self.n_train // n
+        ts = (torch.arange(0, n) * ratio).round().long() + self.offset
+        self.timesteps = torch.cat([ts[:-1], ts[-2:-1], ts[-1:]]).flip(0)
+        self.ets: List[torch.Tensor] = []
+        self.counter = 0
+        self.cur_sample = None
+        return self.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def _coeffs(self, t: int, prev_t: int) -> Tuple[float, float]:
+        a_t = self.ac[t]
+        a_p = self.ac[prev_t] if prev_t >= 0 else self.final_alpha
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return float(sample_coeff), float((a_p - a_t) / denom)
+
+    def step(self, eps: torch.Tensor, t, sample: torch.Tensor) -> torch.Tensor:
+        """eps, sample: fp32 device tensors. Returns the previous sample (new tensor)."""
+        t = int(t)
+        ratio = self.n_train // self.n
+        prev_t = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+        else:
+            prev_t, t = t, t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            terms, self.cur_sample = [(1.0, eps)], sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            terms = [(0.5, eps), (0.5, self.ets[-1])]
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(self.ets) == 2:
+            terms = [(1.5, self.ets[-1]), (-0.5, self.ets[-2])]
+        elif len(self.ets) == 3:
+            terms = [(23 / 12, self.ets[-1]), (-16 / 12, self.ets[-2]), (5 / 12, self.ets[-3])]
+        else:
+            terms = [(55 / 24, self.ets[-1]), (-59 / 24, self.ets[-2]), (37 / 24, self.ets[-3]), (-9 / 24, self.ets[-4])]
+        cs, cm = self._coeffs(t, prev_t)
+        self.counter += 1
+        return ops.lincomb([sample] + [e for _, e in terms], [cs] + [-cm * c for c, _ in terms])
+
+
+class DDIMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, **unused):
+        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps)
+        self.final_alpha = self.ac[0]
+        self.n_train, self.offset = num_train_timesteps, steps_offset
+
+    def set_timesteps(self, n: int):
+        self.n = n
+        ratio = self.n_train // n
+        self.timesteps = (torch.arange(0, n) * ratio).round().flip(0).long() + self.offset
+        return self.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, eps: torch.Tensor, t, sample: torch.Tensor) -> torch.Tensor:
+        t = int(t)
+        prev_t = t - self.n_train // self.n
+        a_t = self.ac[t]
+        a_p = self.ac[prev_t] if prev_t >= 0 else self.final_alpha
+        cx = float((a_p / a_t) ** 0.5)
+        ce = float((1 - a_p) ** 0.5 - (a_p / a_t) ** 0.5 * (1 - a_t) ** 0.5)
+        return ops.lincomb([sample, eps], [cx, ce])
+
+
+SCHEDULERS = {"PNDMScheduler": PNDMScheduler, "DDIMScheduler": DDIMScheduler}

@@ -1,0 +1,442 @@
+"""Native UNet2DConditionModel step on the HIP kernels (NHWC bf16), for SD-v1.5 (SpiderFree IMAGE decoder,
+spider/models/spider_decoder.py:100-120 -> custom_sd.py:634-639) and SDXL (StoryDiffusion,
+StoryDiffusion/Comic_Generation.py:313,440). The layer graph restates diffusers==0.25.0 (external to the
+reference tree; see oracle/unet.py for the algorithm statement and the 'parity unpinned' note).
+
+MI355X-first choices (vs. the reference's per-op PyTorch calls):
+  * activations stay NHWC bf16 in HBM: conv = implicit GEMM on MFMA, 1x1 conv / proj_in / proj_out = plain GEMM
+  * self-attention q,k,v come from ONE fused [3C,C] GEMM and are consumed in place (strided views, no transposes)
+  * cross-attention K/V of the 77 text tokens are projected ONCE per prompt and reused by all steps
+  * the whole time-embedding path (sinusoid -> MLP -> every resnet's time_emb_proj) is computed once per call
+    for all timesteps with 3 GEMMs; each step only copies its slice into a static buffer
+  * bias / time-embedding / residual adds, 1/rescale and the nearest-2x upsample are fused into GEMM epilogues
+    or the conv's input addressing; one UNet step is one hipGraph replay (about 420 kernel launches for SD-v1.5)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class UNetConfig:
+    in_ch: int = 4
+    out_ch: int = 4
+    block_out: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_attn: Tuple[bool, ...] = (True, True, True, False)
+    up_attn: Tuple[bool, ...] = (False, True, True, True)
+    depth: Tuple[int, ...] = (1, 1, 1, 1)
+    heads: Tuple[int, ...] = (8, 8, 8, 8)
+    layers_per_block: int = 2
+    cross_dim: int = 768
+    groups: int = 32
+    linear_proj: bool = False
+    addition_time_dim: int = 0
+    addition_in: int = 0
+    mid_depth: Optional[int] = None
+
+    @staticmethod
+    def sd15():
+        return UNetConfig()
+
+    @staticmethod
+    def sdxl():
+        return UNetConfig(4, 4, (320, 640, 1280), (False, True, True), (True, True, False), (1, 2, 10), (5, 10, 20), 2,
+                          2048, 32, True, 256, 2816, 10)
+
+    @staticmethod
+    def from_diffusers_dict(c: dict) -> "UNetConfig":
+        bo = tuple(c["block_out_channels"])
+        nb = len(bo)
+        ahd = c.get("num_attention_heads") or c["attention_head_dim"]
+        heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * nb
+        tl = c.get("transformer_layers_per_block", 1)
+        depth = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * nb
+        return UNetConfig(c["in_channels"], c["out_channels"], bo,
+                          tuple(t.startswith("CrossAttn") for t in c["down_block_types"]),
+                          tuple(t.startswith("CrossAttn") for t in c["up_block_types"]), depth, heads,
+                          c.get("layers_per_block", 2), c["cross_attention_dim"], c.get("norm_num_groups", 32),
+                          bool(c.get("use_linear_projection", False)), c.get("addition_time_embed_dim") or 0,
+                          c.get("projection_class_embeddings_input_dim") or 0,
+                          depth[-1] if c.get("addition_embed_type") == "text_time" else None)
+
+    @property
+    def temb_dim(self):
+        return self.block_out[0] * 4
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos=True, shift=0.0) -> torch.Tensor:
+    """diffusers Timesteps (fp32 on the host; [n, dim])."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - shift)
+    emb = t.float()[:, None] * torch.exp(exponent)[None]
+    emb = torch.cat([emb.sin(), emb.cos()], -1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], -1)
+    return emb
+
+
+class UNetEngine:
+    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        dv = self.device
+        for n, t in weights.items():
+            t = t.to(dv)
+            if t.ndim == 4:      # conv OIHW -> OHWI (K-contiguous rows for the implicit GEMM)
+                t = t.permute(0, 2, 3, 1)
+            self.w[n] = t.to(BF16).contiguous()
+        # fused projections
+        for n in [k[:-len(".attn1.to_q.weight")] for k in list(self.w) if k.endswith(".attn1.to_q.weight")]:
+            self.w[n + ".attn1.qkv"] = torch.cat([self.w[n + ".attn1.to_q.weight"], self.w[n + ".attn1.to_k.weight"],
+                                                  self.w[n + ".attn1.to_v.weight"]], 0).contiguous()
+            self.w[n + ".attn2.kv"] = torch.cat([self.w[n + ".attn2.to_k.weight"], self.w[n + ".attn2.to_v.weight"]], 0).contiguous()
+        # resnet table: order of time_emb_proj consumers
+        self.resnets = [k[:-len(".time_emb_proj.weight")] for k in self.w if k.endswith(".time_emb_proj.weight")]
+        self.tproj_w = torch.cat([self.w[r + ".time_emb_proj.weight"] for r in self.resnets], 0).contiguous()
+        self.tproj_b = torch.cat([self.w[r + ".time_emb_proj.bias"] for r in self.resnets], 0).contiguous()
+        self.tproj_off, off = {}, 0
+        for r in self.resnets:
+            c = self.w[r + ".time_emb_proj.weight"].shape[0]
+            self.tproj_off[r] = (off, c)
+            off += c
+        self.tproj_total = off
+        self.cross_layers = [k[:-len(".attn2.kv")] for k in self.w if k.endswith(".attn2.kv")]
+        self.self_attn_hook: Optional[Callable] = None   # StoryDiffusion consistent self-attention
+        self.freeu: Optional[Tuple[float, float, float, float]] = None
+        self._graph = None
+        self._graph_key = None
+        self.kv: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0):
+        from_shapes = _param_shapes(cfg)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        w = {}
+        for n, shp in from_shapes.items():
+            if n.endswith(".bias"):
+                t = torch.randn(shp, generator=gen, device=device) * 0.02
+            elif "norm" in n.split(".")[-2]:
+                t = torch.ones(shp, device=device)
+            else:
+                t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
+            w[n] = t.to(BF16)
+        return cls(cfg, w, device)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0"):
+        """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors."""
+        import glob, json, os
+        from safetensors import safe_open
+        cfg = UNetConfig.from_diffusers_dict(json.load(open(os.path.join(path, "config.json"))))
+        w = {}
+        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+            with safe_open(f, framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    w[k] = sf.get_tensor(k)
+        return cls(cfg, w, device)
+
+    # ------------------------------------------------------------------ per-call preparation
+    def prepare(self, timesteps: torch.Tensor, enc: torch.Tensor, added: Optional[dict] = None):
+        """timesteps [n] (host), enc [B2, 77, cross] bf16 on device, added: SDXL {'text_embeds','time_ids'}.
+        Computes every step's per-resnet time projection and every cross-attention layer's K/V once."""
+        cfg, dv = self.cfg, self.device
+        B2 = enc.shape[0]
+        n = len(timesteps)
+        te = timestep_embedding(torch.as_tensor(timesteps), cfg.block_out[0]).to(dv).to(BF16)          # [n, c0]
+        h = ops.gemm(te, self.w["time_embedding.linear_1.weight"], bias=self.w["time_embedding.linear_1.bias"], act="silu")
+        emb = ops.gemm(h, self.w["time_embedding.linear_2.weight"], bias=self.w["time_embedding.linear_2.bias"])  # [n, T]
+        if cfg.addition_in:
+            tid = timestep_embedding(added["time_ids"].flatten().cpu(), cfg.addition_time_dim).reshape(B2, -1)
+            add = torch.cat([added["text_embeds"].to(dv).float(), tid.to(dv)], -1).to(BF16).contiguous()
+            a = ops.gemm(add, self.w["add_embedding.linear_1.weight"], bias=self.w["add_embedding.linear_1.bias"], act="silu")
+            aug = ops.gemm(a, self.w["add_embedding.linear_2.weight"], bias=self.w["add_embedding.linear_2.bias"])  # [B2, T]
+            emb = (emb[:, None, :].float() + aug[None].float()).to(BF16).reshape(n * B2, -1).contiguous()
+            per = B2
+        else:
+            per = 1
+        se = ops.act(emb.contiguous(), "silu")
+        tp = ops.gemm(se, self.tproj_w, bias=self.tproj_b)                     # [n*per, total]
+        tp = tp.view(n, per, self.tproj_total)
+        if per == 1:
+            tp = tp.expand(n, B2, self.tproj_total)
+        # regroup to [n, concat_r(B2 * C_r)] so each resnet's rowbias block [B2, C_r] is contiguous
+        self.tproj_steps = torch.cat([tp[:, :, o:o + c].reshape(n, B2 * c) for (o, c) in (self.tproj_off[r] for r in self.resnets)], 1).contiguous()
+        self.tproj_cur = torch.empty_like(self.tproj_steps[0])
+        self.tproj_view, off = {}, 0
+        for r in self.resnets:
+            c = self.tproj_off[r][1]
+            self.tproj_view[r] = self.tproj_cur[off:off + B2 * c].view(B2, c)
+            off += B2 * c
+        enc = enc.to(BF16).contiguous()
+        for l in self.cross_layers:
+            self.kv[l] = ops.gemm(enc, self.w[l + ".attn2.kv"])               # [B2, 77, 2C]
+        self._graph = None
+        self.B2 = B2
+
+    # ------------------------------------------------------------------ blocks
+    def _gn(self, n, x, silu, eps=1e-5):
+        return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu)
+
+    def _resnet(self, n, x):
+        w = self.w
+        a = self._gn(n + ".norm1", x, True)
+        h = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n])
+        a = self._gn(n + ".norm2", h, True)
+        sc = x
+        if n + ".conv_shortcut.weight" in w:
+            sc = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0)
+        return ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=sc)
+
+    def _self_attn(self, b, y, heads):
+        """y [B, N, C] (LayerNorm output) -> attention output before the to_out projection's residual."""
+        C = y.shape[-1]
+        qkv = ops.gemm(y, self.w[b + ".attn1.qkv"])
+        return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+
+    def _transformer(self, n, x, heads, depth):
+        w = self.w
+        B, H, W_, C = x.shape
+        a = self._gn(n + ".norm", x, False, eps=1e-6)
+        pw = w[n + ".proj_in.weight"].view(C, C)
+        h = ops.gemm(a.view(B, H * W_, C), pw, bias=w[n + ".proj_in.bias"])
+        for d in range(depth):
+            b = f"{n}.transformer_blocks.{d}"
+            y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
+            if self.self_attn_hook is not None and self.self_attn_hook.wants(b + ".attn1"):
+                o = self.self_attn_hook(self, b + ".attn1", y, heads)
+            else:
+                o = self._self_attn(b, y, heads)
+            h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
+            y = ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
+            q = ops.gemm(y, w[b + ".attn2.to_q.weight"])
+            kv = self.kv[b]
+            o = ops.attention(q, kv[..., :C], kv[..., C:], heads)
+            h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
+            y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
+            p = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"])
+            g = ops.geglu(p)
+            h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
+        out = ops.gemm(h, w[n + ".proj_out.weight"].view(C, C), bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
+        return out.view(B, H, W_, C)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B2, h, w, in_ch] bf16 NHWC -> eps [B2, h, w, out_ch] fp32 NHWC (time step = current tproj_cur)."""
+        cfg, w = self.cfg, self.w
+        h = ops.conv2d_small_cin(x, w["conv_in.weight"], w["conv_in.bias"])
+        skips = [h]
+        nb = len(cfg.block_out)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                if cfg.down_attn[i]:
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cfg.heads[i], cfg.depth[i])
+                skips.append(h)
+            if i != nb - 1:
+                h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
+                               stride=2, pad=1)
+                skips.append(h)
+        h = self._resnet("mid_block.resnets.0", h)
+        h = self._transformer("mid_block.attentions.0", h, cfg.heads[-1], cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1])
+        h = self._resnet("mid_block.resnets.1", h)
+        rheads, rdepth = list(reversed(cfg.heads)), list(reversed(cfg.depth))
+        for i in range(nb):
+            for j in range(cfg.layers_per_block + 1):
+                skip = skips.pop()
+                hh = h
+                if self.freeu is not None and i < 2:
+                    hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", ops.concat_channels(hh, skip))
+                if cfg.up_attn[i]:
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], rdepth[i])
+            if i != nb - 1:
+                h = ops.conv2d(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"], ups=True)
+        a = self._gn("conv_norm_out", h, True)
+        return ops.conv2d_small_cout(a, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
+
+    # ------------------------------------------------------------------ public step
+    def step(self, x: torch.Tensor, step_idx: int, use_graph: bool = True) -> torch.Tensor:
+        """One UNet evaluation at timestep index `step_idx` of the prepared schedule. x bf16 NHWC [B2,h,w,C]."""
+        self.tproj_cur.copy_(self.tproj_steps[step_idx])
+        if not use_graph or self.self_attn_hook is not None:
+            return self._forward(x)
+        key = tuple(x.shape)
+        if self._graph is None or self._graph_key != key:
+            self._x_static = torch.empty_like(x)
+            self._x_static.copy_(x)
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                self._forward(self._x_static)       # warm-up outside capture
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out_static = self._forward(self._x_static)
+            self._graph_key = key
+        self._x_static.copy_(x)
+        self._graph.replay()
+        return self._out_static
+
+
+def _fourier_filter(x_nhwc: torch.Tensor, threshold: int, scale: float) -> torch.Tensor:
+    """FreeU low-pass on the skip features (hipFFT through torch.fft is glue, not a north_star kernel)."""
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    B, C, H, W = x.shape
+    xf = torch.fft.fftshift(torch.fft.fftn(x, dim=(-2, -1)), dim=(-2, -1))
+    mask = torch.ones((B, C, H, W), device=x.device)
+    cr, cc = H // 2, W // 2
+    mask[..., cr - threshold:cr + threshold, cc - threshold:cc + threshold] = scale
+    xf = torch.fft.ifftshift(xf * mask, dim=(-2, -1))
+    return torch.fft.ifftn(xf, dim=(-2, -1)).real.permute(0, 2, 3, 1).to(BF16).contiguous()
+
+
+def _apply_freeu(res_idx, hidden, skip, s1, s2, b1, b2):
+    n = hidden.shape[-1] // 2
+    b, s = (b1, s1) if res_idx == 0 else (b2, s2)
+    hidden = torch.cat([(hidden[..., :n].float() * b).to(BF16), hidden[..., n:]], -1).contiguous()
+    return hidden, _fourier_filter(skip, 1, s)
+
+
+def _param_shapes(cfg: UNetConfig) -> dict:
+    """name -> shape in diffusers naming (conv OIHW); mirrors UNet2DConditionModel's module tree."""
+    S = {}
+    T, c0 = cfg.temb_dim, cfg.block_out[0]
+
+    def conv(n, co, ci, k): S[n + ".weight"] = (co, ci, k, k); S[n + ".bias"] = (co,)
+    def lin(n, co, ci, bias=True):
+        S[n + ".weight"] = (co, ci)
+        if bias: S[n + ".bias"] = (co,)
+    def norm(n, c): S[n + ".weight"] = (c,); S[n + ".bias"] = (c,)
+    def resnet(n, ci, co):
+        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci, 3); lin(n + ".time_emb_proj", co, T)
+        norm(n + ".norm2", co); conv(n + ".conv2", co, co, 3)
+        if ci != co: conv(n + ".conv_shortcut", co, ci, 1)
+    def transformer(n, c, depth):
+        norm(n + ".norm", c)
+        if cfg.linear_proj: lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
+        else: conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
+        for d in range(depth):
+            b = f"{n}.transformer_blocks.{d}"
+            norm(b + ".norm1", c); norm(b + ".norm2", c); norm(b + ".norm3", c)
+            for a, kd in (("attn1", c), ("attn2", cfg.cross_dim)):
+                lin(f"{b}.{a}.to_q", c, c, False); lin(f"{b}.{a}.to_k", c, kd, False); lin(f"{b}.{a}.to_v", c, kd, False)
+                lin(f"{b}.{a}.to_out.0", c, c)
+            lin(b + ".ff.net.0.proj", 8 * c, c); lin(b + ".ff.net.2", c, 4 * c)
+
+    conv("conv_in", c0, cfg.in_ch, 3)
+    lin("time_embedding.linear_1", T, c0); lin("time_embedding.linear_2", T, T)
+    if cfg.addition_in:
+        lin("add_embedding.linear_1", T, cfg.addition_in); lin("add_embedding.linear_2", T, T)
+    nb, ch = len(cfg.block_out), c0
+    for i, co in enumerate(cfg.block_out):
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{i}.resnets.{j}", ch if j == 0 else co, co)
+            if cfg.down_attn[i]: transformer(f"down_blocks.{i}.attentions.{j}", co, cfg.depth[i])
+        ch = co
+        if i != nb - 1: conv(f"down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+    cm = cfg.block_out[-1]
+    resnet("mid_block.resnets.0", cm, cm)
+    transformer("mid_block.attentions.0", cm, cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1])
+    resnet("mid_block.resnets.1", cm, cm)
+    rev, rdepth, prev = list(reversed(cfg.block_out)), list(reversed(cfg.depth)), cm
+    for i, co in enumerate(rev):
+        cin_skip = rev[min(i + 1, nb - 1)]
+        for j in range(cfg.layers_per_block + 1):
+            skip = cin_skip if j == cfg.layers_per_block else co
+            resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else co) + skip, co)
+            if cfg.up_attn[i]: transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i])
+        prev = co
+        if i != nb - 1: conv(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
+    norm("conv_norm_out", c0); conv("conv_out", cfg.out_ch, c0, 3)
+    return S
+
+
+def unet_flops(cfg: UNetConfig, h: int, w: int, text_len: int = 77) -> dict:
+    """Exact multiply-add count (x2) of one UNet evaluation per sample at latent h x w, by category
+    (convs 2*Cin*Cout*k^2*h*w, linears 2*N*Cin*Cout, attention cores 4*N*Lk*C) -- the layer-table sum that
+    SURVEY.md section 8d asks for instead of the literature figure."""
+    S = _param_shapes(cfg)
+    res = {}   # module prefix -> (h, w) at which it runs
+    fl = dict(conv=0.0, linear=0.0, attn_self=0.0, attn_cross=0.0)
+    nb = len(cfg.block_out)
+    hh, ww = h, w
+    sizes = {}
+    for i in range(nb):
+        sizes[f"down_blocks.{i}."] = (hh, ww)
+        if i != nb - 1:
+            sizes[f"down_blocks.{i}.downsamplers"] = (hh // 2, ww // 2)
+            hh, ww = hh // 2, ww // 2
+    sizes["mid_block."] = (hh, ww)
+    for i in range(nb):
+        sizes[f"up_blocks.{i}."] = (hh, ww)
+        if i != nb - 1:
+            sizes[f"up_blocks.{i}.upsamplers"] = (hh * 2, ww * 2)
+            hh, ww = hh * 2, ww * 2
+    sizes["conv_in"] = sizes["conv_out"] = (h, w)
+
+    def size_of(name):
+        best = None
+        for p, s in sizes.items():
+            if name.startswith(p) and (best is None or len(p) > len(best[0])):
+                best = (p, s)
+        return best[1] if best else (1, 1)
+
+    for n, shp in S.items():
+        if not n.endswith(".weight") or len(shp) == 1:
+            continue
+        sh, sw = size_of(n)
+        if len(shp) == 4:
+            fl["conv"] += 2.0 * shp[0] * shp[1] * shp[2] * shp[3] * sh * sw
+        elif "time_emb" in n or "add_embedding" in n:
+            continue  # hoisted out of the step
+        elif ".attn2.to_k" in n or ".attn2.to_v" in n:
+            continue  # hoisted: projected once per prompt
+        else:
+            fl["linear"] += 2.0 * shp[0] * shp[1] * sh * sw
+            if n.endswith(".attn1.to_q.weight"):
+                fl["attn_self"] += 4.0 * (sh * sw) ** 2 * shp[0]
+            if n.endswith(".attn2.to_q.weight"):
+                fl["attn_cross"] += 4.0 * (sh * sw) * text_len * shp[0]
+    fl["total"] = sum(fl.values())
+    return fl
+
+
+def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: torch.Tensor, guidance: float, steps: int,
+            added: Optional[dict] = None, use_graph: bool = True) -> torch.Tensor:
+    """The reference's denoising loop (custom_sd.py:627-652) on device: latents fp32 NCHW [B,4,h,w] in HBM,
+    enc [2B,77,C] (uncond first, as _encode_prompt concatenates them, custom_sd.py:372). Per step:
+    cat([latents]*2)+scale (1 launch) -> UNet graph replay -> CFG combine (1) -> scheduler update (1)."""
+    ts = scheduler.set_timesteps(steps)
+    unet.prepare(ts, enc, added)
+    latents = (latents * scheduler.init_noise_sigma).contiguous()
+    do_cfg = guidance > 1.0
+    for i, t in enumerate(ts):
+        x2 = ops.latent_to_nhwc(latents, reps=2 if do_cfg else 1)
+        e = unet.step(x2, i, use_graph=use_graph)
+        eps = ops.cfg_combine(e, guidance) if do_cfg else ops.nhwc_to_nchw(e)
+        latents = scheduler.step(eps, t, latents)
+    return latents
+
+
+def smoke_check(dev) -> None:
+    """Tiny UNet step on the GPU against the fp32 CPU oracle (used by __graft_entry__.smoke())."""
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
+    ocfg = UNetCfg.tiny()
+    w = random_unet_weights(ocfg, seed=0)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 16, 16, generator=g).bfloat16().float()
+    enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    ref = UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc)
+    eng.prepare(torch.tensor([500]), enc.to(dev))
+    got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(BF16), 0, use_graph=False).permute(0, 3, 1, 2).cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < 2e-2, f"smoke: UNet step differs from the oracle (rel L2 {rel:.4f})"

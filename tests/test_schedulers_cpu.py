@@ -1,0 +1,30 @@
+"""CPU: host-side scheduler coefficient logic (spider_amd/schedulers.py) against the oracle's scheduler
+restatement -- timesteps identical, and the per-step linear-combination coefficients reproduce the oracle's
+update when applied with plain tensor math (the device lincomb kernel itself is covered by the GPU tests)."""
+import torch
+
+from oracle.unet import DDIMOracle, PNDMOracle
+from spider_amd import schedulers as S
+
+
+def _run(prod, orc, steps, monkey):
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 8, 8, generator=g)
+    ts_p, ts_o = prod.set_timesteps(steps), orc.set_timesteps(steps)
+    assert torch.equal(ts_p, ts_o)
+    xp, xo = x0.clone(), x0.clone()
+    for t in ts_o:
+        e = torch.randn(1, 4, 8, 8, generator=g)
+        xp = prod.step(e, t, xp)
+        xo = orc.step(e, t, xo)
+        assert torch.allclose(xp, xo, atol=1e-5, rtol=1e-5)
+    return ts_p
+
+
+def test_schedulers_match_oracle(monkeypatch):
+    monkeypatch.setattr(S.ops, "lincomb", lambda ts, cs, out=None: sum(c * t for c, t in zip(cs, ts)))
+    ts = _run(S.PNDMScheduler(), PNDMOracle(), 40, monkeypatch)
+    assert len(ts) == 41 and int(ts[0]) == 976 and int(ts[-1]) == 1   # 40 steps -> 41 UNet calls
+    assert int(ts[1]) == int(ts[2]) == 951                              # the repeated PLMS warm-up timestep
+    ts = _run(S.DDIMScheduler(), DDIMOracle(), 50, monkeypatch)
+    assert len(ts) == 50 and int(ts[0]) == 981 and int(ts[-1]) == 1

@@ -1,0 +1,96 @@
+"""GPU: native UNet step / denoising loop (spider_amd/unet.py on the HIP kernels) against the fp32 CPU oracle
+(oracle/unet.py -- diffusers-0.25 restatement, parity unpinned upstream) on tiny SD-v1.5-like and SDXL-like configs.
+
+Tolerances are relative L2 errors against the fp32 oracle, derived from bf16 storage (half-ulp 2^-9 = 2.0e-3):
+  * every block (resnet / transformer / conv) measured 1.7e-3 .. 6e-3 in isolation (scripts/debug_unet_blocks.py),
+    i.e. one bf16 rounding of its output; a whole evaluation chains ~25 blocks -> sqrt(25) * 3e-3 ~ 1.5e-2
+    measured; bound 2.5e-2
+  * latents after a coarse 6-8 step loop: measured 2.9e-2 (each coarse step weighs eps heavily); bound 5e-2.
+north_star asks for 1e-3 relative on the latents; a bf16 tensor alone is only exact to 2e-3, so that target needs
+an fp32 residual stream -- tracked in DESIGN.md ("numerics"), not asserted here.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("sdxl_like", [False, True])
+def test_unet_step_matches_oracle(dev, sdxl_like):
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
+    from spider_amd.unet import UNetConfig, UNetEngine
+    ocfg = UNetCfg.tiny(sdxl_like)
+    w = random_unet_weights(ocfg, seed=1)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    g = torch.Generator().manual_seed(2)
+    B2, hh, ww = 2, 16, 24
+    x = torch.randn(B2, 4, hh, ww, generator=g).bfloat16().float()
+    enc = torch.randn(B2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    added = None
+    if sdxl_like:
+        added = dict(text_embeds=torch.randn(B2, 64, generator=g).bfloat16().float(),
+                     time_ids=torch.tensor([[hh * 8, ww * 8, 0, 0, hh * 8, ww * 8]] * B2, dtype=torch.float32))
+    oracle = UNetOracle(ocfg, w)
+    ts = torch.tensor([981, 500, 21])
+    eng.prepare(ts, enc.to(dev), added)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    for i, t in enumerate(ts):
+        ref = oracle.forward(x, t, enc, added)
+        eager = eng.step(xn, i, use_graph=False).permute(0, 3, 1, 2)
+        graph = eng.step(xn, i, use_graph=True).permute(0, 3, 1, 2)
+        assert torch.equal(eager.cpu(), graph.cpu()), "hipGraph replay must be bit-identical to eager launches"
+        r = _rel(eager, ref)
+        assert r < 2.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
+
+
+@pytest.mark.parametrize("sched_name,steps", [("pndm", 8), ("ddim", 6)])
+def test_denoise_loop_matches_oracle(dev, sched_name, steps):
+    from oracle.unet import DDIMOracle, PNDMOracle, UNetCfg, UNetOracle, denoise_loop, random_unet_weights
+    from spider_amd.schedulers import DDIMScheduler, PNDMScheduler
+    from spider_amd.unet import UNetConfig, UNetEngine, denoise
+    ocfg = UNetCfg.tiny()
+    w = random_unet_weights(ocfg, seed=3)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(1, 4, 16, 16, generator=g)
+    enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    ref = denoise_loop(UNetOracle(ocfg, w), PNDMOracle() if sched_name == "pndm" else DDIMOracle(), lat, enc, 7.5, steps)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    sched = PNDMScheduler() if sched_name == "pndm" else DDIMScheduler()
+    got = denoise(eng, sched, lat.to(dev), enc.to(dev), 7.5, steps)
+    assert got.shape == lat.shape
+    r = _rel(got, ref)
+    assert r < 5e-2, f"latents rel L2 {r:.5f}"
+
+
+def test_freeu_matches_oracle(dev):
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
+    from spider_amd.unet import UNetConfig, UNetEngine
+    ocfg = UNetCfg.tiny(True)
+    w = random_unet_weights(ocfg, seed=5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 4, 16, 16, generator=g).bfloat16().float()
+    enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    added = dict(text_embeds=torch.randn(2, 64, generator=g).bfloat16().float(),
+                 time_ids=torch.tensor([[128, 128, 0, 0, 128, 128]] * 2, dtype=torch.float32))
+    oracle = UNetOracle(ocfg, w); oracle.freeu = (0.6, 0.4, 1.1, 1.2)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev); eng.freeu = (0.6, 0.4, 1.1, 1.2)
+    eng.prepare(torch.tensor([300]), enc.to(dev), added)
+    got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), 0, use_graph=False).permute(0, 3, 1, 2)
+    ref = oracle.forward(x, torch.tensor(300), enc, added)
+    r_on = _rel(got, ref)
+    assert r_on < 2.5e-2
+    oracle.freeu = None
+    r_off = _rel(got, oracle.forward(x, torch.tensor(300), enc, added))
+    assert r_off > 3 * r_on, (r_on, r_off)  # FreeU really changes the result
+
+
+def test_unet_flop_table():
+    from spider_amd.unet import UNetConfig, unet_flops
+    f = unet_flops(UNetConfig.sd15(), 64, 64)
+    # attention cores must reproduce SURVEY.md section 8d: self 122.5 GF, cross 3.56 GF per sample
+    assert abs(f["attn_self"] / 1e9 - 122.5) < 0.3 and abs(f["attn_cross"] / 1e9 - 3.56) < 0.05
+    assert 0.6e12 < f["total"] < 1.0e12
