@@ -69,16 +69,18 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
 
 /* C = act(A[M,K] . W[N,K]^T + bias[N] + rowbias[row/rows_per_group, N]) (+res) * out_scale.
  * Exactly one of C (bf16) / C32 (fp32). act: 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu.
+ * ws/ws_bytes: optional fp32 split-K workspace (NULL = never split K); small-M / large-K problems use it
+ * to fill the 256 CUs.
  * Prefill projections (modeling_llama3.py:186-313), diffusers Attention/FeedForward/proj linears. */
 int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, void* stream);
+                     float out_scale, void* ws, long ws_bytes, void* stream);
 
 /* conv2d NHWC as implicit GEMM (ResnetBlock2D / Downsample2D / Upsample2D convs reached from
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* stream);
+                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream);
 
 /* fused attention (prefill causal GQA: modeling_llama3.py:202-237; UNet self/cross attention:
  * StoryDiffusion/utils/gradio_utils.py:400-472; consistent self-attention with the column keep vector of

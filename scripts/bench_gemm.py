@@ -1,0 +1,73 @@
+"""Tuning aid: time the GEMM / implicit-GEMM conv at the shapes of the hot path under a forced tile / split-K
+(env SPIDER_GEMM_TILE / SPIDER_GEMM_SPLITS are read once per process, so each config runs in a child process)."""
+import json, os, subprocess, sys
+import torch
+
+SHAPES = [  # (tag, M, N, K, conv_cin or 0, hw)
+    ("prefill qkv", 1536, 4608, 3584, 0, 0), ("prefill o", 1536, 3584, 3584, 0, 0),
+    ("prefill gate_up", 1536, 37888, 3584, 0, 0), ("prefill down", 1536, 3584, 18944, 0, 0),
+    ("u64 qkv", 8192, 960, 320, 0, 0), ("u64 out", 8192, 320, 320, 0, 0), ("u64 ff1", 8192, 2560, 320, 0, 0), ("u64 ff2", 8192, 320, 1280, 0, 0),
+    ("u32 qkv", 2048, 1920, 640, 0, 0), ("u32 out", 2048, 640, 640, 0, 0), ("u32 ff1", 2048, 5120, 640, 0, 0), ("u32 ff2", 2048, 640, 2560, 0, 0),
+    ("u16 qkv", 512, 3840, 1280, 0, 0), ("u16 out", 512, 1280, 1280, 0, 0), ("u16 ff1", 512, 10240, 1280, 0, 0), ("u16 ff2", 512, 1280, 5120, 0, 0),
+    ("u8 qkv", 128, 3840, 1280, 0, 0), ("u8 ff1", 128, 10240, 1280, 0, 0),
+    ("c64 320>320", 8192, 320, 2880, 320, 64), ("c64 640>320", 8192, 320, 5760, 640, 64), ("c64 960>320", 8192, 320, 8640, 960, 64),
+    ("c32 640>640", 2048, 640, 5760, 640, 32), ("c32 320>640", 2048, 640, 2880, 320, 32), ("c32 1280>640", 2048, 640, 11520, 1280, 32),
+    ("c32 1920>640", 2048, 640, 17280, 1920, 32),
+    ("c16 1280>1280", 512, 1280, 11520, 1280, 16), ("c16 640>1280", 512, 1280, 5760, 640, 16), ("c16 2560>1280", 512, 1280, 23040, 2560, 16),
+    ("c8 1280>1280", 128, 1280, 11520, 1280, 8), ("c8 2560>1280", 128, 1280, 23040, 2560, 8),
+]
+
+
+def child():
+    from spider_amd import ops
+    dev = torch.device("cuda:0")
+    out = {}
+    for tag, M, N, K, cin, hw in SHAPES:
+        if cin:
+            x = torch.randn(2, hw, hw, cin, device=dev).bfloat16()
+            w = (torch.randn(N, 3, 3, cin, device=dev) * 0.02).bfloat16()
+            f = lambda: ops.conv2d(x, w)
+        else:
+            A = torch.randn(M, K, device=dev).bfloat16()
+            W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+            f = lambda: ops.gemm(A, W)
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        # time inside a hipGraph: Python/ctypes launch overhead (~10 us per call) would otherwise hide small kernels
+        n = 20
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                f()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record(); e1.synchronize()
+        out[tag] = e0.elapsed_time(e1) * 1e3 / (3 * n)
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child()
+        sys.exit(0)
+    res = {}
+    for cfg in ([(0, 0), (128, 1), (64, 1)] if os.environ.get("QUICK") else [(0, 0), (128, 1), (128, 2), (128, 4), (128, 8), (64, 1), (64, 2), (64, 4), (64, 8), (64, 16)]):
+        env = dict(os.environ, PYTHONPATH=".")
+        if cfg != (0, 0):
+            env["SPIDER_GEMM_TILE"], env["SPIDER_GEMM_SPLITS"] = str(cfg[0]), str(cfg[1])
+        o = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+        line = [l for l in o.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line:
+            print("config", cfg, "failed:", o.stderr[-500:]); continue
+        res[cfg] = json.loads(line[0][7:])
+    tags = [s[0] for s in SHAPES]
+    print(f"{'shape':16s} " + " ".join(f"{str(c):>9s}" for c in res))
+    for i, t in enumerate(tags):
+        M, N, K = SHAPES[i][1:4]
+        row = [res[c][t] for c in res]
+        best = min(row)
+        print(f"{t:16s} " + " ".join(f"{v:9.1f}" for v in row) + f"   best {list(res)[row.index(best)]} {2*M*N*K/best/1e6:.0f} TF/s")

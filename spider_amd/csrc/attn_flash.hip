@@ -139,42 +139,70 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnArgs p) {
         }
 
         // ---- mask + online softmax (lane = query column; the partner lane^32 holds the other 32 keys) ----
-        const unsigned long long kbits = p.keep_bits ? p.keep_bits[t] : ~0ull;
-        float tmax = -1e30f;
-        bool vis[2][16];
+        // Fast path (wave-uniform): a tile entirely inside [kbeg, Lk), below the causal diagonal of every row of
+        // this wave and without a keep vector needs no per-element predicates: max, one fma + exp2, add.
+        const int wave_q0 = q0 + wave * 32;
+        const bool full_tile = (t * 64 >= kbeg) && (t * 64 + 64 <= p.Lk) && !p.keep_bits &&
+                               (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off);
+        float psum = 0.f, alpha;
+        if (full_tile) {
+            float tmax = s[0][0];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h32;
-                const int key = t * 64 + kk;
-                bool ok = key < p.Lk && key >= kbeg;
-                if (p.causal) ok = ok && key <= caus_max;
-                if (p.keep_bits) ok = ok && (((kbits >> kk) & 1ull) || (key >= own_lo && key < own_hi));
-                vis[kt][r] = ok;
-                const float sv = s[kt][r] * p.scale_log2e;
-                s[kt][r] = sv;
-                tmax = fmaxf(tmax, ok ? sv : -1e30f);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
-        float psum = 0.f;
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kt][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = exp2f(m_run - m_new);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = vis[kt][r] ? exp2f(s[kt][r] - m_new) : 0.f;
-                s[kt][r] = pv;
-                psum += pv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][r], p.scale_log2e, -m_new));
+                    s[kt][r] = pv;
+                    psum += pv;
+                }
+            m_run = m_new;
+        } else {
+            const unsigned long long kbits = p.keep_bits ? p.keep_bits[t] : ~0ull;
+            float tmax = -1e30f;
+            unsigned vis = 0u;  // bit (kt*16 + r)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h32;
+                    const int key = t * 64 + kk;
+                    bool ok = key < p.Lk && key >= kbeg;
+                    if (p.causal) ok = ok && key <= caus_max;
+                    if (p.keep_bits) ok = ok && (((kbits >> kk) & 1ull) || (key >= own_lo && key < own_hi));
+                    vis |= ok ? (1u << (kt * 16 + r)) : 0u;
+                    const float sv = s[kt][r] * p.scale_log2e;
+                    s[kt][r] = sv;
+                    tmax = fmaxf(tmax, ok ? sv : -1e30f);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = exp2f(m_run - m_new);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = ((vis >> (kt * 16 + r)) & 1u) ? exp2f(s[kt][r] - m_new) : 0.f;
+                    s[kt][r] = pv;
+                    psum += pv;
+                }
+            m_run = m_new;
+        }
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
-        m_run = m_new;
+        // rescale O only when some row of the wave actually moved its max (alpha == 1 exactly otherwise)
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int i = 0; i < DP / 32; ++i)
+            for (int i = 0; i < DP / 32; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc_o[i][r] *= alpha;
+        }
 
         // ---- P^T as the B operand: registers 8s..8s+7 of each half, packed to bf16 ----
         bf16x8 pf[2][2];

@@ -1,21 +1,26 @@
 // bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )   (both operands K-contiguous)
 //
-// One kernel serves
+// One kernel family serves
 //   * LLM prefill projections            (modeling_llama3.py:186-199,260-313 at S = prompt length)
 //   * UNet / text-encoder / VAE linears  (diffusers-0.25 Attention.to_q/k/v/out, FeedForward, proj_in/out)
 //   * conv2d as implicit GEMM on NHWC    (ResnetBlock2D conv1/conv2, Down/Upsample2D, conv_shortcut;
 //                                         call sites custom_sd.py:634-639 -> UNet2DConditionModel.forward)
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of mfma_f32_16x16x32_bf16.
-// Operand roles are swapped (W tile is the MFMA "A" operand) so each lane ends up with 4 consecutive
-// output columns of one row -> 8-byte epilogue loads/stores. LDS rows are padded to 144 B (odd multiple
-// of 16 B: conflict-free ds_read_b128), double-buffered, global->register prefetch one K tile ahead.
+// Tiles: 128x128x64 (large problems) or 64x64x64 (small M*N), 256 threads = 4 waves (2x2); each wave owns a
+// (BM/2)x(BN/2) sub-tile of mfma_f32_16x16x32_bf16 tiles. The UNet at CFG batch 2 has M = 8192 .. 128 rows and
+// K up to 23040 (3x3 conv over 2560 channels): grids of a few dozen tiles would leave most of the 256 CUs idle,
+// so the host picks the tile and a split-K factor that bring the grid to >= ~2 blocks per CU; split-K partials go
+// to an fp32 workspace (plain stores, one slab per split) and a second kernel reduces them and applies the epilogue.
+// Operand roles are swapped (W tile is the MFMA "A" operand) so each lane ends up with 4 consecutive output
+// columns of one row -> 8-byte epilogue loads/stores. LDS rows are padded to 144 B (odd multiple of 16 B:
+// conflict-free ds_read_b128), double-buffered, global->register prefetch one K tile ahead.
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace spider;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int LDS_STRIDE = BK + 8;  // elements; 144 bytes
 
 struct GemmArgs {
@@ -26,20 +31,76 @@ struct GemmArgs {
     const bf16_t* res;      // [M, ldc] or null (added after rounding the GEMM result to bf16)
     const bf16_t* rowbias;  // [M / rows_per_group, N] or null (time-embedding add)
     float* C32;             // optional fp32 output instead of bf16
+    float* ws;              // split-K workspace [splits, M, N] fp32
     int M, N, K, lda, ldc;
     int rows_per_group;
     int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu
     float out_scale;        // multiplies the final value (1/rescale_output_factor)
+    int splits, kt_per_split;
     // implicit-GEMM conv (NHWC): A is the image [B, Hin, Win, Cin]; K = ks*ks*Cin
     int conv, Hin, Win, Cin, Hout, Wout, ks, stride, pad, ups;
 };
 
-template <bool CONV>
+// bias / rowbias / activation / residual / scale on 4 consecutive columns of one row, then store
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v[4]) {
+    const int grp = p.rowbias ? m / p.rows_per_group : 0;
+    if (n + 3 < p.N) {
+        if (p.bias) {
+            const u32x2 bq = *reinterpret_cast<const u32x2*>(p.bias + n);
+            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
+            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+        }
+        if (p.rowbias) {
+            const u32x2 bq = *reinterpret_cast<const u32x2*>(p.rowbias + (size_t)grp * p.N + n);
+            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
+            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p.act == 1) v[e] = silu_f(v[e]);
+            else if (p.act == 2) v[e] = gelu_erf_f(v[e]);
+            else if (p.act == 3) v[e] = quick_gelu_f(v[e]);
+        }
+        if (p.res) {
+            const u32x2 rq = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldc + n);
+            v[0] = bf16_to_f32(f32_to_bf16(v[0])) + bf16lo_to_f32(rq.x);
+            v[1] = bf16_to_f32(f32_to_bf16(v[1])) + bf16hi_to_f32(rq.x);
+            v[2] = bf16_to_f32(f32_to_bf16(v[2])) + bf16lo_to_f32(rq.y);
+            v[3] = bf16_to_f32(f32_to_bf16(v[3])) + bf16hi_to_f32(rq.y);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        if (p.C32) {
+            *reinterpret_cast<f32x4*>(p.C32 + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            u32x2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+        }
+    } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float t = v[e];
+            if (p.bias) t += bf16_to_f32(p.bias[n + e]);
+            if (p.rowbias) t += bf16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
+            if (p.act == 1) t = silu_f(t);
+            else if (p.act == 2) t = gelu_erf_f(t);
+            else if (p.act == 3) t = quick_gelu_f(t);
+            if (p.res) t = bf16_to_f32(f32_to_bf16(t)) + bf16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
+            t *= p.out_scale;
+            if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
+            else p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(t);
+        }
+    }
+}
+
+template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
-    // layout: [2 buffers][A tile 128 rows | W tile 128 rows][LDS_STRIDE]
-    constexpr int TILE_ELEMS = (BM + BN) * LDS_STRIDE;
+    constexpr int TILE_ELEMS = (BM + BN) * LDS_STRIDE;  // [A tile BM rows | W tile BN rows]
+    constexpr int MT = BM / 32, NT = BN / 32;           // 16x16 MFMA tiles per wave (wave sub-tile BM/2 x BN/2)
+    constexpr int AC = BM / 32, WC = BN / 32;           // 16-byte chunks per thread per K tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -48,17 +109,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = bid % tiles_m, tn = bid / tiles_m;  // m fastest: neighbours share the W tile
     const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
 
-    // ---- per-thread staging assignment: 4 A chunks + 4 W chunks of 16 B per K tile ----
     const int chunk = tid & 7;       // 16-byte chunk within the 64-wide K tile
     const int lrow = tid >> 3;       // 0..31, rows lrow + 32*i
-    const bf16_t* a_ptr[4];
-    bool a_ok[4];
-    int a_oy[4], a_ox[4];
-    const bf16_t* w_ptr[4];
-    bool w_ok[4];
+    const bf16_t* a_ptr[AC];
+    bool a_ok[AC];
+    int a_oy[AC], a_ox[AC];
+    const bf16_t* w_ptr[WC];
+    bool w_ok[WC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AC; ++i) {
         const int m = m0 + lrow + 32 * i;
         a_ok[i] = m < p.M;
         const int mc = a_ok[i] ? m : 0;
@@ -72,16 +133,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             a_ptr[i] = p.A + (size_t)mc * p.lda;
             a_oy[i] = a_ox[i] = 0;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < WC; ++i) {
         const int n = n0 + lrow + 32 * i;
         w_ok[i] = n < p.N;
         w_ptr[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K;
     }
 
-    const int nk = (p.K + BK - 1) / BK;
-    u32x4 ra[4], rw[4];
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
-    auto load_tile = [&](int kt) {
+    // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring)
+    auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC]) {
         const int k = kt * BK + chunk * 8;
         const bool kok = k < p.K;
         if (CONV) {
@@ -90,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             const int ky = tap / p.ks, kx = tap % p.ks;
             const int hlim = p.ups ? p.Hin * 2 : p.Hin, wlim = p.ups ? p.Win * 2 : p.Win;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < AC; ++i) {
                 int iy = a_oy[i] * p.stride + ky - p.pad;
                 int ix = a_ox[i] * p.stride + kx - p.pad;
                 const bool ok = a_ok[i] && kok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
@@ -99,126 +165,169 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < AC; ++i)
                 ra[i] = (a_ok[i] && kok) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k) : zero;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WC; ++i)
             rw[i] = (w_ok[i] && kok) ? *reinterpret_cast<const u32x4*>(w_ptr[i] + k) : zero;
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
         bf16_t* base = lds + buf * TILE_ELEMS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AC; ++i)
             *reinterpret_cast<u32x4*>(base + (lrow + 32 * i) * LDS_STRIDE + chunk * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < WC; ++i)
             *reinterpret_cast<u32x4*>(base + (BM + lrow + 32 * i) * LDS_STRIDE + chunk * 8) = rw[i];
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    auto compute = [&](int buf) {
+        const bf16_t* abase = lds + buf * TILE_ELEMS + (wm * (BM / 2) + frow) * LDS_STRIDE + fk;
+        const bf16_t* wbase = lds + buf * TILE_ELEMS + (BM + wn * (BN / 2) + frow) * LDS_STRIDE + fk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abase + i * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wbase + j * 16 * LDS_STRIDE + ks * 32);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    load_tile(0);
-    store_tile(0);
+    u32x4 a0[AC], w0[WC], a1[AC], w1[WC];
+    if (kt0 < kt1) {
+        load_tile(kt0, a0, w0);
+        if (kt0 + 1 < kt1) load_tile(kt0 + 1, a1, w1);
+        store_tile(0, a0, w0);
+        if (kt0 + 2 < kt1) load_tile(kt0 + 2, a0, w0);
+    }
     __syncthreads();
-
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const bf16_t* abase = lds + cur * TILE_ELEMS + (wm * 64 + frow) * LDS_STRIDE + fk;
-        const bf16_t* wbase = lds + cur * TILE_ELEMS + (BM + wn * 64 + frow) * LDS_STRIDE + fk;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(abase + i * 16 * LDS_STRIDE + ks * 32);
-                wf[i] = *reinterpret_cast<const bf16x8*>(wbase + i * 16 * LDS_STRIDE + ks * 32);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    // invariant at loop top: LDS buf0 = tile kt; R1 = tile kt+1 (in flight); R0 = tile kt+2 (in flight)
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        compute(0);
+        if (kt + 1 < kt1) store_tile(1, a1, w1);
         __syncthreads();
+        if (kt + 3 < kt1) load_tile(kt + 3, a1, w1);
+        if (kt + 1 < kt1) compute(1);
+        if (kt + 2 < kt1) store_tile(0, a0, w0);
+        __syncthreads();
+        if (kt + 4 < kt1) load_tile(kt + 4, a0, w0);
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int grp = p.rowbias ? m / p.rows_per_group : 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = (n + 3 < p.N);
-            if (full) {
-                if (p.bias) {
-                    const u32x2 bq = *reinterpret_cast<const u32x2*>(p.bias + n);
-                    v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
-                    v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
-                }
-                if (p.rowbias) {
-                    const u32x2 bq = *reinterpret_cast<const u32x2*>(p.rowbias + (size_t)grp * p.N + n);
-                    v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
-                    v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (p.act == 1) v[e] = silu_f(v[e]);
-                    else if (p.act == 2) v[e] = gelu_erf_f(v[e]);
-                    else if (p.act == 3) v[e] = quick_gelu_f(v[e]);
-                }
-                if (p.res) {
-                    const u32x2 rq = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldc + n);
-                    v[0] = bf16_to_f32(f32_to_bf16(v[0])) + bf16lo_to_f32(rq.x);
-                    v[1] = bf16_to_f32(f32_to_bf16(v[1])) + bf16hi_to_f32(rq.x);
-                    v[2] = bf16_to_f32(f32_to_bf16(v[2])) + bf16lo_to_f32(rq.y);
-                    v[3] = bf16_to_f32(f32_to_bf16(v[3])) + bf16hi_to_f32(rq.y);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-                if (p.C32) {
-                    *reinterpret_cast<f32x4*>(p.C32 + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    u32x2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
-                }
+            if (p.splits > 1) {
+                float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+                if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
             } else {
-                for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                    float t = v[e];
-                    if (p.bias) t += bf16_to_f32(p.bias[n + e]);
-                    if (p.rowbias) t += bf16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
-                    if (p.act == 1) t = silu_f(t);
-                    else if (p.act == 2) t = gelu_erf_f(t);
-                    else if (p.act == 3) t = quick_gelu_f(t);
-                    if (p.res) t = bf16_to_f32(f32_to_bf16(t)) + bf16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
-                    t *= p.out_scale;
-                    if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
-                    else p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(t);
-                }
+                epilogue_store(p, m, n, v);
             }
         }
     }
 }
 
-int launch(const GemmArgs& a, void* stream) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16_t);  // 73,728 B
-    if (a.conv) gemm_kernel<true><<<tiles, 256, smem, (hipStream_t)stream>>>(a);
-    else gemm_kernel<false><<<tiles, 256, smem, (hipStream_t)stream>>>(a);
+// split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+    const int n4 = (p.N + 3) / 4;
+    const size_t total = (size_t)p.M * n4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splits; ++s) {
+            const float* src = p.ws + ((size_t)s * p.M + m) * p.N + n;
+            if (n + 3 < p.N) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[e];
+            }
+        }
+        epilogue_store(p, m, n, v);
+    }
+}
+
+template <int BM, int BN>
+void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
+    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16_t);
+    dim3 grid(tiles, a.splits);
+    if (a.conv) gemm_kernel<BM, BN, true><<<grid, 256, smem, st>>>(a);
+    else gemm_kernel<BM, BN, false><<<grid, 256, smem, st>>>(a);
+}
+
+// Tile / split-K choice: fill >= ~2 blocks per CU (512) when the problem allows it, keep >= 4 K tiles per split.
+int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+int launch(GemmArgs a, long ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    static const int force_tile = env_int("SPIDER_GEMM_TILE"), force_splits = env_int("SPIDER_GEMM_SPLITS");  // tuning aid
+    const int nk = (a.K + BK - 1) / BK;
+    const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const int t64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    // Measured on MI355X (scripts/bench_gemm.py): K-heavy problems (3x3 convs, down_proj) want 128^2 tiles plus
+    // split-K up to ~768 blocks; everything else with < 384 big tiles is faster on 64^2 tiles (more blocks, all
+    // resident), split only when even those leave CUs idle.
+    bool small;
+    int splits = 1;
+    if (nk >= 44 && t128 >= 24) {
+        small = false;
+        splits = (768 + t128 - 1) / t128;
+        if (splits > 8) splits = 8;
+        if (splits > nk / 8) splits = nk / 8;
+    } else if (t128 >= 384) {
+        small = false;
+    } else {
+        small = true;
+        if (t64 < 256 && nk >= 16) {
+            splits = (512 + t64 - 1) / t64;
+            if (splits > 16) splits = 16;
+            if (splits > nk / 4) splits = nk / 4;
+        }
+    }
+    if (force_tile) small = force_tile == 64;
+    if (!a.ws || splits < 1) splits = 1;
+    while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
+    const int tiles = small ? t64 : t128;
+    if (force_splits && a.ws) {
+        splits = force_splits < nk ? force_splits : nk;
+        while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
+    }
+    a.kt_per_split = (nk + splits - 1) / splits;
+    a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
+    if (small) launch_tile<64, 64>(a, tiles, st);
+    else launch_tile<128, 128>(a, tiles, st);
     SPIDER_LAUNCH_OK();
+    if (a.splits > 1) {
+        const size_t total = (size_t)a.M * ((a.N + 3) / 4);
+        size_t g = (total + 255) / 256;
+        if (g > 2048) g = 2048;
+        splitk_reduce_kernel<<<(int)g, 256, 0, st>>>(a);
+        SPIDER_LAUNCH_OK();
+    }
     return 0;
 }
 
@@ -226,11 +335,11 @@ int launch(const GemmArgs& a, void* stream) {
 
 extern "C" {
 
-// C[M,N] = act(A[M,K] . W[N,K]^T + bias + rowbias[row / rows_per_group]) (+ res) , * out_scale
-// ldc applies to C, C32 and res. N % 4 == 0 and ldc % 4 == 0 keep the 8-byte epilogue path aligned.
+// C = act(A[M,K] . W[N,K]^T + bias + rowbias[row / rows_per_group]) (+ res) , * out_scale
+// ldc applies to C, C32 and res. ws/ws_bytes: optional fp32 split-K workspace (NULL disables split-K).
 int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, void* stream) {
+                     float out_scale, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
     SPIDER_CHECK(ldc % 4 == 0 && ldc >= N, "gemm: ldc must be >= N and a multiple of 4");
@@ -241,8 +350,8 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.C32 = (float*)C32;
     a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
     a.rows_per_group = rows_per_group; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.act = act;
-    a.out_scale = out_scale; a.conv = 0;
-    return launch(a, stream);
+    a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;
+    return launch(a, ws ? ws_bytes : 0, stream);
 }
 
 // NHWC conv2d as implicit GEMM. x [B, Hin, Win, Cin] bf16; w [Cout, ks, ks, Cin] bf16 (OHWI);
@@ -250,7 +359,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
 // rowbias [B, Cout] is the per-image time-embedding add of ResnetBlock2D; res is [B,Hout,Wout,Cout].
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* stream) {
+                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv2d: empty problem");
     SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
     SPIDER_CHECK(stride == 1 || stride == 2, "conv2d: stride must be 1 or 2");
@@ -263,10 +372,10 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
     a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.C = (bf16_t*)y; a.C32 = nullptr;
     a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
     a.rows_per_group = Hout * Wout; a.M = B * Hout * Wout; a.N = Cout; a.K = ks * ks * Cin; a.lda = Cin; a.ldc = Cout;
-    a.act = 0; a.out_scale = out_scale;
+    a.act = 0; a.out_scale = out_scale; a.ws = (float*)ws;
     a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.ks = ks; a.stride = stride;
     a.pad = pad; a.ups = ups;
-    return launch(a, stream);
+    return launch(a, ws ? ws_bytes : 0, stream);
 }
 
 }  // extern "C"

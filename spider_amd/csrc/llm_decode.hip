@@ -570,20 +570,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 template <int D>
-__global__ __launch_bounds__(D) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                         bf16_t* __restrict__ out, int nsplit) {
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           bf16_t* __restrict__ out, int nsplit) {
+    static_assert(D == 128, "one wave covers the head dim with 2 elements per lane");
+    __shared__ float sm_m[4], sm_l[4], sm_o[4][D];
     const size_t bh = blockIdx.x;  // b * n_q + hq
-    const int dd = threadIdx.x;
-    float mm = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, part_ml[(bh * nsplit + s) * 2]);
-    float ll = 0.f, oo = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = part_ml[(bh * nsplit + s) * 2];
-        const float a = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
-        ll += part_ml[(bh * nsplit + s) * 2 + 1] * a;
-        oo += part_o[(bh * nsplit + s) * D + dd] * a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int s = wave; s < nsplit; s += 4) {
+        const float ms = part_ml[(bh * nsplit + s) * 2], ls = part_ml[(bh * nsplit + s) * 2 + 1];
+        const float2 ov = *reinterpret_cast<const float2*>(part_o + (bh * nsplit + s) * D + lane * 2);
+        const float mn = fmaxf(m, ms);
+        const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
+        const float bsc = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
+        l = l * a + ls * bsc;
+        o0 = o0 * a + ov.x * bsc;
+        o1 = o1 * a + ov.y * bsc;
+        m = mn;
     }
-    out[bh * D + dd] = f32_to_bf16(ll > 0.f ? oo / ll : 0.f);
+    if (lane == 0) { sm_m[wave] = m; sm_l[wave] = l; }
+    sm_o[wave][lane * 2] = o0;
+    sm_o[wave][lane * 2 + 1] = o1;
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int dd = threadIdx.x;
+        float mm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float ll = 0.f, oo = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - mm);
+            ll += sm_l[w] * a;
+            oo += sm_o[w][dd] * a;
+        }
+        out[bh * D + dd] = f32_to_bf16(ll > 0.f ? oo / ll : 0.f);
+    }
 }
 
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
@@ -724,7 +744,7 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
     }
     SPIDER_LAUNCH_OK();
     if (nsplit > 1) {
-        attn_combine_kernel<128><<<B * n_q, 128, 0, (hipStream_t)stream>>>((const float*)ws_o, (const float*)ws_ml,
+        attn_combine_kernel<128><<<B * n_q, 256, 0, (hipStream_t)stream>>>((const float*)ws_o, (const float*)ws_ml,
                                                                           (bf16_t*)out, nsplit);
         SPIDER_LAUNCH_OK();
     }

@@ -20,15 +20,13 @@ namespace {
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
                                 int nchunk, int KP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ch_sum = reinterpret_cast<float*>(smem);   // [C]
-    float* ch_sq = ch_sum + C;                         // [C]
+    float* sm_s = reinterpret_cast<float*>(smem);   // [KP][C]
+    float* sm_q = sm_s + KP * C;                    // [KP][C]
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cv = C / 8;
     const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
     const int per = (HW + nchunk - 1) / nchunk;
     const int p0 = chunk * per, p1 = min(HW, p0 + per);
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) ch_sum[i] = 0.f;
-    __syncthreads();
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -43,16 +41,23 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
             s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        atomicAdd(&ch_sum[v * 8 + j], s[j]);
-        atomicAdd(&ch_sq[v * 8 + j], q[j]);
+    *reinterpret_cast<f32x4*>(sm_s + pl * C + v * 8) = f32x4{s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f32x4*>(sm_s + pl * C + v * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+    *reinterpret_cast<f32x4*>(sm_q + pl * C + v * 8) = f32x4{q[0], q[1], q[2], q[3]};
+    *reinterpret_cast<f32x4*>(sm_q + pl * C + v * 8 + 4) = f32x4{q[4], q[5], q[6], q[7]};
+    __syncthreads();
+    // channel totals over the KP pixel lanes, kept in row 0
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float ts = 0.f, tq = 0.f;
+        for (int k = 0; k < KP; ++k) { ts += sm_s[k * C + c]; tq += sm_q[k * C + c]; }
+        sm_s[c] = ts;
+        sm_q[c] = tq;
     }
     __syncthreads();
     const int cpg = C / G;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         float gs = 0.f, gq = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { gs += ch_sum[c]; gq += ch_sq[c]; }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { gs += sm_s[c]; gq += sm_q[c]; }
         float* dst = partial + (((size_t)b * nchunk + chunk) * G + g) * 2;
         dst[0] = gs;
         dst[1] = gq;
@@ -66,20 +71,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
                                                        float eps, int silu, int pix_per_block) {
     __shared__ float mean[64], rstd[64];
+    __shared__ float ps[256], pq[256];
     const int b = blockIdx.y;
     const int cpg = C / G;
-    if (threadIdx.x < G) {
+    {
+        const int parts = 256 / G;                  // G in {32, 64, ...}: 8 or 4 parts
+        const int g = threadIdx.x % G, part = threadIdx.x / G;
         float gs = 0.f, gq = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* src = partial + (((size_t)b * nchunk + c) * G + threadIdx.x) * 2;
-            gs += src[0];
-            gq += src[1];
+        if (part < parts) {
+            for (int c = part; c < nchunk; c += parts) {
+                const float* src = partial + (((size_t)b * nchunk + c) * G + g) * 2;
+                gs += src[0];
+                gq += src[1];
+            }
         }
-        const float n = (float)HW * (float)cpg;
-        const float mu = gs / n;
-        const float var = fmaxf(gq / n - mu * mu, 0.f);
-        mean[threadIdx.x] = mu;
-        rstd[threadIdx.x] = rsqrtf(var + eps);
+        ps[threadIdx.x] = gs;
+        pq[threadIdx.x] = gq;
+        __syncthreads();
+        if (threadIdx.x < G) {
+            gs = 0.f; gq = 0.f;
+            for (int k = 0; k < parts; ++k) { gs += ps[k * G + threadIdx.x]; gq += pq[k * G + threadIdx.x]; }
+            const float n = (float)HW * (float)cpg;
+            const float mu = gs / n;
+            const float var = fmaxf(gq / n - mu * mu, 0.f);
+            mean[threadIdx.x] = mu;
+            rstd[threadIdx.x] = rsqrtf(var + eps);
+        }
     }
     __syncthreads();
     const int cv = C / 8;
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = reinterpret_cast<float*>(smem);
     const int kk = ks * ks * Cin;
-    for (int i = threadIdx.x; i < Cout * kk; i += 256) ws[i] = bf16_to_f32(w[i]);
+    for (int i = threadIdx.x; i < Cout * kk; i += 256) ws[(i % kk) * Cout + i / kk] = bf16_to_f32(w[i]);
     __syncthreads();
     const int cov = Cout / 8;
     const size_t total = (size_t)B * H * W * cov;
@@ -298,8 +315,10 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __res
                 const bf16_t* src = x + (((size_t)b * H + iy) * W + ix) * Cin;
                 for (int c = 0; c < Cin; ++c) {
                     const float xv = bf16_to_f32(src[c]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += xv * ws[(v * 8 + j) * kk + (ky * ks + kx) * Cin + c];
+                    const float* wk = ws + ((ky * ks + kx) * Cin + c) * Cout + v * 8;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
+                    acc[0] += xv * w0[0]; acc[1] += xv * w0[1]; acc[2] += xv * w0[2]; acc[3] += xv * w0[3];
+                    acc[4] += xv * w1[0]; acc[5] += xv * w1[1]; acc[6] += xv * w1[2]; acc[7] += xv * w1[3];
                 }
             }
         }
@@ -422,14 +441,14 @@ inline int grid_for(size_t n) {
 extern "C" {
 
 int spider_groupnorm_nchunk(int HW) {
-    int n = HW / 128;
-    return n < 1 ? 1 : (n > 64 ? 64 : n);
+    int n = HW / 32;
+    return n < 1 ? 1 : (n > 128 ? 128 : n);
 }
 
 // x, y [B, HW, C] bf16 (NHWC); ws >= B * nchunk * G * 2 floats, nchunk = spider_groupnorm_nchunk(HW)
 int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
                                int C, int G, float eps, int silu, void* stream) {
-    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "groupnorm: bad shape (G <= 64)");
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
     const int nchunk = spider_groupnorm_nchunk(HW);
     const int cv = C / 8;
@@ -438,7 +457,7 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
     const int threads = cv * KP;
     SPIDER_CHECK(threads <= 1024, "groupnorm: C too large");
     dim3 g1(nchunk, B);
-    gn_stats_kernel<<<g1, threads, (size_t)2 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
+    gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
                                                                                        G, nchunk, KP);
     SPIDER_LAUNCH_OK();
     int ppb = (8 * 256 * 4) / C;  // ~8K elements per thread block iteration set

@@ -248,7 +248,7 @@ class LlamaEngine:
     def _make_state(self, B: int, want_hidden: bool, want_logits: bool) -> dict:
         c, dv = self.cfg, self.device
         nq_d = c.n_q * c.head_dim
-        nsplit = max(1, min(64, 512 // max(1, B * c.n_kv)))
+        nsplit = max(1, min(32, 256 // max(1, B * c.n_kv)))
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dv)
         bf = lambda *s: torch.empty(*s, dtype=BF16, device=dv)
         npart = ops.lm_head_nparts(c.vocab)

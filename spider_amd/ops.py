@@ -22,6 +22,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_WS = {}
+WS_BYTES = 64 << 20
+
+
+def _workspace(device) -> torch.Tensor:
+    """Per-device fp32 split-K workspace (stream-ordered reuse; allocated once, outside any graph capture)."""
+    key = (device.type, device.index)
+    if key not in _WS:
+        _WS[key] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -137,7 +149,7 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
         out = torch.empty(*A.shape[:-1], N, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
     _lib.call("spider_gemm_bf16", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
-              M, N, K, K, N, ACT[act], float(out_scale), _stream())
+              M, N, K, K, N, ACT[act], float(out_scale), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
 
@@ -153,7 +165,7 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
     _lib.call("spider_conv2d_nhwc_bf16", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
-              ks, stride, pad, int(ups), float(out_scale), _stream())
+              ks, stride, pad, int(ups), float(out_scale), _p(_workspace(x.device)), WS_BYTES, _stream())
     return out
 
 

@@ -59,7 +59,10 @@ def test_engine_matches_oracle_d128(dev, seed):
     assert exact >= 16  # at least one full sequence's worth agrees
     # logits of the steps that share the same history (step 0 always does)
     got0 = out.logits[:, 0].float().cpu()
-    assert torch.allclose(got0, ref_logits[:, 0], atol=0.06, rtol=0.03), float((got0 - ref_logits[:, 0]).abs().max())
+    # bf16 path vs fp32 oracle: relative L2 < 2.5 %, no logit off by more than 5 % of the logit range
+    r0 = ref_logits[:, 0]
+    assert float((got0 - r0).norm() / r0.norm()) < 2.5e-2
+    assert float((got0 - r0).abs().max()) < 0.05 * float(r0.abs().max())
     # hidden states: step 0 is the prompt [B,S,H] x (L+1), later steps [B,1,H]
     assert len(out.hidden_states) == gen.shape[1]
     assert out.hidden_states[0][0].shape == (2, 21, 256) and out.hidden_states[1][0].shape == (2, 1, 256)
