@@ -119,6 +119,8 @@ int spider_latent_to_nhwc_bf16(const float* lat, void* out, int B, int C, int HW
 int spider_cfg_combine_f32(const float* eps2, float* out, int B, int C, int HW, float guidance, void* stream);
 /* scheduler.step as a linear update: out = sum_j host_coefs[j] * ins[j]; host_ins is a HOST array of n device ptrs */
 int spider_lincomb_f32(const float* const* host_ins, const float* host_coefs, int n, float* out, long total, void* stream);
+/* row softmax of fp32 scores -> bf16 probabilities (VAE mid-block single-head attention, d = 512) */
+int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, float scale, void* stream);
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream);
 
 #ifdef __cplusplus

@@ -431,6 +431,24 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
+// Row softmax: y[r, :] = bf16(softmax(scale * x[r, :])), x fp32 [rows, n] (scores of the VAE's single-head
+// d=512 attention, diffusers AttnProcessor on AutoencoderKL.mid_block.attentions.0). One block per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int n, float scale) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * n;
+    bf16_t* yr = y + (size_t)blockIdx.x * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += __expf(xr[i] * scale - m);
+    const float inv = 1.f / block_sum<4>(s, red);
+    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_bf16(__expf(xr[i] * scale - m) * inv);
+}
+
 inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -572,6 +590,13 @@ int spider_lincomb_f32(const float* const* ins, const float* coefs, int n, float
     lc.n = n;
     for (int j = 0; j < n; ++j) { lc.in[j] = ins[j]; lc.coef[j] = coefs[j]; }
     lincomb_kernel<<<grid_for((size_t)total), 256, 0, (hipStream_t)stream>>>(lc, out, (size_t)total);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, float scale, void* stream) {
+    SPIDER_CHECK(rows > 0 && n > 0 && scale > 0.f, "softmax_rows: bad shape");
+    softmax_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n, scale);
     SPIDER_LAUNCH_OK();
     return 0;
 }

@@ -347,3 +347,13 @@ def nhwc_to_nchw(x, mul=1.0, add_=0.0, clamp01=False, out=None):
         out = torch.empty(B, Cn, H, Wd, dtype=torch.float32, device=x.device)
     _lib.call("spider_nhwc_to_nchw_f32", _p(x), _p(out), B, Cn, H * Wd, float(mul), float(add_), int(clamp01), _stream())
     return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    """fp32 [rows, n] -> bf16 softmax(scale * x) per row."""
+    _chk(x, torch.float32, "x")
+    n = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.call("spider_softmax_rows_f32_bf16", _p(x), _p(out), x.numel() // n, n, float(scale), _stream())
+    return out

@@ -207,3 +207,26 @@ def test_story_write_sequence_matches_reference(golden_dir):
         assert torch.allclose(ya, torch.from_numpy(z["seq_ya"][step]), atol=2e-5), step
         assert torch.allclose(yb, torch.from_numpy(z["seq_yb"][step]), atol=2e-5), step
     assert st.cur_step == 7
+
+
+def test_clip_oracle_matches_transformers_tiny():
+    """The CLIP text encoder lives in `transformers` (reference call site custom_sd.py:306-310); pin the restatement
+    against the installed CLIPTextModel on a tiny random config."""
+    import transformers
+    from oracle.clip_vae import CLIPCfg, clip_param_shapes, clip_text_forward, random_weights
+    c = CLIPCfg.tiny()
+    hf = transformers.CLIPTextConfig(vocab_size=c.vocab, hidden_size=c.hidden, intermediate_size=c.inter,
+                                     num_hidden_layers=c.layers, num_attention_heads=c.heads,
+                                     max_position_embeddings=c.max_pos, hidden_act="quick_gelu", layer_norm_eps=c.eps,
+                                     pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    model = transformers.CLIPTextModel(hf).float().eval()
+    w = random_weights(clip_param_shapes(c), seed=4)
+    keys = set(model.state_dict().keys())
+    wl = w if "text_model.final_layer_norm.weight" in keys else {k.replace("text_model.", "", 1): v for k, v in w.items()}
+    missing, unexpected = model.load_state_dict(wl, strict=False)   # transformers 5.x dropped the text_model. prefix
+    assert not unexpected and not [k for k in missing if "position_ids" not in k], (missing, unexpected)
+    ids = torch.randint(3, c.vocab, (2, 77), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = model(input_ids=ids).last_hidden_state
+    got = clip_text_forward(c, w, ids)
+    assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4), float((got - ref).abs().max())

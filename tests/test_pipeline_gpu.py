@@ -1,0 +1,76 @@
+"""GPU: StableDiffusionPipeline call contract (custom_sd.py:476-667) on tiny engines with a stand-in tokenizer, and the
+SpiderDecoder image path end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipe(dev):
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from oracle.unet import UNetCfg, random_unet_weights
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.pipelines import StableDiffusionPipeline
+    from spider_amd.unet import UNetConfig, UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    from helpers import FakeTokenizer
+    uc, cc, vc = UNetCfg.tiny(), CLIPCfg.tiny(), VAECfg.tiny()
+    return StableDiffusionPipeline(UNetEngine(UNetConfig(**uc.__dict__), random_unet_weights(uc, seed=1), dev),
+                                   VAEDecoderEngine(VAEConfig(**vc.__dict__), random_weights(vae_param_shapes(vc), seed=2), dev),
+                                   CLIPTextEngine(CLIPTextConfig(**cc.__dict__), random_weights(clip_param_shapes(cc), seed=3), dev),
+                                   FakeTokenizer(), sample_size=16), (uc, cc, vc)
+
+
+def test_pipeline_contract(dev):
+    pipe, (uc, cc, vc) = _pipe(dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = pipe(prompt=["an apple on a table"], guidance_scale=7.5, num_inference_steps=6, generator=g)
+    assert len(out.images) == 1 and out.images[0].size == (64, 64)   # tiny VAE: 3 levels -> x4
+    # return_prompts_only: encoder states WITHOUT the CFG concat (custom_sd.py:589-605)
+    emb = pipe(["an apple on a table"], return_prompts_only=True)
+    assert emb.shape == (1, 77, cc.hidden)
+    # prompt_embeds path == prompt path (same latents)
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1))
+    a = pipe(prompt=["an apple on a table"], num_inference_steps=5, latents=lat, output_type="np").images
+    b = pipe(prompt_embeds=emb, num_inference_steps=5, latents=lat, output_type="np").images
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        pipe(prompt=["x"], height=100, width=64)
+    # left truncation of over-long prompts (custom_sd.py:267-276): keeps the LAST model_max_length tokens
+    long_prompt = " ".join(f"word{i}" for i in range(120))
+    ids = pipe._tokenize([long_prompt])
+    assert ids.shape == (1, 77)
+
+
+def test_pipeline_matches_oracle_end_to_end(dev):
+    """text -> CLIP -> PNDM loop -> VAE, HIP engines vs the fp32 oracle pieces chained the same way."""
+    from oracle.clip_vae import clip_text_forward, vae_decode
+    from oracle.unet import PNDMOracle, UNetOracle, denoise_loop
+    pipe, (uc, cc, vc) = _pipe(dev)
+    prompt = ["a cozy cabin in the snow"]
+    ids_c = pipe._tokenize(prompt)
+    ids_u = pipe.tokenizer([""], padding="max_length", max_length=77, truncation=True).input_ids
+    wu = {k: v.float().cpu() for k, v in pipe.unet.w.items()}  # not used: oracle takes the original fp32 dicts below
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from oracle.unet import UNetCfg, random_unet_weights
+    enc = torch.cat([clip_text_forward(cc, random_weights(clip_param_shapes(cc), seed=3), ids_u),
+                     clip_text_forward(cc, random_weights(clip_param_shapes(cc), seed=3), ids_c)])
+    lat0 = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    lat = denoise_loop(UNetOracle(uc, random_unet_weights(uc, seed=1)), PNDMOracle(), lat0, enc, 7.5, 6)
+    ref = vae_decode(vc, random_weights(vae_param_shapes(vc), seed=2), lat).permute(0, 2, 3, 1).numpy()
+    got = pipe(prompt=prompt, guidance_scale=7.5, num_inference_steps=6, latents=lat0, output_type="np").images
+    err = np.abs(got - ref)
+    assert err.mean() < 2e-2 and got.shape == ref.shape, float(err.mean())
+
+
+def test_spider_decoder_image_path(dev):
+    from spider_amd import routing
+    from spider_amd.spider_decoder import SpiderDecoder
+    pipe, _ = _pipe(dev)
+    dec = SpiderDecoder(diffusion_modules={}, pipelines=dict(IMAGE=pipe))
+    a, p, pt = dec.generate({"llm_text_all": ["Sure: <IMAGE>a red car</IMAGE>"]}, *routing.new_outputs())
+    assert pt["IMAGE"] == ["a red car"] and len(p["IMAGE"]) == 1 and p["IMAGE"][0].size == (64, 64)
+    dec2 = SpiderDecoder(diffusion_modules={}, pipelines=dict(IMAGE=pipe), get_prompt_embed_for_diffusion=True)
+    a, p2, _ = dec2.generate({"llm_text_all": ["<IMAGE>a red car</IMAGE>"]}, *routing.new_outputs())
+    assert len(p2["IMAGE"]) == 1

@@ -1,0 +1,154 @@
+"""GPU: StoryDiffusion consistent self-attention on the HIP kernels against (a) the reference-generated golden
+sequence (tests/golden/story_ref.npz: SpatialAttnProcessor2_0 driven through 7 write-phase steps with recorded coin
+flips) and (b) the fp32 oracle inside a tiny SDXL-like UNet in write and read mode; plus the story_generation API."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+class _Eng:
+    """Minimal stand-in for UNetEngine: the hook only needs the fused qkv weight table."""
+    def __init__(self, w):
+        self.w = w
+
+
+def test_consistent_attention_matches_reference_sequence(dev, golden_dir):
+    from spider_amd.story import ConsistentSelfAttention, StoryState
+    z = np.load(os.path.join(golden_dir, "story_ref.npz"))
+    C, heads, hh, ww = [int(v) for v in z["seq_cfg"]]
+    coins = iter([float(c) for row in z["seq_coins"] for c in row if c >= 0])
+    torch.manual_seed(2047)   # CPU stream of the fixture generator (device="cpu" there)
+    st = StoryState(total_count=2, height=hh, width=ww, coin=lambda: next(coins),
+                    uniforms=lambda n: torch.rand((1, n), dtype=torch.float32).reshape(-1))
+    st.regen_masks(dev)
+    hook = ConsistentSelfAttention(st)
+    engs, outw = {}, {}
+    for tag in ("sa", "sb"):
+        t = lambda k: torch.from_numpy(z[f"seq_{tag}_{k}"])
+        qkv = torch.cat([t("to_q.weight"), t("to_k.weight"), t("to_v.weight")], 0).to(BF)
+        engs[tag] = _Eng({f"up_blocks.0.{tag}.attn1.qkv": qkv.to(dev)})
+        outw[tag] = (t("to_out.0.weight"), t("to_out.0.bias"))
+    for step in range(7):
+        # fixture rows are mask row 0 = keep | own block 0; outside block 0 they must equal our keep vectors
+        assert torch.equal(st.keep1024[2:], torch.from_numpy(z["seq_keep1024"][step])[2:])
+        assert torch.equal(st.keep4096[8:], torch.from_numpy(z["seq_keep4096"][step])[8:])
+        for tag, xk, yk in (("sa", "seq_xa", "seq_ya"), ("sb", "seq_xb", "seq_yb")):
+            x = torch.from_numpy(z[xk][step]).to(BF)
+            o = hook(engs[tag], f"up_blocks.0.{tag}.attn1", x.to(dev), heads).float().cpu()
+            got = F.linear(o, outw[tag][0].to(BF).float(), outw[tag][1])
+            ref = torch.from_numpy(z[yk][step])
+            rel = float((got - ref).norm() / ref.norm())
+            assert rel < 2e-2, (step, tag, rel)      # bf16 inputs/weights/P vs the reference's fp32 run
+    assert st.cur_step == 7
+
+
+def _mk(sdxl_seed=5):
+    from oracle.unet import UNetCfg, random_unet_weights
+    from spider_amd.unet import UNetConfig
+    ocfg = UNetCfg.tiny(True)
+    w = random_unet_weights(ocfg, seed=sdxl_seed)
+    return ocfg, w, UNetConfig(**ocfg.__dict__)
+
+
+class _OracleHook:
+    """Adapts oracle.story.ProcessorOracle to UNetOracle.attn_hook."""
+    def __init__(self, st, w):
+        from oracle import story as ostory
+        self.st, self.w, self.os, self.procs = st, w, ostory, {}
+
+    def wants(self, name):
+        return name.startswith("up_blocks") and name.endswith("attn1")
+
+    def __call__(self, unet, name, y, heads):
+        w = self.w
+        aw = self.os.AttnWeights(w[name + ".to_q.weight"], w[name + ".to_k.weight"], w[name + ".to_v.weight"],
+                                 w[name + ".to_out.0.weight"], w[name + ".to_out.0.bias"], heads)
+        return self.procs.setdefault(name, self.os.ProcessorOracle())(self.st, aw, y)
+
+
+def test_story_unet_write_then_read_matches_oracle(dev):
+    from oracle import story as ostory
+    from oracle.unet import UNetOracle
+    from spider_amd.story import ConsistentSelfAttention, StoryState
+    from spider_amd.unet import UNetEngine
+    ocfg, w, cfg = _mk()
+    hh = ww = 64            # latent 8x8 -> attention at N = 16 (4x4) and N = 4 (2x2) = (h/16)^2 and (h/32)^2
+    g = torch.Generator().manual_seed(1)
+    coins_seq = [torch.rand(1, generator=g).item() for _ in range(200)]
+    unis = [torch.rand(4000, generator=g) for _ in range(40)]
+
+    def run(side, write_steps=7, read_steps=6):
+        ci, ui = iter(coins_seq), iter(unis)
+        hooks = dict(coin=lambda: next(ci), uniforms=lambda n: next(ui)[:n])
+        outs = []
+        if side == "oracle":
+            unet = UNetOracle(ocfg, w)
+            n_proc = sum(1 for k in w if k.startswith("up_blocks") and k.endswith(".attn1.to_q.weight"))
+            st = ostory.StoryState(total_count=n_proc, height=hh, width=ww, **hooks)
+            st.regen_masks()
+            unet.attn_hook = _OracleHook(st, unet.w)
+        else:
+            unet = UNetEngine(cfg, w, dev)
+            st = StoryState(total_count=ConsistentSelfAttention.count_processors(unet), height=hh, width=ww, **hooks)
+            st.regen_masks(dev)
+            unet.self_attn_hook = ConsistentSelfAttention(st)
+        gg = torch.Generator().manual_seed(2)
+        for phase, B2, nsteps in (("write", 8, write_steps), ("read", 2, read_steps)):
+            st.write, st.cur_step, st.attn_count = phase == "write", 0, 0
+            enc = torch.randn(B2, 77, ocfg.cross_dim, generator=gg).bfloat16().float()
+            added = dict(text_embeds=torch.randn(B2, 64, generator=gg).bfloat16().float(),
+                         time_ids=torch.tensor([[hh, ww, 0, 0, hh, ww]] * B2, dtype=torch.float32))
+            ts = torch.tensor([981 - 60 * i for i in range(nsteps)])
+            if side != "oracle":
+                unet.prepare(ts, enc.to(dev), added)
+            for i, t in enumerate(ts):
+                x = torch.randn(B2, 4, 8, 8, generator=gg).bfloat16().float()
+                if side == "oracle":
+                    outs.append(unet.forward(x, t, enc, added))
+                else:
+                    e = unet.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(BF), i)
+                    outs.append(e.permute(0, 3, 1, 2).float().cpu())
+        return outs, st
+
+    ref, st_o = run("oracle")
+    got, st_g = run("hip")
+    assert st_o.cur_step == st_g.cur_step == 6
+    for i, (a, b) in enumerate(zip(got, ref)):
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2.5e-2, (i, rel)
+
+
+def test_story_generation_api(dev):
+    """story_generation end to end on tiny engines: 4 id images + 1 real image, deterministic for a fixed seed."""
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.story import StableDiffusionXLPipeline, story_generation
+    from spider_amd.unet import UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    from helpers import FakeTokenizer
+    ocfg, w, cfg = _mk(9)     # cross_dim 64 = 32 + 32 (two tiny text encoders), pooled 64, time ids 6 x 32
+    c1 = CLIPCfg(400, 32, 2, 2, 64, 77)
+    w1 = random_weights(clip_param_shapes(c1), seed=1)
+    w2 = random_weights(clip_param_shapes(c1), seed=2)
+    w2["text_projection.weight"] = torch.randn(64, 32) * 0.1
+    vc = VAECfg(4, 3, (64, 64, 64, 128), 1, 32)     # 4 levels -> x8, so latent = height / 8 as the N rule of the processor assumes
+    pipe = StableDiffusionXLPipeline(UNetEngine(cfg, w, dev), VAEDecoderEngine(VAEConfig(**vc.__dict__), random_weights(vae_param_shapes(vc), seed=3), dev),
+                                     CLIPTextEngine(CLIPTextConfig(**c1.__dict__), w1, dev), CLIPTextEngine(CLIPTextConfig(**c1.__dict__), w2, dev),
+                                     FakeTokenizer(), FakeTokenizer(), DDIMScheduler())
+    pipe.enable_freeu(0.6, 0.4, 1.1, 1.2)
+    args = dict(general_prompt="a man with a black suit", prompt_array=["wake up", "have breakfast", "go to work", "read a book", "sleep"],
+                style_name="Comic book", height=64, width=64, num_steps=7, output_type="np")
+    a = story_generation(pipe, **args)
+    b = story_generation(pipe, **args)
+    assert len(a) == 5 and a[0].shape == (64, 64, 3)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert pipe.unet.self_attn_hook is None
