@@ -132,9 +132,20 @@ def measure_roofline(resp, device):
     us = e0.elapsed_time(e1) * 1e3 / n
     bytes_alg = 2 * c.inter * c.hidden * 2 + c.hidden * 2 + c.hidden * 2 + c.inter * 2
     achieved = bytes_alg / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
+    # valid for the shapes it was collected on
+    traffic, src = None, None
+    pm = os.path.join(ROOT, "profiles", "r01_pmc_decode_hbm.json")
+    if os.path.exists(pm) and bytes_alg == 271633408:
+        try:
+            traffic = json.load(open(pm))["dominant_kernel"]["hbm_read_bytes_corrected"]
+            src = "profiles/r01_pmc_decode_hbm.json"
+        except Exception:
+            pass
     return {"bound": "hbm", "kernel": "gemv_kernel<NB=1,R=1,GATEUP=1,XLDS=1> (decode gate/up + SwiGLU)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n}
+            "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
+            "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n}
 
 
 def cpu_baseline(args):

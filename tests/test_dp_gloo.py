@@ -1,0 +1,64 @@
+"""CPU, 2 processes over gloo: the data-parallel layer (spider_amd/dp.py) -- strided prompt sharding, ONE gather of the
+padded outputs to rank 0, and the un-sharding on the root. The per-rank 'engine' is a stand-in (token ids derived
+from the prompt index) so that the test exercises only the N > 1 host logic that bench.py --gpus N runs."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from spider_amd import dp
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    mine = dp.shard_indices(n_items, rank, world)
+    per_rank_max = (n_items + world - 1) // world
+    toks = torch.stack([torch.arange(6, dtype=torch.int32) + 100 * i for i in mine]) if mine else torch.zeros(0, 6, dtype=torch.int32)
+    imgs = torch.stack([torch.full((3, 4, 4), i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 3, 4, 4, dtype=torch.uint8)
+    g = dp.gather_padded({"tokens": toks, "images": imgs}, per_rank_max, rank, world, dst=0)
+    if rank == 0:
+        assert g["count"].tolist() == [len(dp.shard_indices(n_items, r_, world)) for r_ in range(world)]
+        full = dp.unshard(g, n_items, world)
+        q.put((full["tokens"][:, 0].tolist(), full["images"][:, 0, 0, 0].tolist()))
+    else:
+        assert g is None
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_gather_unshard_world2():
+    n_items = 5   # ragged: rank 0 gets 3 prompts, rank 1 gets 2 (padding exercised)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    toks, imgs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert toks == [100 * i for i in range(n_items)] and imgs == list(range(n_items))
+
+
+def test_single_process_gather_and_length_ordering():
+    from spider_amd import dp
+    g = dp.gather_padded({"x": torch.ones(2, 3)}, 4, rank=0, world=1)
+    assert g["x"].shape == (1, 4, 3) and g["count"].tolist() == [2]
+    assert dp.order_by_length([5, 50, 20]) == [1, 2, 0]
+    assert dp.shard_indices(10, 3, 8) == [3] and dp.shard_indices(3, 5, 8) == []
