@@ -65,6 +65,14 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
                             const int* kv_end, void* out, void* ws_o, void* ws_ml, int B, int n_q, int n_kv, int d,
                             int T_max, float scale, int nsplit, void* stream);
 
+/* The three calls above (RoPE, KV append, attention + combine) fused into ONE launch for decode: qkv [B,(n_q+2n_kv)d]
+ * is the current token's fused projection; kv_end[b] INCLUDES the current token (slot kv_end[b]-1 is written here).
+ * counters: int[B*n_kv], zeroed once at allocation (the kernel resets them). */
+int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* cos_sin, void* k_cache, void* v_cache,
+                                  const int* kv_beg, const int* kv_end, void* out, void* ws_o, void* ws_ml,
+                                  int* counters, int B, int n_q, int n_kv, int d, int T_max, float scale, int nsplit,
+                                  void* stream);
+
 /* ======================= MFMA GEMM / conv / attention ======================= */
 
 /* C = act(A[M,K] . W[N,K]^T + bias[N] + rowbias[row/rows_per_group, N]) (+res) * out_scale.

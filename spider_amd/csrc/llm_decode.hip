@@ -10,6 +10,7 @@
 // Layouts: activations [B, H] bf16 row-major; weights [N, K] bf16 row-major (nn.Linear layout, never
 // transposed); KV cache [B, n_kv, T_max, d] bf16. All reductions accumulate in fp32.
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace spider;
 
@@ -606,20 +607,249 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fused decode attention: RoPE(q, k_new) + KV-cache append + split-KV attention + cross-block combine in ONE
+// launch (replaces rope_kv_kernel + attn_decode_kernel + attn_combine_kernel: 3 launches -> 1 per layer).
+//   qkv [B, (n_q + 2 n_kv) * D] : fused projection of the current token;  pos [B] rotary position
+//   caches [B, n_kv, T_max, D]; valid slots [kv_beg, kv_end) where slot kv_end-1 is THIS token: it is rotated in
+//   registers, used from registers by the last split and written to the cache by that block only, so no block
+//   reads a cache row another block writes in this launch.
+// Cross-block combine (split-KV): every block stores its partial (m, l, O) with plain stores, drains them,
+// lane 0 issues an agent-scope release and takes a ticket on cnt[b, kv head]; the block that draws the last
+// ticket issues an agent-scope acquire, reduces all partials and writes the output (placement-independent
+// release/acquire hand-off; the counter is reset by the reducer, so graph replays need no memset).
+// ----------------------------------------------------------------------------------------------
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(
+    const bf16_t* __restrict__ qkv, const int* __restrict__ pos, const float* __restrict__ cs, bf16_t* __restrict__ kc,
+    bf16_t* __restrict__ vc, const int* __restrict__ kv_beg, const int* __restrict__ kv_end, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int* __restrict__ cnt, bf16_t* __restrict__ out, int n_kv, int T_max, float scale,
+    int nsplit, int inline_combine) {
+    static_assert(D == 128, "decode attention is specialised for head_dim 128");
+    constexpr int HALF = D / 2;
+    const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+    const int n_q = n_kv * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4;
+    const int dl = (lane & 15) * 8;
+    const bool hi_half = dl >= HALF;
+    const int dp = hi_half ? dl - HALF : dl + HALF;   // rotary partner chunk
+    const int beg = kv_beg ? kv_beg[b] : 0, end = kv_end[b];
+    const int t_new = end - 1;                        // slot of the current token
+    const int len_old = max(t_new - beg, 0);
+    const int per = (len_old + nsplit - 1) / nsplit;
+    const int t0 = beg + split * per, t1 = min(t_new, t0 + per);
+
+    const bf16_t* row = qkv + (size_t)b * (n_q + 2 * n_kv) * D;
+    const float* c = cs + (size_t)pos[b] * D;
+    float cosv[8], sinv[8];
+    {
+        const int ci = hi_half ? dl - HALF : dl;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(c + ci), c1 = *reinterpret_cast<const f32x4*>(c + ci + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(c + HALF + ci), s1 = *reinterpret_cast<const f32x4*>(c + HALF + ci + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cosv[j] = c0[j]; cosv[4 + j] = c1[j]; sinv[j] = s0[j]; sinv[4 + j] = s1[j]; }
+    }
+    // rotate 8 elements of one head: out = bf16( bf16(x*cos) + bf16(+-partner*sin) )  (rope_kv_kernel's arithmetic)
+    auto rope8 = [&](const bf16_t* head, float (&o)[8]) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(head + dl), pq = *reinterpret_cast<const u32x4*>(head + dp);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, pw[4] = {pq.x, pq.y, pq.z, pq.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
+            const float pv = (j & 1) ? bf16hi_to_f32(pw[j >> 1]) : bf16lo_to_f32(pw[j >> 1]);
+            const float t1_ = bf16_to_f32(f32_to_bf16(xv * cosv[j]));
+            const float t2_ = bf16_to_f32(f32_to_bf16((hi_half ? pv : -pv) * sinv[j]));
+            o[j] = bf16_to_f32(f32_to_bf16(t1_ + t2_));
+        }
+    };
+
+    float qf[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rope8(row + (size_t)(hk * G + g) * D, qf[g]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[g][j] *= scale;
+    }
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+    }
+    const bf16_t* kbase = kc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+    const bf16_t* vbase = vc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+
+    auto update = [&](const float (&kf)[8], const float (&vf)[8]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float sc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc += qf[g][j] * kf[j];
+            sc += __shfl_xor(sc, 1, 64);
+            sc += __shfl_xor(sc, 2, 64);
+            sc += __shfl_xor(sc, 4, 64);
+            sc += __shfl_xor(sc, 8, 64);
+            const float mn = fmaxf(m[g], sc);
+            const float alpha = __expf(m[g] - mn);
+            const float pr = __expf(sc - mn);
+            l[g] = l[g] * alpha + pr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * alpha + pr * vf[j];
+            m[g] = mn;
+        }
+    };
+
+    for (int t = t0 + wave * 4 + sub; t < t1; t += 16) {
+        const u32x4 kq = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
+        const u32x4 vq = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
+        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kf[2 * j] = bf16lo_to_f32(kw[j]); kf[2 * j + 1] = bf16hi_to_f32(kw[j]);
+            vf[2 * j] = bf16lo_to_f32(vw[j]); vf[2 * j + 1] = bf16hi_to_f32(vw[j]);
+        }
+        update(kf, vf);
+    }
+    // the current token: last split, wave 0, row sub-group 0 (16 lanes) -- from registers, and appended to the cache
+    if (split == nsplit - 1 && wave == 0 && sub == 0 && t_new >= beg) {
+        float kf[8], vf[8];
+        rope8(row + (size_t)(n_q + hk) * D, kf);
+        const u32x4 vq = *reinterpret_cast<const u32x4*>(row + (size_t)(n_q + n_kv + hk) * D + dl);
+        const uint32_t vw[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vf[2 * j] = bf16lo_to_f32(vw[j]); vf[2 * j + 1] = bf16hi_to_f32(vw[j]); }
+        update(kf, vf);
+        u32x4 ko;
+        ko.x = pack_bf16x2(kf[0], kf[1]); ko.y = pack_bf16x2(kf[2], kf[3]);
+        ko.z = pack_bf16x2(kf[4], kf[5]); ko.w = pack_bf16x2(kf[6], kf[7]);
+        *reinterpret_cast<u32x4*>(kc + (((size_t)b * n_kv + hk) * T_max + t_new) * D + dl) = ko;
+        *reinterpret_cast<u32x4*>(vc + (((size_t)b * n_kv + hk) * T_max + t_new) * D + dl) = vq;
+    }
+
+    // merge the 4 row sub-groups of the wave, then the 4 waves via LDS
+    __shared__ float sm_m[4][G], sm_l[4][G];
+    __shared__ float sm_o[4][G][D];
+    __shared__ int sm_last;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float m2 = __shfl_xor(m[g], off, 64);
+            const float l2 = __shfl_xor(l[g], off, 64);
+            const float mn = fmaxf(m[g], m2);
+            const float a1 = (m[g] == -INFINITY) ? 0.f : __expf(m[g] - mn);
+            const float a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+            l[g] = l[g] * a1 + l2 * a2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o2 = __shfl_xor(o[g][j], off, 64);
+                o[g][j] = o[g][j] * a1 + o2 * a2;
+            }
+            m[g] = mn;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm_o[wave][g][dl + j] = o[g][j];
+            if (lane == 0) { sm_m[wave][g] = m[g]; sm_l[wave][g] = l[g]; }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+        const int g = idx / D, dd = idx % D;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm_m[w][g]);
+        float ll = 0.f, oo = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = (sm_m[w][g] == -INFINITY) ? 0.f : __expf(sm_m[w][g] - mm);
+            ll += sm_l[w][g] * a;
+            oo += sm_o[w][g][dd] * a;
+        }
+        const int hq = hk * G + g;
+        if (nsplit == 1) {
+            out[((size_t)b * n_q + hq) * D + dd] = f32_to_bf16(ll > 0.f ? oo / ll : 0.f);
+        } else {
+            const size_t pi = ((size_t)b * n_q + hq) * nsplit + split;
+            part_o[pi * D + dd] = oo;
+            if (dd == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
+        }
+    }
+    if (nsplit == 1 || !inline_combine) return;
+
+    // ---- publish the partials, take a ticket; the last arriver reduces ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep: the compiler may drop the fence's own wait
+        const int ticket = __hip_atomic_fetch_add(cnt + (size_t)b * n_kv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = (ticket == nsplit - 1) ? 1 : 0;
+        if (sm_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    // reducer: wave w owns heads w, w+4 (no LDS, no barriers); each lane 2 head-dim elements, loop over the splits
+    for (int g = wave; g < G; g += 4) {
+        const size_t bh = (size_t)b * n_q + hk * G + g;
+        float mr = -INFINITY, lr = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll 4
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float ms = part_ml[(bh * nsplit + sidx) * 2], ls = part_ml[(bh * nsplit + sidx) * 2 + 1];
+            const float2 ov = *reinterpret_cast<const float2*>(part_o + (bh * nsplit + sidx) * D + lane * 2);
+            const float mn = fmaxf(mr, ms);
+            const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mn);
+            const float bs = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
+            lr = lr * a + ls * bs;
+            o0 = o0 * a + ov.x * bs;
+            o1 = o1 * a + ov.y * bs;
+            mr = mn;
+        }
+        const float inv = lr > 0.f ? 1.f / lr : 0.f;
+        *reinterpret_cast<uint32_t*>(out + bh * D + lane * 2) = pack_bf16x2(o0 * inv, o1 * inv);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(cnt + (size_t)b * n_kv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
     gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
         (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
         (const bf16_t*)norm_w, eps, N, K)
+
+static int gemv_env_r() {
+    static const int v = [] { const char* e = getenv("SPIDER_GEMV_R"); return e ? atoi(e) : 0; }();
+    return v;
+}
 
 template <int NB, bool GU>
 static int gemv_dispatch(const void* W, const void* x, void* out, const void* bias, const void* res,
                          const void* norm_w, float eps, int N, int K, void* stream) {
     const bool xlds = (size_t)NB * K * 2 <= 64 * 1024;
     if (!xlds) SPIDER_CHECK(norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
-    constexpr int R = GU ? 1 : 2;
+    // rows per wave: 1 for the fused gate/up form (2 weight rows per output) and for small matrices (more blocks in
+    // flight hide the per-block activation prologue), 2 otherwise
+    int R = GU ? 1 : 2;
+    if (!GU && (size_t)N * K * 2 < (size_t)48 << 20) R = 1;
+    if (gemv_env_r()) R = gemv_env_r();
+    if (GU && R > 2) R = 2;
+    if (NB > 4 && R > 2) R = 2;
     const int grid = (N + 4 * R - 1) / (4 * R);
-    if (xlds) GEMV_LAUNCH(NB, R, GU, true);
-    else GEMV_LAUNCH(NB, R, GU, false);
+#define GEMV_PICK(R_)                                   \
+    do {                                                \
+        if (xlds) GEMV_LAUNCH(NB, R_, GU, true);        \
+        else GEMV_LAUNCH(NB, R_, GU, false);            \
+    } while (0)
+    if (R == 1) GEMV_PICK(1);
+    else if (R == 2) GEMV_PICK(2);
+    else GEMV_PICK(4);
+#undef GEMV_PICK
     SPIDER_LAUNCH_OK();
     return 0;
 }
@@ -744,6 +974,41 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
     }
     SPIDER_LAUNCH_OK();
     if (nsplit > 1) {
+        attn_combine_kernel<128><<<B * n_q, 256, 0, (hipStream_t)stream>>>((const float*)ws_o, (const float*)ws_ml,
+                                                                          (bf16_t*)out, nsplit);
+        SPIDER_LAUNCH_OK();
+    }
+    return 0;
+}
+
+#define ATTN_FUSED_LAUNCH(G_)                                                                                   \
+    attn_decode_fused_kernel<128, G_><<<grid, 256, 0, (hipStream_t)stream>>>(                                   \
+        (const bf16_t*)qkv, pos, cos_sin, (bf16_t*)k_cache, (bf16_t*)v_cache, kv_beg, kv_end, (float*)ws_o,      \
+        (float*)ws_ml, counters, (bf16_t*)out, n_kv, T_max, scale, nsplit, inline_combine)
+
+// Fused decode attention (RoPE + KV append of the current token + split-KV attention + combine), one launch.
+// kv_end[b] INCLUDES the current token (its slot is kv_end[b]-1). counters: int[B*n_kv], zero before first use.
+int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* cos_sin, void* k_cache, void* v_cache,
+                                  const int* kv_beg, const int* kv_end, void* out, void* ws_o, void* ws_ml,
+                                  int* counters, int B, int n_q, int n_kv, int d, int T_max, float scale, int nsplit,
+                                  void* stream) {
+    SPIDER_CHECK(d == 128, "attn_decode_fused: head_dim must be 128");
+    SPIDER_CHECK(B > 0 && n_kv > 0 && n_q % n_kv == 0 && nsplit >= 1 && T_max > 0, "attn_decode_fused: bad shape");
+    SPIDER_CHECK(nsplit == 1 || (ws_o && ws_ml && counters), "attn_decode_fused: workspace + counters required for nsplit > 1");
+    const int G = n_q / n_kv;
+    dim3 grid(nsplit, n_kv, B);
+    // combine inline (ticket + last-arriver reduce) or by the separate combine kernel (SPIDER_ATTN_INLINE=0/1)
+    static const int inline_combine = [] { const char* e = getenv("SPIDER_ATTN_INLINE"); return e ? atoi(e) : 0; }();
+    switch (G) {
+        case 1: ATTN_FUSED_LAUNCH(1); break;
+        case 2: ATTN_FUSED_LAUNCH(2); break;
+        case 4: ATTN_FUSED_LAUNCH(4); break;
+        case 7: ATTN_FUSED_LAUNCH(7); break;
+        case 8: ATTN_FUSED_LAUNCH(8); break;
+        default: spider_set_error("attn_decode_fused: GQA group size must be one of 1,2,4,7,8"); return -1;
+    }
+    SPIDER_LAUNCH_OK();
+    if (nsplit > 1 && !inline_combine) {
         attn_combine_kernel<128><<<B * n_q, 256, 0, (hipStream_t)stream>>>((const float*)ws_o, (const float*)ws_ml,
                                                                           (bf16_t*)out, nsplit);
         SPIDER_LAUNCH_OK();

@@ -226,10 +226,14 @@ class LlamaEngine:
             hs[0].copy_(h)
         for l, lw in enumerate(self.layers):
             ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
-            ops.rope_kv_append(st["qkv"], st["pos"], st["slot"], self.cos_sin, st["q"], self.k_cache[l], self.v_cache[l],
-                               B, 1, c.n_q, c.n_kv, c.head_dim)
-            ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
-                            nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
+            if c.head_dim == 128:   # RoPE + KV append + split-KV attention + combine: one launch
+                ops.attn_decode_fused(st["qkv"], st["pos"], self.cos_sin, self.k_cache[l], self.v_cache[l], st["kv_end"],
+                                      st["kv_beg"], st["attn_cnt"], c.n_q, st["nsplit"], st["attn_ws"], st["attn"])
+            else:
+                ops.rope_kv_append(st["qkv"], st["pos"], st["slot"], self.cos_sin, st["q"], self.k_cache[l], self.v_cache[l],
+                                   B, 1, c.n_q, c.n_kv, c.head_dim)
+                ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
+                                nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
             h1 = ops.gemv(lw["w_o"], st["attn"], res=h, out=st["h1"])
             ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
             h = ops.gemv(lw["w_down"], st["act"], res=h1, out=st["h2"][l & 1])
@@ -258,7 +262,7 @@ class LlamaEngine:
                   attn_ws=(torch.empty(B * c.n_q * nsplit * c.head_dim, dtype=torch.float32, device=dv),
                            torch.empty(B * c.n_q * nsplit * 2, dtype=torch.float32, device=dv)),
                   lm_ws=(torch.empty(B * npart, dtype=torch.float32, device=dv), i32(B * npart)),
-                  embeds_in=None)
+                  attn_cnt=i32(B * c.n_kv), embeds_in=None)
         if want_hidden:
             st["hidden_buf"] = bf(c.layers + 1, B, c.hidden)
         if want_logits:

@@ -138,6 +138,22 @@ def attn_decode(q, k_cache, v_cache, kv_end, kv_beg=None, nsplit=1, ws=None, out
     return out
 
 
+def attn_decode_fused(qkv, pos, cos_sin, k_cache, v_cache, kv_end, kv_beg, counters, n_q, nsplit, ws, out, scale=None):
+    """RoPE + KV append + split-KV decode attention + combine in one launch. kv_end includes the current token."""
+    _chk(qkv, BF16, "qkv"); _chk(pos, torch.int32, "pos"); _chk(cos_sin, torch.float32, "cos_sin")
+    _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache"); _chk(kv_end, torch.int32, "kv_end")
+    _chk(counters, torch.int32, "counters"); _chk(out, BF16, "out")
+    B = kv_end.numel()
+    n_kv, T_max, d = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
+    assert qkv.numel() == B * (n_q + 2 * n_kv) * d and counters.numel() >= B * n_kv and cos_sin.shape[1] == d
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    _lib.call("spider_attn_decode_fused_bf16", _p(qkv), _p(pos), _p(cos_sin), _p(k_cache), _p(v_cache), _p(kv_beg), _p(kv_end),
+              _p(out), _p(ws[0]) if ws else None, _p(ws[1]) if ws else None, _p(counters), B, n_q, n_kv, d, T_max,
+              float(scale), nsplit, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------- GEMM / conv / attention
 def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, out_scale=1.0, out=None, out_f32=False):
     """C = act(A @ W^T + bias + rowbias[row // rows_per_group]) (+ res) * out_scale.  A [..., K], W [N, K]."""

@@ -309,3 +309,34 @@ def test_latent_plumbing(ops, dev):
     close(ops.lincomb([t.to(dev) for t in ts], cs), sum(c * t for c, t in zip(cs, ts)), 1e-5, 1e-5, "lincomb")
     img = torch.randn(1, 16, 16, 3, generator=g)
     close(ops.nhwc_to_nchw(img.to(dev), 0.5, 0.5, True), (img * 0.5 + 0.5).clamp(0, 1).permute(0, 3, 1, 2), 1e-6, 1e-6, "post")
+
+
+@pytest.mark.parametrize("B,n_q,n_kv,T,nsplit,beg", [(1, 28, 4, 1537, 32, 0), (2, 32, 8, 300, 8, 0), (3, 8, 8, 1, 4, 0),
+                                                    (2, 4, 2, 130, 5, 17), (1, 7, 1, 6, 1, 0), (1, 28, 4, 2000, 32, 0)])
+def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
+    """One-launch RoPE + KV append + split-KV attention + cross-block combine == the three separate kernels
+    (bit-identical cache rows, outputs equal up to fp32 summation order), repeated to exercise the self-resetting
+    ticket counters the way hipGraph replays do."""
+    from oracle.llama import LlamaCfg, rope_table
+    d, Tmax = 128, T + 5
+    cs = rope_table(LlamaCfg(head_dim=d, rope_theta=1e6), Tmax + 8).to(dev)
+    kc0, vc0 = rnd(B, n_kv, Tmax, d, seed=2).to(dev), rnd(B, n_kv, Tmax, d, seed=3).to(dev)
+    kv_end = torch.tensor([T - (b % 2) * (1 if T > 3 else 0) for b in range(B)], dtype=torch.int32, device=dev)
+    kv_beg = torch.full((B,), beg, dtype=torch.int32, device=dev)
+    pos = (kv_end - 1 - kv_beg).to(torch.int32)
+    slot = (kv_end - 1).to(torch.int32)
+    cnt = torch.zeros(B * n_kv, dtype=torch.int32, device=dev)
+    ws = (torch.empty(B * n_q * nsplit * d, dtype=torch.float32, device=dev), torch.empty(B * n_q * nsplit * 2, dtype=torch.float32, device=dev))
+    for rep in range(3):
+        qkv = rnd(B, (n_q + 2 * n_kv) * d, seed=10 + rep).to(dev)
+        # reference path: separate kernels on a copy of the caches
+        k1, v1 = kc0.clone(), vc0.clone()
+        q = torch.empty(B, 1, n_q, d, dtype=BF, device=dev)
+        ops.rope_kv_append(qkv, pos, slot, cs, q, k1, v1, B, 1, n_q, n_kv, d)
+        ref = ops.attn_decode(q.view(B, n_q, d), k1, v1, kv_end, kv_beg=kv_beg, nsplit=nsplit)
+        k2, v2 = kc0.clone(), vc0.clone()
+        out = torch.empty(B, n_q * d, dtype=BF, device=dev)
+        ops.attn_decode_fused(qkv, pos, cs, k2, v2, kv_end, kv_beg, cnt, n_q, nsplit, ws, out)
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "KV append must be bit-identical"
+        close(out, ref.float(), 4e-3, 1e-2, f"fused decode attention rep {rep}")
+        assert int(cnt.abs().sum()) == 0, "ticket counters must be back to zero after every launch"
