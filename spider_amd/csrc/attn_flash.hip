@@ -44,11 +44,12 @@ struct Cfg {
 };
 
 template <int DP>
-__global__ __launch_bounds__(256) void attn_flash_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + 64 * C::KS;
+    // two LDS images [K tile | V tile]: tile t+1 is written while tile t is still being read -> one barrier per tile
+    constexpr int IMG = 64 * (C::KS + C::VS);
+    bf16_t* const lds0 = reinterpret_cast<bf16_t*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h32 = lane >> 5, l32 = lane & 31;
@@ -103,25 +104,30 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnArgs p) {
             rv[i] = ok ? *reinterpret_cast<const u32x4*>(vb + (long)key * p.v_rs + ch * 8) : zero;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        bf16_t* Kd = lds0 + buf * IMG;
+        bf16_t* Vd = Kd + 64 * C::KS;
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
             const int c = tid + i * 256;
             if (c < 64 * C::CPR) {
                 const int row = c / C::CPR, ch = c % C::CPR;
-                *reinterpret_cast<u32x4*>(Ks + row * C::KS + ch * 8) = rk[i];
-                *reinterpret_cast<u32x4*>(Vs + row * C::VS + ch * 8) = rv[i];
+                *reinterpret_cast<u32x4*>(Kd + row * C::KS + ch * 8) = rk[i];
+                *reinterpret_cast<u32x4*>(Vd + row * C::VS + ch * 8) = rv[i];
             }
         }
     };
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile();
+        store_tile(0);
     }
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bf16_t* Ks = lds0 + cur * IMG;
+        const bf16_t* Vs = Ks + 64 * C::KS;
         if (t + 1 < t_end) load_tile(t + 1);
 
         // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
@@ -239,8 +245,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(AttnArgs p) {
                 }
         }
 
-        __syncthreads();
-        if (t + 1 < t_end) store_tile();
+        if (t + 1 < t_end) store_tile(cur ^ 1);   // buffer cur^1 was last read in iteration t-1, before its barrier
         __syncthreads();
     }
 
@@ -267,7 +272,7 @@ template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid((a.Lq + 127) / 128, a.Hq, a.B);
-    const size_t smem = (size_t)64 * (C::KS + C::VS) * sizeof(bf16_t);
+    const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
     attn_flash_kernel<DP><<<grid, 256, smem, (hipStream_t)stream>>>(a);
     SPIDER_LAUNCH_OK();
     return 0;

@@ -117,12 +117,37 @@ template <int NB, int R, bool GATEUP, bool XLDS>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                    bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, const bf16_t* __restrict__ norm_w,
-                                                   float eps, int N, int K) {
+                                                   float eps, int N, int K, int hoist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K] when XLDS
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NR = GATEUP ? 2 * R : R;  // weight rows per wave
+    constexpr int U = (NR * NB <= 4) ? 4 : 2;  // chunks in flight per row
+
+    // Row pointers first; with `hoist` the first weight chunks are requested BEFORE the activation prologue (the
+    // weight stream does not depend on x), so their HBM latency overlaps the RMSNorm / LDS staging below.
+    const int col0 = (blockIdx.x * 4 + wave) * R;
+    const bf16_t* wrow[NR];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = col0 + r;
+        n = n < N ? n : N - 1;
+        wrow[r] = W + (size_t)n * K;
+        if (GATEUP) wrow[R + r] = W + (size_t)(N + n) * K;
+    }
+    u32x4 w0[U][NR];
+    if (hoist) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = lane * 8 + u * 512;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    w0[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+            }
+        }
+    }
 
     if (XLDS) {
         const int nv = K / 8;
@@ -162,34 +187,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
         __syncthreads();
     }
 
-    const int col0 = (blockIdx.x * 4 + wave) * R;
     if (col0 >= N) return;
-    const bf16_t* wrow[NR];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int n = col0 + r;
-        n = n < N ? n : N - 1;
-        wrow[r] = W + (size_t)n * K;
-        if (GATEUP) wrow[R + r] = W + (size_t)(N + n) * K;
-    }
     float acc[NB][NR];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[b][r] = 0.f;
 
-    constexpr int U = (NR * NB <= 4) ? 4 : 2;  // chunks in flight per row
-    for (int k0 = lane * 8; k0 < K; k0 += 512 * U) {
-        u32x4 wq[U][NR];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + u * 512;
-            if (k < K) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    wq[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
-            }
-        }
+    auto fma_w = [&](const u32x4 (&wq)[U][NR], int k0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u * 512;
@@ -211,6 +216,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
                 }
             }
         }
+    };
+    int kstart = lane * 8;
+    if (hoist) {
+        fma_w(w0, kstart);
+        kstart += 512 * U;
+    }
+    for (int k0 = kstart; k0 < K; k0 += 512 * U) {
+        u32x4 wq[U][NR];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 512;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    wq[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+            }
+        }
+        fma_w(wq, k0);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
     gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
         (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
-        (const bf16_t*)norm_w, eps, N, K)
+        (const bf16_t*)norm_w, eps, N, K, hoist)
 
 static int gemv_env_r() {
     static const int v = [] { const char* e = getenv("SPIDER_GEMV_R"); return e ? atoi(e) : 0; }();
@@ -835,6 +858,7 @@ static int gemv_dispatch(const void* W, const void* x, void* out, const void* bi
     if (!xlds) SPIDER_CHECK(norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
     // rows per wave: 1 for the fused gate/up form (2 weight rows per output) and for small matrices (more blocks in
     // flight hide the per-block activation prologue), 2 otherwise
+    static const int hoist = [] { const char* e = getenv("SPIDER_GEMV_HOIST"); return e ? atoi(e) : 1; }();
     int R = GU ? 1 : 2;
     if (!GU && (size_t)N * K * 2 < (size_t)48 << 20) R = 1;
     if (gemv_env_r()) R = gemv_env_r();

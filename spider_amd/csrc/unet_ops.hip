@@ -31,14 +31,24 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     const bf16_t* xb = x + (size_t)b * HW * C;
-    for (int px = p0 + pl; px < p1; px += KP) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(xb + (size_t)px * C + v * 8);
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+    // 4 independent 16-byte loads in flight per thread (a runtime-trip loop with one load per iteration would
+    // serialise the L2/HBM round trips)
+    for (int px = p0 + pl; px < p1; px += 4 * KP) {
+        u32x4 a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
-            s[2 * j] += lo; q[2 * j] += lo * lo;
-            s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
+        for (int u = 0; u < 4; ++u) {
+            const int pp = px + u * KP;
+            a[u] = pp < p1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)pp * C + v * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t aw[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+                s[2 * j] += lo; q[2 * j] += lo * lo;
+                s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
+            }
         }
     }
     *reinterpret_cast<f32x4*>(sm_s + pl * C + v * 8) = f32x4{s[0], s[1], s[2], s[3]};
@@ -79,10 +89,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const int g = threadIdx.x % G, part = threadIdx.x / G;
         float gs = 0.f, gq = 0.f;
         if (part < parts) {
-            for (int c = part; c < nchunk; c += parts) {
-                const float* src = partial + (((size_t)b * nchunk + c) * G + g) * 2;
-                gs += src[0];
-                gq += src[1];
+            // nchunk <= 128 and parts >= 4: at most 32 partials per thread, loaded 8 at a time (independent loads)
+            for (int c0 = part; c0 < nchunk; c0 += 8 * parts) {
+                float2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * parts;
+                    t[u] = c < nchunk ? *reinterpret_cast<const float2*>(partial + (((size_t)b * nchunk + c) * G + g) * 2)
+                                      : float2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { gs += t[u].x; gq += t[u].y; }
             }
         }
         ps[threadIdx.x] = gs;
@@ -103,6 +120,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(HW, p0 + pix_per_block);
     const size_t base = (size_t)b * HW * C;
+#pragma unroll 2
     for (int idx = p0 * cv + threadIdx.x; idx < p1 * cv; idx += 256) {
         const int v = idx % cv;
         const u32x4 a = *reinterpret_cast<const u32x4*>(x + base + (size_t)idx * 8);
@@ -125,6 +143,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
         ov.z = pack_bf16x2(o[4], o[5]); ov.w = pack_bf16x2(o[6], o[7]);
         *reinterpret_cast<u32x4*>(y + base + (size_t)idx * 8) = ov;
+    }
+}
+
+// GroupNorm for small feature maps (HW <= 256): ONE launch, one block per (group, batch); the group's data
+// (HW x cpg values, 4-byte pairs, L2-resident) is read twice by the same block. Replaces the stats + apply pair
+// whose two launches dominate at 16x16 / 8x8 latents.
+__global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C,
+                                                       int G, float eps, int silu) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, hp = cpg / 2;          // channel pairs per group
+    const int n = HW * hp;
+    const bf16_t* xb = x + (size_t)b * HW * C + g * cpg;
+    bf16_t* yb = y + (size_t)b * HW * C + g * cpg;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i / hp, cp = i - px * hp;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + (size_t)px * C + 2 * cp);
+        const float lo = bf16lo_to_f32(v), hi = bf16hi_to_f32(v);
+        s += lo + hi;
+        q += lo * lo + hi * hi;
+    }
+    const float cnt = (float)HW * (float)cpg;
+    const float mu = block_sum<4>(s, red) / cnt;
+    const float var = fmaxf(block_sum<4>(q, red) / cnt - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i / hp, cp = i - px * hp;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + (size_t)px * C + 2 * cp);
+        const uint32_t gv = *reinterpret_cast<const uint32_t*>(gamma + g * cpg + 2 * cp);
+        const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + 2 * cp);
+        float lo = (bf16lo_to_f32(v) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
+        float hi = (bf16hi_to_f32(v) - mu) * rs * bf16hi_to_f32(gv) + bf16hi_to_f32(bv);
+        if (silu) {
+            lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
+            hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
+        }
+        *reinterpret_cast<uint32_t*>(yb + (size_t)px * C + 2 * cp) = pack_bf16x2(lo, hi);
     }
 }
 
@@ -182,6 +239,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             u32x4 ov;
             ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
             *reinterpret_cast<u32x4*>(y + row * C + i * 8) = ov;
+        }
+    }
+}
+
+// LayerNorm, one WAVE per row (C <= 2048): no LDS, no barriers; 4 rows per block. A 256-thread block per row leaves
+// most lanes idle at C = 320 (40 vectors).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
+                                                             const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C / 8;
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x + (size_t)row * C);
+    float h[VPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        const int i = lane + it * 64;
+        if (i < nv) {
+            const u32x4 a = xv[i];
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[it][2 * j] = bf16lo_to_f32(aw[j]);
+                h[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                s += h[it][2 * j] + h[it][2 * j + 1];
+            }
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        if (lane + it * 64 < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = h[it][j] - mu; q += dlt * dlt; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        const int i = lane + it * 64;
+        if (i < nv) {
+            const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + i * 8);
+            const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + i * 8);
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+            u32x4 ov;
+            ov.x = pack_bf16x2((h[it][0] - mu) * rs * bf16lo_to_f32(gw[0]) + bf16lo_to_f32(bw[0]), (h[it][1] - mu) * rs * bf16hi_to_f32(gw[0]) + bf16hi_to_f32(bw[0]));
+            ov.y = pack_bf16x2((h[it][2] - mu) * rs * bf16lo_to_f32(gw[1]) + bf16lo_to_f32(bw[1]), (h[it][3] - mu) * rs * bf16hi_to_f32(gw[1]) + bf16hi_to_f32(bw[1]));
+            ov.z = pack_bf16x2((h[it][4] - mu) * rs * bf16lo_to_f32(gw[2]) + bf16lo_to_f32(bw[2]), (h[it][5] - mu) * rs * bf16hi_to_f32(gw[2]) + bf16hi_to_f32(bw[2]));
+            ov.w = pack_bf16x2((h[it][6] - mu) * rs * bf16lo_to_f32(gw[3]) + bf16lo_to_f32(bw[3]), (h[it][7] - mu) * rs * bf16hi_to_f32(gw[3]) + bf16hi_to_f32(bw[3]));
+            *reinterpret_cast<u32x4*>(y + (size_t)row * C + i * 8) = ov;
         }
     }
 }
@@ -468,6 +579,13 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
                                int C, int G, float eps, int silu, void* stream) {
     SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
+    if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch
+        dim3 g0(G, B);
+        gn_small_kernel<<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                             (bf16_t*)y, HW, C, G, eps, silu);
+        SPIDER_LAUNCH_OK();
+        return 0;
+    }
     const int nchunk = spider_groupnorm_nchunk(HW);
     const int cv = C / 8;
     int KP = 256 / cv;
@@ -490,6 +608,15 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
 int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                           void* stream) {
     SPIDER_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 8192, "layernorm: C must be a multiple of 8 and <= 8192");
+    if (C <= 2048) {
+        const int vpl = (C / 8 + 63) / 64, grid = (rows + 3) / 4;
+#define LNW(V_) layernorm_wave_kernel<V_><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, \
+                                                                                (const bf16_t*)beta, (bf16_t*)y, rows, C, eps)
+        if (vpl == 1) LNW(1); else if (vpl == 2) LNW(2); else if (vpl == 3) LNW(3); else LNW(4);
+#undef LNW
+        SPIDER_LAUNCH_OK();
+        return 0;
+    }
     layernorm_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
                                                            (bf16_t*)y, C, eps);
     SPIDER_LAUNCH_OK();
@@ -544,7 +671,10 @@ int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias,
     const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(float);
     SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cin: weights exceed LDS");
     const size_t total = (size_t)B * H * W * (Cout / 8);
-    conv_small_cin_kernel<<<grid_for(total), 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
+    // every block re-stages the whole weight tensor into LDS: keep the grid at ~2 blocks per CU and grid-stride
+    int grid = grid_for(total);
+    if (grid > 512) grid = 512;
+    conv_small_cin_kernel<<<grid, 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
                                                                                (const bf16_t*)bias, (bf16_t*)y, B, H, W,
                                                                                Cin, Cout, ks);
     SPIDER_LAUNCH_OK();
@@ -562,7 +692,7 @@ int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias
     SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cout: weights exceed LDS");
     const size_t npix = (size_t)B * H * W;
     size_t grid = (npix + 3) / 4;
-    if (grid > 4096) grid = 4096;
+    if (grid > 2048) grid = 2048;   // each block stages all weights into LDS once, then grid-strides over pixels
     conv_small_cout_kernel<<<(int)grid, 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
                                                                          (const bf16_t*)bias, (float*)y32, (bf16_t*)y16, B,
                                                                          H, W, Cin, Cout, ks);
