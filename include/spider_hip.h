@@ -76,7 +76,8 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
 /* ======================= MFMA GEMM / conv / attention ======================= */
 
 /* C = act(A[M,K] . W[N,K]^T + bias[N] + rowbias[row/rows_per_group, N]) (+res) * out_scale.
- * Exactly one of C (bf16) / C32 (fp32). act: 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu.
+ * Exactly one of C (bf16) / C32 (fp32). act: 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu, 4 GEGLU (W = [value rows |
+ * gate rows], N counts W rows, the output has N/2 columns: out = (A.Wv^T + bv) * gelu(A.Wg^T + bg), diffusers FeedForward).
  * ws/ws_bytes: optional fp32 split-K workspace (NULL = never split K); small-M / large-K problems use it
  * to fill the 256 CUs.
  * Prefill projections (modeling_llama3.py:186-313), diffusers Attention/FeedForward/proj linears. */

@@ -35,6 +35,7 @@ struct GemmArgs {
     int M, N, K, lda, ldc;
     int rows_per_group;
     int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu
+    int geglu;              // 1: W = [value rows (N) | gate rows (N)], out[m,n] = bf16(v) * bf16(gelu(bf16(g)))  (diffusers GEGLU)
     float out_scale;        // multiplies the final value (1/rescale_output_factor)
     int splits, kt_per_split;
     // implicit-GEMM conv (NHWC): A is the image [B, Hin, Win, Cin]; K = ks*ks*Cin
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int ncols = p.geglu ? 2 * p.N : p.N;   // GEGLU: a BN-wide W tile yields BN/2 output columns
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (ncols + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = bid % tiles_m, tn = bid / tiles_m;  // m fastest: neighbours share the W tile
     const int m0 = tm * BM, n0 = tn * BN;
@@ -136,8 +138,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        w_ok[i] = n < p.N;
+        int n = n0 + lrow + 32 * i;
+        if (p.geglu) {
+            // each wave column holds BN/4 value rows followed by the BN/4 gate rows of the same output columns, so a
+            // lane finds value and gate of one output element in its own accumulators (tiles j and j + NT/2)
+            const int rr = lrow + 32 * i, wn_ = rr / (BN / 2), within = rr % (BN / 2);
+            const int oc = (n0 / 2) + wn_ * (BN / 4) + within % (BN / 4);
+            w_ok[i] = oc < p.N;
+            n = (within >= BN / 4 ? p.N : 0) + oc;
+        } else {
+            w_ok[i] = n < p.N;
+        }
         w_ptr[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K;
     }
 
@@ -227,6 +238,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         if (kt + 4 < kt1) load_tile(kt + 4, a0, w0);
     }
 
+    // ---- GEGLU epilogue: value tile j and gate tile j + NT/2 of the same lane ----
+    if (p.geglu) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NT / 2; ++j) {
+                const int n = (n0 / 2) + wn * (BN / 4) + j * 16 + (lane >> 4) * 4;
+                if (m < p.M && n < p.N) {
+                    float r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ne = n + e < p.N ? n + e : p.N - 1;
+                        float v = acc[i][j][e], g = acc[i][j + NT / 2][e];
+                        if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
+                        v = bf16_to_f32(f32_to_bf16(v));
+                        g = bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16_to_f32(f32_to_bf16(g)))));
+                        r[e] = v * g;
+                    }
+                    if (n + 3 < p.N) {
+                        u32x2 o;
+                        o.x = pack_bf16x2(r[0], r[1]);
+                        o.y = pack_bf16x2(r[2], r[3]);
+                        *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(r[e]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -286,8 +330,9 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     static const int force_tile = env_int("SPIDER_GEMM_TILE"), force_splits = env_int("SPIDER_GEMM_SPLITS");  // tuning aid
     const int nk = (a.K + BK - 1) / BK;
-    const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const int t64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    const int ncols = a.geglu ? 2 * a.N : a.N;
+    const int t128 = ((a.M + 127) / 128) * ((ncols + 127) / 128);
+    const int t64 = ((a.M + 63) / 64) * ((ncols + 63) / 64);
     // Measured on MI355X (scripts/bench_gemm.py): K-heavy problems (3x3 convs, down_proj) want 128^2 tiles plus
     // split-K up to ~768 blocks; everything else with < 384 big tiles is faster on 64^2 tiles (more blocks, all
     // resident), split only when even those leave CUs idle.
@@ -309,10 +354,10 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         }
     }
     if (force_tile) small = force_tile == 64;
-    if (!a.ws || splits < 1) splits = 1;
+    if (!a.ws || splits < 1 || a.geglu) splits = 1;
     while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
     const int tiles = small ? t64 : t128;
-    if (force_splits && a.ws) {
+    if (force_splits && a.ws && !a.geglu) {
         splits = force_splits < nk ? force_splits : nk;
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
     }
@@ -342,14 +387,18 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
                      float out_scale, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
-    SPIDER_CHECK(ldc % 4 == 0 && ldc >= N, "gemm: ldc must be >= N and a multiple of 4");
+    SPIDER_CHECK(ldc % 4 == 0 && ldc >= (act == 4 ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
     SPIDER_CHECK((C != nullptr) != (C32 != nullptr), "gemm: exactly one of C (bf16) / C32 (fp32) must be given");
     SPIDER_CHECK(!rowbias || rows_per_group > 0, "gemm: rowbias needs rows_per_group > 0");
-    SPIDER_CHECK(act >= 0 && act <= 3, "gemm: unknown activation");
+    SPIDER_CHECK(act >= 0 && act <= 4, "gemm: unknown activation");
+    SPIDER_CHECK(act != 4 || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU epilogue needs bf16 output, even N, no res/rowbias");
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.C32 = (float*)C32;
     a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
-    a.rows_per_group = rows_per_group; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.act = act;
+    a.rows_per_group = rows_per_group; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc;
+    a.geglu = act == 4;
+    a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU output has N/2 columns
+    a.act = a.geglu ? 0 : act;
     a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;
     return launch(a, ws ? ws_bytes : 0, stream);
 }

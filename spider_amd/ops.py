@@ -15,7 +15,7 @@ import torch
 from . import lib as _lib
 
 BF16 = torch.bfloat16
-ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3}
+ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4}
 
 
 def _stream() -> int:
@@ -161,11 +161,12 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     N, K = W.shape
     assert A.shape[-1] == K, f"gemm: A[..., {A.shape[-1]}] vs W[{N},{K}]"
     M = A.numel() // K
+    n_out = N // 2 if act == "geglu" else N    # GEGLU epilogue: W = [value rows | gate rows], output has N/2 columns
     if out is None:
-        out = torch.empty(*A.shape[:-1], N, dtype=torch.float32 if out_f32 else BF16, device=A.device)
+        out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
     _lib.call("spider_gemm_bf16", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
-              M, N, K, K, N, ACT[act], float(out_scale), _p(_workspace(A.device)), WS_BYTES, _stream())
+              M, N, K, K, n_out, ACT[act], float(out_scale), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
 

@@ -222,8 +222,7 @@ class UNetEngine:
             o = ops.attention(q, kv[..., :C], kv[..., C:], heads)
             h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
-            p = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"])
-            g = ops.geglu(p)
+            g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
             h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
         out = ops.gemm(h, w[n + ".proj_out.weight"].view(C, C), bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
         return out.view(B, H, W_, C)

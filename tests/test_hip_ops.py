@@ -340,3 +340,14 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
         assert torch.equal(k1, k2) and torch.equal(v1, v2), "KV append must be bit-identical"
         close(out, ref.float(), 4e-3, 1e-2, f"fused decode attention rep {rep}")
         assert int(cnt.abs().sum()) == 0, "ticket counters must be back to zero after every launch"
+
+
+@pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280)])
+def test_gemm_fused_geglu(ops, dev, M, inner, K):
+    A, W, b = rnd(M, K, seed=1), rnd(2 * inner, K, seed=2, scale=0.05), rnd(2 * inner, seed=3, scale=0.2)
+    p = A.float() @ W.float().T + b.float()
+    ref = p[:, :inner] * F.gelu(p[:, inner:])
+    got = ops.gemm(A.to(dev), W.to(dev), bias=b.to(dev), act="geglu")
+    assert got.shape == (M, inner)
+    close(got, ref, 1.5e-2, 2e-2, "fused geglu", rel_to_std=True)
+    close(got, ops.geglu(ops.gemm(A.to(dev), W.to(dev), bias=b.to(dev))).float(), 1e-6, 1e-2, "fused == unfused geglu")
