@@ -25,15 +25,16 @@ __device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) {
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) {
     return __uint_as_float(packed & 0xffff0000u);
 }
-// round-to-nearest-even f32 -> bf16 (NaN kept quiet)
+// round-to-nearest-even f32 -> bf16 through the hardware converter (v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN).
+// A software rounding sequence costs ~7 VALU ops per element -- it dominated the flash-attention softmax.
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const hw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
