@@ -208,10 +208,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
                     for (int r = 0; r < NR; ++r) {
                         const uint32_t ww[4] = {wq[u][r].x, wq[u][r].y, wq[u][r].z, wq[u][r].w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            acc[b][r] += bf16lo_to_f32(ww[j]) * bf16lo_to_f32(xw[j]);
-                            acc[b][r] += bf16hi_to_f32(ww[j]) * bf16hi_to_f32(xw[j]);
-                        }
+                        for (int j = 0; j < 4; ++j) acc[b][r] = dot2_bf16(ww[j], xw[j], acc[b][r]);
                     }
                 }
             }
@@ -347,10 +344,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(const bf16_t* __res
                 for (int r = 0; r < R; ++r) {
                     const uint32_t ww[4] = {wq[r].x, wq[r].y, wq[r].z, wq[r].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[b][r] += bf16lo_to_f32(ww[j]) * bf16lo_to_f32(xw[j]);
-                        acc[b][r] += bf16hi_to_f32(ww[j]) * bf16hi_to_f32(xw[j]);
-                    }
+                    for (int j = 0; j < 4; ++j) acc[b][r] = dot2_bf16(ww[j], xw[j], acc[b][r]);
                 }
             }
         }
