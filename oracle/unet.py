@@ -150,9 +150,13 @@ def random_unet_weights(cfg: UNetCfg, seed=0, bf16_round=True) -> dict:
 
 
 class UNetOracle:
-    def __init__(self, cfg: UNetCfg, weights: dict):
+    def __init__(self, cfg: UNetCfg, weights: dict, dtype=torch.float32):
+        """dtype=torch.float32: the fp32 restatement (the parity target). dtype=torch.bfloat16 runs the SAME graph
+        with torch's CPU bf16 kernels, i.e. what the reference's module would compute in bf16 (every op output
+        rounded to bf16): used to separate 'bf16 storage' error from implementation error."""
         self.cfg = cfg
-        self.w = {k: v.float() for k, v in weights.items()}
+        self.dtype = dtype
+        self.w = {k: v.to(dtype) for k, v in weights.items()}
         self.attn_hook = None   # optional: fn(name, self_attn_ctx) -> tensor, used by the StoryDiffusion oracle
         self.freeu = None       # optional (s1, s2, b1, b2)
 
@@ -216,11 +220,11 @@ class UNetOracle:
 
     def time_embed(self, t: torch.Tensor, B: int, added: Optional[dict] = None):
         cfg = self.cfg
-        te = timestep_embedding(t.expand(B) if t.ndim == 0 else t, cfg.block_out[0])
+        te = timestep_embedding(t.expand(B) if t.ndim == 0 else t, cfg.block_out[0]).to(self.dtype)
         emb = self._lin("time_embedding.linear_2", F.silu(self._lin("time_embedding.linear_1", te)))
         if cfg.addition_in:
             tid = timestep_embedding(added["time_ids"].flatten(), cfg.addition_time_dim).reshape(B, -1)
-            add = torch.cat([added["text_embeds"], tid], -1)
+            add = torch.cat([added["text_embeds"].float(), tid], -1).to(self.dtype)
             emb = emb + self._lin("add_embedding.linear_2", F.silu(self._lin("add_embedding.linear_1", add)))
         return emb
 
@@ -229,6 +233,7 @@ class UNetOracle:
         """sample [B,4,h,w] fp32, t scalar tensor, enc [B,77,cross] -> [B,4,h,w]."""
         cfg = self.cfg
         B = sample.shape[0]
+        sample, enc = sample.to(self.dtype), enc.to(self.dtype)
         temb = self.time_embed(torch.as_tensor(t), B, added)
         h = self._conv("conv_in", sample)
         skips = [h]
@@ -260,7 +265,7 @@ class UNetOracle:
                 h = F.interpolate(h, scale_factor=2.0, mode="nearest")
                 h = self._conv(f"up_blocks.{i}.upsamplers.0.conv", h)
         h = F.silu(self._gn("conv_norm_out", h))
-        return self._conv("conv_out", h)
+        return self._conv("conv_out", h).float()
 
 
 def fourier_filter(x, threshold, scale):
