@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--throughput-batch", type=int, default=8,
+                   help="also report (outside the timed region, as an extra field) the rate with this many prompts per GPU; 0 = skip")
     p.add_argument("--llm", default="qwen25_7b", choices=["qwen25_7b", "llama3_8b"])
     return p.parse_args()
 
@@ -54,7 +56,8 @@ class Responder:
         from spider_amd.unet import UNetConfig, UNetEngine
         self.args, self.dev = args, device
         cfg = getattr(LLMConfig, args.llm)()
-        self.llm = LlamaEngine.random_init(cfg, device, max_batch=args.batch, max_len=args.prompt_len + args.new_tokens + 8, seed=0)
+        self.max_batch = max(args.batch, min(args.throughput_batch, 8))
+        self.llm = LlamaEngine.random_init(cfg, device, max_batch=self.max_batch, max_len=args.prompt_len + args.new_tokens + 8, seed=0)
         self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1)
         self.sched = PNDMScheduler()
         self.text_enc = self.vae = None
@@ -66,10 +69,12 @@ class Responder:
         except ImportError:
             pass
         g = torch.Generator(device=device).manual_seed(2047)  # seed echoes Comic_Generation.py:387
-        self.prompt = torch.randint(3, cfg.vocab, (args.batch, args.prompt_len), generator=g, device=device)
-        self.latents0 = torch.randn(args.batch, 4, 64, 64, generator=g, device=device)
-        self.clip_ids = torch.randint(1000, 40000, (2 * args.batch, 77), generator=g, device=device, dtype=torch.int32)
-        self.enc_synth = torch.randn(2 * args.batch, 77, 768, generator=g, device=device).to(torch.bfloat16)
+        mb = self.max_batch
+        self.prompt = torch.randint(3, cfg.vocab, (mb, args.prompt_len), generator=g, device=device)
+        self.latents0 = torch.randn(mb, 4, 64, 64, generator=g, device=device)
+        self.clip_ids_u = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
+        self.clip_ids_c = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
+        self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(torch.bfloat16)
 
     def includes(self):
         inc = ["llm_prefill", "llm_decode", "routing", "unet_denoise_loop"]
@@ -79,25 +84,25 @@ class Responder:
             inc.append("vae_decode")
         return inc
 
-    def respond(self):
+    def respond(self, batch=None):
         from spider_amd import routing
         from spider_amd.unet import denoise
         a = self.args
-        toks = self.llm.generate(input_ids=self.prompt, max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
+        B = batch or a.batch
+        toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
         gen = toks[:, a.prompt_len:]
         gen_host = gen.cpu()                       # the one device->host sync of the LLM phase
         images = []
-        for b in range(a.batch):
+        for b in range(B):
             # synthetic text forced to carry exactly one <IMAGE> tag (random-init weights emit no real tags)
             text = "Here you go: <IMAGE>tokens " + " ".join(str(int(t)) for t in gen_host[b, :8]) + "</IMAGE>"
             answers, ptext, calls = routing.route_text(text)
             assert len(calls) == 1 and calls[0][0] == "IMAGE"
-        if self.text_enc is not None:
-            enc = self.text_enc.encode(self.clip_ids)          # [2B, 77, 768]: uncond rows first
+        if self.text_enc is not None:   # CFG layout of _encode_prompt (custom_sd.py:372): [uncond(B) | cond(B)]
+            enc = self.text_enc.encode(torch.cat([self.clip_ids_u[:B], self.clip_ids_c[:B]]))
         else:
-            enc = self.enc_synth
-        # CFG layout of _encode_prompt (custom_sd.py:372): [uncond(B) | cond(B)]
-        lat = denoise(self.unet, self.sched, self.latents0, enc, 7.5, a.denoise_steps)
+            enc = torch.cat([self.enc_synth[:B], self.enc_synth[self.max_batch:self.max_batch + B]]).contiguous()
+        lat = denoise(self.unet, self.sched, self.latents0[:B].contiguous(), enc, 7.5, a.denoise_steps)
         if self.vae is not None:
             img = self.vae.decode(lat)                          # [B, 3, 512, 512] fp32 in [0,1]
             out = (img * 255.0).round().to(torch.uint8)
@@ -262,15 +267,26 @@ def main():
         extra["unet_flops_per_sample"] = {k: round(v / 1e9, 2) for k, v in fl.items()}
         # LLM phases
         t1 = time.perf_counter()
-        resp.llm.generate(input_ids=resp.prompt, max_new_tokens=2, use_graph=False)
+        resp.llm.generate(input_ids=resp.prompt[:a.batch].contiguous(), max_new_tokens=2, use_graph=False)
         torch.cuda.synchronize(device)
         t_prefill = time.perf_counter() - t1
         t1 = time.perf_counter()
-        resp.llm.generate(input_ids=resp.prompt, max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
+        resp.llm.generate(input_ids=resp.prompt[:a.batch].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
         torch.cuda.synchronize(device)
         t_gen = time.perf_counter() - t1
         extra["llm_prefill_ms"] = round(t_prefill * 1e3, 1)
         extra["llm_decode_tokens_per_s"] = round(a.batch * (a.new_tokens - 2) / max(t_gen - t_prefill, 1e-6), 1)
+        if a.throughput_batch and a.throughput_batch != a.batch:
+            tb = min(a.throughput_batch, 8)
+            resp.respond(tb)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            resp.respond(tb)
+            torch.cuda.synchronize(device)
+            dtb = time.perf_counter() - t1
+            extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
+                                           "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
+                                                   "not the headline value"}
         roof = measure_roofline(resp, device)
         c = resp.llm.cfg
         wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)

@@ -835,6 +835,98 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     if (threadIdx.x == 0) __hip_atomic_store(cnt + (size_t)b * n_kv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Skinny MFMA GEMM for batched decode (2..16 sequences): out[m, n] = epilogue(sum_k x[m,k] W[n,k]).
+// The FMA GEMV above spends NB x the VALU work per weight byte and turns VALU-bound beyond ~4 sequences; here the
+// weight rows are the MFMA "A" operand (16 output columns per block) and the <= 16 activation rows the "B" operand,
+// so the weight stream is read once at the HBM rate for any batch <= 16. Each of the 4 waves takes a quarter of K
+// (deep unrolled 32-byte loads straight to registers: weights are used once, no LDS staging), partial tiles are
+// summed through LDS. k is permuted identically for both operands (lane group g owns k = 16g..16g+15 of every
+// 64-wide block) so every lane issues two adjacent 16-byte loads = full 128-byte lines per weight row.
+// ----------------------------------------------------------------------------------------------
+template <bool GATEUP>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+                                                          bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
+                                                          const bf16_t* __restrict__ res, int B, int N, int K) {
+    constexpr int TN = GATEUP ? 2 : 1;
+    __shared__ float part[4][TN][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = min(n0 + r16, N - 1);
+    const bf16_t* wrow[TN];
+    wrow[0] = W + (size_t)nrow * K + 16 * g;
+    if (GATEUP) wrow[1] = W + (size_t)(N + nrow) * K + 16 * g;
+    const bool x_ok = r16 < B;
+    const bf16_t* xrow = x + (size_t)(x_ok ? r16 : 0) * K + 16 * g;
+
+    const int nkb = K / 64;
+    const int kb0 = (wave * nkb) / 4, kb1 = ((wave + 1) * nkb) / 4;
+    f32x4 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    constexpr int UB = 4;   // 64-wide k blocks in flight
+    for (int kb = kb0; kb < kb1; kb += UB) {
+        u32x4 wq[UB][TN][2], xq[UB][2];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (kb + u < kb1) {
+                const size_t ko = (size_t)(kb + u) * 64;
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    wq[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[t] + ko));
+                    wq[u][t][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[t] + ko + 8));
+                }
+                xq[u][0] = x_ok ? *reinterpret_cast<const u32x4*>(xrow + ko) : zero;
+                xq[u][1] = x_ok ? *reinterpret_cast<const u32x4*>(xrow + ko + 8) : zero;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (kb + u < kb1) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, xq[u][sx]);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[u][t][sx]), xf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[wave][t][lane][j] = acc[t][j];
+    __syncthreads();
+    if (wave != 0) return;
+    // lane holds D[n = n0 + 4g + j][m = r16]
+    float v[TN][4];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[t][j] = part[0][t][lane][j] + part[1][t][lane][j] + part[2][t][lane][j] + part[3][t][lane][j];
+    if (!x_ok) return;
+    const int m = r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 4 * g + j;
+        if (n < N) {
+            float o;
+            if (GATEUP) {
+                const float gg = bf16_to_f32(f32_to_bf16(v[0][j])), uu = bf16_to_f32(f32_to_bf16(v[1][j]));
+                o = bf16_to_f32(f32_to_bf16(silu_f(gg))) * uu;
+            } else {
+                o = v[0][j];
+                if (bias) o += bf16_to_f32(bias[n]);
+                if (res) o = bf16_to_f32(f32_to_bf16(o)) + bf16_to_f32(res[(size_t)m * N + n]);
+            }
+            out[(size_t)m * N + n] = f32_to_bf16(o);
+        }
+    }
+}
+
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
     gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
         (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
@@ -875,6 +967,14 @@ static int gemv_dispatch(const void* W, const void* x, void* out, const void* bi
 template <bool GU>
 static int gemv_batch(const void* W, const void* x, void* out, const void* bias, const void* res, const void* norm_w,
                       float eps, int B, int N, int K, void* stream) {
+    // 2..16 sequences: skinny MFMA GEMM (weights streamed once whatever the batch); needs K % 64 == 0 and no fused norm
+    static const int mfma_min_b = [] { const char* e = getenv("SPIDER_GEMV_MFMA_MIN_B"); return e ? atoi(e) : 2; }();
+    if (B >= mfma_min_b && B <= 16 && K % 64 == 0 && norm_w == nullptr) {
+        skinny_gemm_kernel<GU><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out,
+                                                                               (const bf16_t*)bias, (const bf16_t*)res, B, N, K);
+        SPIDER_LAUNCH_OK();
+        return 0;
+    }
     switch (B) {
         case 1: return gemv_dispatch<1, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
         case 2: return gemv_dispatch<2, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
@@ -884,7 +984,7 @@ static int gemv_batch(const void* W, const void* x, void* out, const void* bias,
         case 6: return gemv_dispatch<6, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
         case 7: return gemv_dispatch<7, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
         case 8: return gemv_dispatch<8, GU>(W, x, out, bias, res, norm_w, eps, N, K, stream);
-        default: spider_set_error("gemv: batch must be 1..8 (use spider_gemm_bf16 beyond that)"); return -1;
+        default: spider_set_error("gemv: batch must be 1..8 (1..16 when K % 64 == 0 and norm_w == NULL; use spider_gemm_bf16 beyond that)"); return -1;
     }
 }
 

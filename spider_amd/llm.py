@@ -224,8 +224,12 @@ class LlamaEngine:
         hs = st.get("hidden_buf")
         if hs is not None:
             hs[0].copy_(h)
+        fuse_norm = B == 1     # batched decode uses the skinny MFMA GEMM, which takes pre-normalised activations
         for l, lw in enumerate(self.layers):
-            ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
+            if fuse_norm:
+                ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
+            else:
+                ops.gemv(lw["w_qkv"], ops.rmsnorm(h, lw["ln1"], c.eps, out=st["xn"]), bias=lw["b_qkv"], out=st["qkv"])
             if c.head_dim == 128:   # RoPE + KV append + split-KV attention + combine: one launch
                 ops.attn_decode_fused(st["qkv"], st["pos"], self.cos_sin, self.k_cache[l], self.v_cache[l], st["kv_end"],
                                       st["kv_beg"], st["attn_cnt"], c.n_q, st["nsplit"], st["attn_ws"], st["attn"])
@@ -235,7 +239,10 @@ class LlamaEngine:
                 ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
                                 nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
             h1 = ops.gemv(lw["w_o"], st["attn"], res=h, out=st["h1"])
-            ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
+            if fuse_norm:
+                ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
+            else:
+                ops.gemv_swiglu(lw["w_gu"], ops.rmsnorm(h1, lw["ln2"], c.eps, out=st["xn"]), out=st["act"])
             h = ops.gemv(lw["w_down"], st["act"], res=h1, out=st["h2"][l & 1])
             if hs is not None:
                 hs[l + 1].copy_(h)
@@ -258,7 +265,7 @@ class LlamaEngine:
         npart = ops.lm_head_nparts(c.vocab)
         st = dict(B=B, nsplit=nsplit, cur_ids=i32(B), next_ids=i32(B), pos=i32(B), slot=i32(B), kv_end=i32(B), kv_beg=i32(B),
                   qkv=bf(B, (c.n_q + 2 * c.n_kv) * c.head_dim), q=bf(B, c.n_q, c.head_dim), attn=bf(B, nq_d),
-                  h1=bf(B, c.hidden), h2=[bf(B, c.hidden), bf(B, c.hidden)], act=bf(B, c.inter),
+                  h1=bf(B, c.hidden), h2=[bf(B, c.hidden), bf(B, c.hidden)], act=bf(B, c.inter), xn=bf(B, c.hidden),
                   attn_ws=(torch.empty(B * c.n_q * nsplit * c.head_dim, dtype=torch.float32, device=dv),
                            torch.empty(B * c.n_q * nsplit * 2, dtype=torch.float32, device=dv)),
                   lm_ws=(torch.empty(B * npart, dtype=torch.float32, device=dv), i32(B * npart)),
@@ -295,7 +302,7 @@ class LlamaEngine:
             raise ValueError(f"batch {B} / length {S}+{max_new_tokens} exceed the preallocated KV cache "
                              f"({self.max_batch} x {self.max_len})")
         if B > 8:
-            raise ValueError("decode GEMV path supports up to 8 sequences per engine call")
+            raise ValueError("decode path supports up to 8 sequences per engine call (lm_head / attention workspaces)")
         am = (attention_mask.to(dv).to(torch.int32) if attention_mask is not None
               else torch.ones(B, S, dtype=torch.int32, device=dv))
         pos2d = (am.cumsum(-1) - 1).clamp(min=0).to(torch.int32).contiguous()

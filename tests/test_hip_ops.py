@@ -351,3 +351,18 @@ def test_gemm_fused_geglu(ops, dev, M, inner, K):
     assert got.shape == (M, inner)
     close(got, ref, 1.5e-2, 2e-2, "fused geglu", rel_to_std=True)
     close(got, ops.geglu(ops.gemm(A.to(dev), W.to(dev), bias=b.to(dev))).float(), 1e-6, 1e-2, "fused == unfused geglu")
+
+
+@pytest.mark.parametrize("B,N,K", [(2, 4608, 3584), (8, 3584, 18944), (16, 130, 1024), (5, 7, 64), (8, 18944, 3584)])
+def test_skinny_mfma_gemm(ops, dev, B, N, K):
+    """Batched-decode GEMV on MFMA (2..16 rows): plain + bias + residual, and the fused gate/up SwiGLU form."""
+    W, x = rnd(N, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    bias, res = rnd(N, seed=3), rnd(B, N, seed=4)
+    ref = x.float() @ W.float().T
+    close(ops.gemv(W.to(dev), x.to(dev)), ref, 1e-2, 1e-2, "skinny gemm", rel_to_std=True)
+    close(ops.gemv(W.to(dev), x.to(dev), bias=bias.to(dev), res=res.to(dev)), ref + bias.float() + res.float(), 1.5e-2, 1e-2,
+          "skinny gemm + bias + res", rel_to_std=True)
+    if N % 2 == 0:
+        I = N // 2
+        gg, uu = ref[:, :I], ref[:, I:]
+        close(ops.gemv_swiglu(W.to(dev), x.to(dev)), F.silu(gg) * uu, 1.5e-2, 2e-2, "skinny swiglu", rel_to_std=True)
