@@ -839,17 +839,17 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 // Skinny MFMA GEMM for batched decode (2..16 sequences): out[m, n] = epilogue(sum_k x[m,k] W[n,k]).
 // The FMA GEMV above spends NB x the VALU work per weight byte and turns VALU-bound beyond ~4 sequences; here the
 // weight rows are the MFMA "A" operand (16 output columns per block) and the <= 16 activation rows the "B" operand,
-// so the weight stream is read once at the HBM rate for any batch <= 16. Each of the 4 waves takes a quarter of K
+// so the weight stream is read once at the HBM rate for any batch <= 16. Each of the NW waves takes 1/NW of K
 // (deep unrolled 32-byte loads straight to registers: weights are used once, no LDS staging), partial tiles are
 // summed through LDS. k is permuted identically for both operands (lane group g owns k = 16g..16g+15 of every
 // 64-wide block) so every lane issues two adjacent 16-byte loads = full 128-byte lines per weight row.
 // ----------------------------------------------------------------------------------------------
-template <bool GATEUP>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+template <bool GATEUP, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                           bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
                                                           const bf16_t* __restrict__ res, int B, int N, int K) {
     constexpr int TN = GATEUP ? 2 : 1;
-    __shared__ float part[4][TN][64][4];
+    __shared__ float part[NW][TN][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
     const bf16_t* xrow = x + (size_t)(x_ok ? r16 : 0) * K + 16 * g;
 
     const int nkb = K / 64;
-    const int kb0 = (wave * nkb) / 4, kb1 = ((wave + 1) * nkb) / 4;
+    const int kb0 = (wave * nkb) / NW, kb1 = ((wave + 1) * nkb) / NW;
     f32x4 acc[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -906,7 +906,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[t][j] = part[0][t][lane][j] + part[1][t][lane][j] + part[2][t][lane][j] + part[3][t][lane][j];
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += part[w][t][lane][j];
+            v[t][j] = a;
+        }
     if (!x_ok) return;
     const int m = r16;
 #pragma unroll
@@ -967,11 +972,14 @@ static int gemv_dispatch(const void* W, const void* x, void* out, const void* bi
 template <bool GU>
 static int gemv_batch(const void* W, const void* x, void* out, const void* bias, const void* res, const void* norm_w,
                       float eps, int B, int N, int K, void* stream) {
-    // 2..16 sequences: skinny MFMA GEMM (weights streamed once whatever the batch); needs K % 64 == 0 and no fused norm
-    static const int mfma_min_b = [] { const char* e = getenv("SPIDER_GEMV_MFMA_MIN_B"); return e ? atoi(e) : 2; }();
+    // 5..16 sequences: skinny MFMA GEMM (weights streamed once whatever the batch); needs K % 64 == 0 and no fused norm.
+    // Measured crossover on MI355X (scripts/prof_decode_batch.py): the dot2 FMA kernel with its fused RMSNorm wins up to
+    // 4 sequences (3.5 / 3.9 / 4.1 ms per step at B = 2 / 3 / 4 vs 4.5 / 4.5 / 4.7), MFMA wins at 8 (5.5 vs 9.5 ms).
+    static const int mfma_min_b = [] { const char* e = getenv("SPIDER_GEMV_MFMA_MIN_B"); return e ? atoi(e) : 5; }();
     if (B >= mfma_min_b && B <= 16 && K % 64 == 0 && norm_w == nullptr) {
-        skinny_gemm_kernel<GU><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>((const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out,
-                                                                               (const bf16_t*)bias, (const bf16_t*)res, B, N, K);
+        // 8 waves per block (each 1/8 of K): N/16 blocks alone would leave most CUs with a single wave of loads in flight
+        skinny_gemm_kernel<GU, 8><<<(N + 15) / 16, 512, 0, (hipStream_t)stream>>>((const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out,
+                                                                                  (const bf16_t*)bias, (const bf16_t*)res, B, N, K);
         SPIDER_LAUNCH_OK();
         return 0;
     }

@@ -224,7 +224,7 @@ class LlamaEngine:
         hs = st.get("hidden_buf")
         if hs is not None:
             hs[0].copy_(h)
-        fuse_norm = B == 1     # batched decode uses the skinny MFMA GEMM, which takes pre-normalised activations
+        fuse_norm = B < 5      # >= 5 sequences use the skinny MFMA GEMM, which takes pre-normalised activations
         for l, lw in enumerate(self.layers):
             if fuse_norm:
                 ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
