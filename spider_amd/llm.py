@@ -314,7 +314,12 @@ class LlamaEngine:
         step0: Optional[list] = [] if output_hidden_states else None
         h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
 
-        st = self._make_state(B, output_hidden_states, return_logits)
+        # decode state (static buffers + captured hipGraph) is cached per (batch, outputs): repeated generate() calls
+        # replay the same graph instead of re-capturing ~200 launches
+        skey = (B, bool(output_hidden_states), bool(return_logits))
+        if skey not in self._graphs:
+            self._graphs[skey] = [self._make_state(B, output_hidden_states, return_logits), None]
+        st = self._graphs[skey][0]
         st["kv_beg"].copy_(kv_beg)
         last = h.view(B, S, -1)[:, -1].contiguous()
         ops.lm_head_argmax(self.lm_head, last, norm_w=self.norm, eps=c.eps, out_ids=st["next_ids"], ws=st["lm_ws"],
@@ -344,10 +349,10 @@ class LlamaEngine:
                 return any(sc(seq, None) for sc in stopping_criteria)
             return False
 
-        graph = None
+        graph = self._graphs[skey][1] if use_graph else None
         n = 1
         stopped = should_stop(1)
-        if use_graph and not stopped and max_new_tokens > 2:
+        if use_graph and graph is None and not stopped and max_new_tokens > 2:
             # warm the kernels outside capture, then capture one decode step; cursors live on device
             snap = {k: st[k].clone() for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end")}
             s = torch.cuda.Stream(device=dv)
@@ -362,6 +367,7 @@ class LlamaEngine:
                 self._decode_step(st)
             for k, v in snap.items():   # capture does not execute; restore is a no-op safety net
                 st[k].copy_(v)
+            self._graphs[skey][1] = graph
         while n < max_new_tokens and not stopped:
             if graph is not None:
                 graph.replay()
