@@ -33,6 +33,7 @@ struct GemmArgs {
     float* C32;             // optional fp32 output instead of bf16
     float* ws;              // split-K workspace [splits, M, N] fp32
     int M, N, K, lda, ldc;
+    uint32_t a_bytes, w_bytes;   // buffer-descriptor ranges of A and W (< 4 GiB each)
     int rows_per_group;
     int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu
     int geglu;              // 1: W = [value rows (N) | gate rows (N)], out[m,n] = bf16(v) * bf16(gelu(bf16(g)))  (diffusers GEGLU)
@@ -115,73 +116,88 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
     const int chunk = tid & 7;       // 16-byte chunk within the 64-wide K tile
     const int lrow = tid >> 3;       // 0..31, rows lrow + 32*i
-    const bf16_t* a_ptr[AC];
-    bool a_ok[AC];
+    // Operands are read through buffer descriptors: an out-of-range offset returns 0 in hardware, so M/N/K tails and
+    // the conv halo need no branches. (With predicated loads the compiler lost track of the outstanding-load count and
+    // drained the whole prefetch ring with s_waitcnt vmcnt(0) before every LDS store.)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+    // Validity is carried as all-ones / zero masks OR-ed into the offset (pure ALU): a select would be turned into a
+    // divergent branch by the compiler, which again hides the loads from its vmcnt bookkeeping.
+    uint32_t a_base[AC], a_inv[AC];   // byte offset of the row (linear) / image (conv); a_inv = ~0 for rows >= M
     int a_oy[AC], a_ox[AC];
-    const bf16_t* w_ptr[WC];
-    bool w_ok[WC];
+    uint32_t w_base[WC], w_inv[WC];
 #pragma unroll
     for (int i = 0; i < AC; ++i) {
         const int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mc = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mc = ok ? m : 0;
+        a_inv[i] = ok ? 0u : 0xFFFFFFFFu;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int b = mc / hw, rem = mc % hw;
             a_oy[i] = rem / p.Wout;
             a_ox[i] = rem % p.Wout;
-            a_ptr[i] = p.A + (size_t)b * p.Hin * p.Win * p.Cin;
+            a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
         } else {
-            a_ptr[i] = p.A + (size_t)mc * p.lda;
+            a_base[i] = (uint32_t)mc * (uint32_t)p.lda * 2u + chunk * 16u;
             a_oy[i] = a_ox[i] = 0;
         }
     }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
         int n = n0 + lrow + 32 * i;
+        bool ok;
         if (p.geglu) {
             // each wave column holds BN/4 value rows followed by the BN/4 gate rows of the same output columns, so a
             // lane finds value and gate of one output element in its own accumulators (tiles j and j + NT/2)
             const int rr = lrow + 32 * i, wn_ = rr / (BN / 2), within = rr % (BN / 2);
             const int oc = (n0 / 2) + wn_ * (BN / 4) + within % (BN / 4);
-            w_ok[i] = oc < p.N;
+            ok = oc < p.N;
             n = (within >= BN / 4 ? p.N : 0) + oc;
         } else {
-            w_ok[i] = n < p.N;
+            ok = n < p.N;
         }
-        w_ptr[i] = p.W + (size_t)(w_ok[i] ? n : 0) * p.K;
+        w_inv[i] = ok ? 0u : 0xFFFFFFFFu;
+        w_base[i] = ok ? (uint32_t)n * (uint32_t)p.K * 2u + chunk * 16u : 0u;
     }
 
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-
-    // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring)
+    // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring); branch-free
     auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC]) {
-        const int k = kt * BK + chunk * 8;
-        const bool kok = k < p.K;
+        const uint32_t kbyte = (uint32_t)kt * (BK * 2);
+        // all ones when this lane's 8 k-elements lie beyond K (ragged last tile) or the tile is past this split's range:
+        // such loads return zeros, so the K loop below needs no conditionals at all (the compiler then counts the
+        // outstanding loads exactly and waits only for the register set it is about to store)
+        const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + chunk * 8)) >> 31) | (uint32_t)((kt1 - 1 - kt) >> 31);
         if (CONV) {
             const int tap = (kt * BK) / p.Cin;
-            const int c = (kt * BK) % p.Cin + chunk * 8;
+            const uint32_t cbyte = (uint32_t)((kt * BK) % p.Cin + chunk * 8) * 2u;
             const int ky = tap / p.ks, kx = tap % p.ks;
             const int hlim = p.ups ? p.Hin * 2 : p.Hin, wlim = p.ups ? p.Win * 2 : p.Win;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
                 int iy = a_oy[i] * p.stride + ky - p.pad;
                 int ix = a_ox[i] * p.stride + kx - p.pad;
-                const bool ok = a_ok[i] && kok && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+                // sign bit set if any of iy, ix, hlim-1-iy, wlim-1-ix is negative -> halo mask
+                const uint32_t halo = (uint32_t)((iy | ix | (hlim - 1 - iy) | (wlim - 1 - ix)) >> 31);
                 if (p.ups) { iy >>= 1; ix >>= 1; }
-                ra[i] = ok ? *reinterpret_cast<const u32x4*>(a_ptr[i] + ((size_t)iy * p.Win + ix) * p.Cin + c) : zero;
+                const uint32_t off = (a_base[i] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[i] | k_inv;
+                ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < AC; ++i)
-                ra[i] = (a_ok[i] && kok) ? *reinterpret_cast<const u32x4*>(a_ptr[i] + k) : zero;
+            for (int i = 0; i < AC; ++i) {
+                const uint32_t off = (a_base[i] + kbyte) | a_inv[i] | k_inv;
+                ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+            }
         }
 #pragma unroll
-        for (int i = 0; i < WC; ++i)
-            rw[i] = (w_ok[i] && kok) ? *reinterpret_cast<const u32x4*>(w_ptr[i] + k) : zero;
+        for (int i = 0; i < WC; ++i) {
+            const uint32_t off = (w_base[i] + kbyte) | w_inv[i] | k_inv;
+            rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+        }
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
         bf16_t* base = lds + buf * TILE_ELEMS;
@@ -219,23 +235,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     };
 
     u32x4 a0[AC], w0[WC], a1[AC], w1[WC];
-    if (kt0 < kt1) {
-        load_tile(kt0, a0, w0);
-        if (kt0 + 1 < kt1) load_tile(kt0 + 1, a1, w1);
-        store_tile(0, a0, w0);
-        if (kt0 + 2 < kt1) load_tile(kt0 + 2, a0, w0);
-    }
+    load_tile(kt0, a0, w0);
+    load_tile(kt0 + 1, a1, w1);
+    store_tile(0, a0, w0);
+    load_tile(kt0 + 2, a0, w0);
     __syncthreads();
-    // invariant at loop top: LDS buf0 = tile kt; R1 = tile kt+1 (in flight); R0 = tile kt+2 (in flight)
+    // invariant at loop top: LDS buf0 = tile kt; R1 = tile kt+1 (in flight); R0 = tile kt+2 (in flight).
+    // Tiles >= kt1 are all-zero (masked loads): an odd tail costs one wasted half-iteration, never a wrong sum.
+    // sched_barrier(0) pins the issue order: each register set's loads go out right after the barrier that frees it,
+    // a full compute phase before they are needed (left alone, hipcc sinks both load groups to the end of the body).
     for (int kt = kt0; kt < kt1; kt += 2) {
         compute(0);
-        if (kt + 1 < kt1) store_tile(1, a1, w1);
+        store_tile(1, a1, w1);
         __syncthreads();
-        if (kt + 3 < kt1) load_tile(kt + 3, a1, w1);
-        if (kt + 1 < kt1) compute(1);
-        if (kt + 2 < kt1) store_tile(0, a0, w0);
+        load_tile(kt + 3, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        store_tile(0, a0, w0);
         __syncthreads();
-        if (kt + 4 < kt1) load_tile(kt + 4, a0, w0);
+        load_tile(kt + 4, a0, w0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- GEGLU epilogue: value tile j and gate tile j + NT/2 of the same lane ----
@@ -400,6 +419,9 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU output has N/2 columns
     a.act = a.geglu ? 0 : act;
     a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;
+    SPIDER_CHECK((size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), "gemm: operands must be < 4 GiB");
+    a.a_bytes = (uint32_t)((size_t)(M - 1) * lda * 2 + (size_t)K * 2);
+    a.w_bytes = (uint32_t)((size_t)N * K * 2);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
 
@@ -424,6 +446,9 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
     a.act = 0; a.out_scale = out_scale; a.ws = (float*)ws;
     a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.ks = ks; a.stride = stride;
     a.pad = pad; a.ups = ups;
+    SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv2d: operands must be < 4 GiB");
+    a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
+    a.w_bytes = (uint32_t)((size_t)Cout * a.K * 2);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
 
