@@ -359,14 +359,15 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     int splits = 1;
     if (nk >= 44 && t128 >= 24) {
         small = false;
-        splits = (768 + t128 - 1) / t128;
+        splits = 768 / t128;                       // fill ~3 blocks per CU ...
+        if (splits < nk / 32) splits = nk / 32;    // ... and never leave one block with hundreds of K tiles (down_proj)
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
     } else if (t128 >= 384) {
         small = false;
     } else {
         small = true;
-        if (t64 < 256 && nk >= 16) {
+        if (t64 < 256 && nk >= 64) {               // short K: the extra reduce launch costs more than it hides
             splits = (512 + t64 - 1) / t64;
             if (splits > 16) splits = 16;
             if (splits > nk / 4) splits = nk / 4;
