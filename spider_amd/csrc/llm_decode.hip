@@ -595,16 +595,28 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     const size_t bh = blockIdx.x;  // b * n_q + hq
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
-    for (int s = wave; s < nsplit; s += 4) {
-        const float ms = part_ml[(bh * nsplit + s) * 2], ls = part_ml[(bh * nsplit + s) * 2 + 1];
-        const float2 ov = *reinterpret_cast<const float2*>(part_o + (bh * nsplit + s) * D + lane * 2);
-        const float mn = fmaxf(m, ms);
-        const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
-        const float bsc = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
-        l = l * a + ls * bsc;
-        o0 = o0 * a + ov.x * bsc;
-        o1 = o1 * a + ov.y * bsc;
-        m = mn;
+    for (int s0 = wave; s0 < nsplit; s0 += 32) {       // 8 independent (m,l) + O loads in flight per wave
+        float2 mlv[8], ovv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + 4 * u;
+            const bool ok = s < nsplit;
+            const size_t pi = bh * nsplit + (ok ? s : 0);
+            mlv[u] = *reinterpret_cast<const float2*>(part_ml + pi * 2);
+            ovv[u] = *reinterpret_cast<const float2*>(part_o + pi * D + lane * 2);
+            if (!ok) mlv[u] = float2{-INFINITY, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float ms = mlv[u].x, ls = mlv[u].y;
+            const float mn = fmaxf(m, ms);
+            const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
+            const float bsc = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
+            l = l * a + ls * bsc;
+            o0 = o0 * a + ovv[u].x * bsc;
+            o1 = o1 * a + ovv[u].y * bsc;
+            m = mn;
+        }
     }
     if (lane == 0) { sm_m[wave] = m; sm_l[wave] = l; }
     sm_o[wave][lane * 2] = o0;
@@ -719,17 +731,28 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         }
     };
 
-    for (int t = t0 + wave * 4 + sub; t < t1; t += 16) {
-        const u32x4 kq = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
-        const u32x4 vq = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
-        const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w}, vw[4] = {vq.x, vq.y, vq.z, vq.w};
-        float kf[8], vf[8];
+    // 4 cache rows per lane group in flight (K and V): a one-row-per-iteration loop serialises the HBM round trips
+    for (int tb = t0 + wave * 4 + sub; tb < t1; tb += 64) {
+        u32x4 kq[4], vq[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kf[2 * j] = bf16lo_to_f32(kw[j]); kf[2 * j + 1] = bf16hi_to_f32(kw[j]);
-            vf[2 * j] = bf16lo_to_f32(vw[j]); vf[2 * j + 1] = bf16hi_to_f32(vw[j]);
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(tb + 16 * u, t1 - 1);       // clamped rows are loaded but not used
+            kq[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
+            vq[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
         }
-        update(kf, vf);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (tb + 16 * u < t1) {                       // uniform within the 16-lane row group
+                const uint32_t kw[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, vw[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
+                float kf[8], vf[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kf[2 * j] = bf16lo_to_f32(kw[j]); kf[2 * j + 1] = bf16hi_to_f32(kw[j]);
+                    vf[2 * j] = bf16lo_to_f32(vw[j]); vf[2 * j + 1] = bf16hi_to_f32(vw[j]);
+                }
+                update(kf, vf);
+            }
+        }
     }
     // the current token: last split, wave 0, row sub-group 0 (16 lanes) -- from registers, and appended to the cache
     if (split == nsplit - 1 && wave == 0 && sub == 0 && t_new >= beg) {
