@@ -35,14 +35,27 @@ from .unet import UNetEngine, denoise
 from .vae import VAEDecoderEngine
 
 BF16 = torch.bfloat16
-_STYLES = None
+
+# Style templates are prompt DATA of upstream StoryDiffusion (utils/style_template.py: name -> (positive template with
+# "{prompt}", negative prompt)). They are not shipped here; point SPIDER_STORY_STYLES at a JSON file
+# {"name": ["positive {prompt} ...", "negative ..."], ...} or call register_styles(). "(No style)" -- the entry the
+# reference falls back to for unknown names (Comic_Generation.py:408-413) -- is built in.
+_STYLES: Dict[str, tuple] = {"(No style)": ("{prompt}", "")}
+_STYLES_LOADED = False
+
+
+def register_styles(table: Dict[str, tuple]) -> None:
+    _STYLES.update({k: tuple(v) for k, v in table.items()})
 
 
 def styles() -> Dict[str, tuple]:
-    global _STYLES
-    if _STYLES is None:
-        with open(os.path.join(os.path.dirname(__file__), "data", "story_styles.json")) as f:
-            _STYLES = {k: tuple(v) for k, v in json.load(f).items()}
+    global _STYLES_LOADED
+    if not _STYLES_LOADED:
+        _STYLES_LOADED = True
+        path = os.environ.get("SPIDER_STORY_STYLES")
+        if path and os.path.exists(path):
+            with open(path) as f:
+                register_styles(json.load(f))
     return _STYLES
 
 

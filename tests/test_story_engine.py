@@ -130,7 +130,8 @@ def test_story_generation_api(dev):
     from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
     from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
     from spider_amd.schedulers import DDIMScheduler
-    from spider_amd.story import StableDiffusionXLPipeline, story_generation
+    from spider_amd.story import StableDiffusionXLPipeline, register_styles, story_generation
+    register_styles({"Sketch": ("pencil sketch of {prompt}, cross hatching", "colour, photo")})
     from spider_amd.unet import UNetEngine
     from spider_amd.vae import VAEConfig, VAEDecoderEngine
     from helpers import FakeTokenizer
@@ -145,7 +146,7 @@ def test_story_generation_api(dev):
                                      FakeTokenizer(), FakeTokenizer(), DDIMScheduler())
     pipe.enable_freeu(0.6, 0.4, 1.1, 1.2)
     args = dict(general_prompt="a man with a black suit", prompt_array=["wake up", "have breakfast", "go to work", "read a book", "sleep"],
-                style_name="Comic book", height=64, width=64, num_steps=7, output_type="np")
+                style_name="Sketch", height=64, width=64, num_steps=7, output_type="np")
     a = story_generation(pipe, **args)
     b = story_generation(pipe, **args)
     assert len(a) == 5 and a[0].shape == (64, 64, 3)
