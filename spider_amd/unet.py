@@ -428,18 +428,3 @@ def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: torch.Ten
         latents = scheduler.step(eps, t, latents)
     return latents
 
-
-def smoke_check(dev) -> None:
-    """Tiny UNet step on the GPU against the fp32 CPU oracle (used by __graft_entry__.smoke())."""
-    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
-    ocfg = UNetCfg.tiny()
-    w = random_unet_weights(ocfg, seed=0)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 16, 16, generator=g).bfloat16().float()
-    enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
-    ref = UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc)
-    eng.prepare(torch.tensor([500]), enc.to(dev))
-    got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(BF16), 0, use_graph=False).permute(0, 3, 1, 2).cpu()
-    rel = float((got - ref).norm() / ref.norm())
-    assert rel < 2e-2, f"smoke: UNet step differs from the oracle (rel L2 {rel:.4f})"
