@@ -1,0 +1,17 @@
+"""PMC aid: repeated launches of one GEMM / conv shape (run under rocprofv3 --pmc ...)."""
+import sys, torch
+from spider_amd import ops
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "gate_up"
+if which == "gate_up":
+    A = torch.randn(1536, 3584, device=dev).bfloat16(); W = (torch.randn(37888, 3584, device=dev) * 0.02).bfloat16()
+    f = lambda: ops.gemm(A, W)
+elif which == "conv64":
+    x = torch.randn(2, 64, 64, 640, device=dev).bfloat16(); w = (torch.randn(320, 3, 3, 640, device=dev) * 0.02).bfloat16()
+    f = lambda: ops.conv2d(x, w)
+else:
+    A = torch.randn(8192, 320, device=dev).bfloat16(); W = (torch.randn(960, 320, device=dev) * 0.02).bfloat16()
+    f = lambda: ops.gemm(A, W)
+for _ in range(6):
+    f()
+torch.cuda.synchronize()

@@ -11,8 +11,8 @@
 // so the host picks the tile and a split-K factor that bring the grid to >= ~2 blocks per CU; split-K partials go
 // to an fp32 workspace (plain stores, one slab per split) and a second kernel reduces them and applies the epilogue.
 // Operand roles are swapped (W tile is the MFMA "A" operand) so each lane ends up with 4 consecutive output
-// columns of one row -> 8-byte epilogue loads/stores. LDS rows are padded to 144 B (odd multiple of 16 B:
-// conflict-free ds_read_b128), double-buffered, global->register prefetch one K tile ahead.
+// columns of one row -> 8-byte epilogue loads/stores. LDS rows are 128 B with an XOR chunk swizzle (conflict-free
+// ds_read_b128 / ds_write_b128), double-buffered, with a 2-deep global->register prefetch ring.
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -21,7 +21,11 @@ using namespace spider;
 namespace {
 
 constexpr int BK = 64;
-constexpr int LDS_STRIDE = BK + 8;  // elements; 144 bytes
+constexpr int LDS_STRIDE = BK;      // elements; 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7
+// LDS image: chunk c (16 B) of row r lives at r*128 + ((c ^ ((r >> 1) & 7)) * 16). A ds_read_b128 serves 16-lane groups
+// that MIX two k-chunks of the 16x16x32 fragment (lanes {0-3,12-15} of chunk g with lanes {20-27} of chunk g+1), so
+// row padding alone leaves 2-way conflicts (measured: SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE); with this
+// swizzle every group hits 16 distinct 16-byte slots, and so do the 8-lane groups of the ds_write_b128 stores.
 
 struct GemmArgs {
     const bf16_t* A;
@@ -199,14 +203,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
         }
     };
+    const int st_chunk = chunk ^ ((lrow >> 1) & 7);   // rows lrow + 32*i share bits 1..3 with lrow
     auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
         bf16_t* base = lds + buf * TILE_ELEMS;
 #pragma unroll
         for (int i = 0; i < AC; ++i)
-            *reinterpret_cast<u32x4*>(base + (lrow + 32 * i) * LDS_STRIDE + chunk * 8) = ra[i];
+            *reinterpret_cast<u32x4*>(base + (lrow + 32 * i) * LDS_STRIDE + st_chunk * 8) = ra[i];
 #pragma unroll
         for (int i = 0; i < WC; ++i)
-            *reinterpret_cast<u32x4*>(base + (BM + lrow + 32 * i) * LDS_STRIDE + chunk * 8) = rw[i];
+            *reinterpret_cast<u32x4*>(base + (BM + lrow + 32 * i) * LDS_STRIDE + st_chunk * 8) = rw[i];
     };
 
     f32x4 acc[MT][NT];
@@ -215,17 +220,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;   // fragment rows are frow + 16*i: same swizzle
     auto compute = [&](int buf) {
-        const bf16_t* abase = lds + buf * TILE_ELEMS + (wm * (BM / 2) + frow) * LDS_STRIDE + fk;
-        const bf16_t* wbase = lds + buf * TILE_ELEMS + (BM + wn * (BN / 2) + frow) * LDS_STRIDE + fk;
+        const bf16_t* abase = lds + buf * TILE_ELEMS + (wm * (BM / 2) + frow) * LDS_STRIDE;
+        const bf16_t* wbase = lds + buf * TILE_ELEMS + (BM + wn * (BN / 2) + frow) * LDS_STRIDE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fg) ^ fswz) * 8;
             bf16x8 af[MT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abase + i * 16 * LDS_STRIDE + ks * 32);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abase + i * 16 * LDS_STRIDE + coff);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wbase + j * 16 * LDS_STRIDE + ks * 32);
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wbase + j * 16 * LDS_STRIDE + coff);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
