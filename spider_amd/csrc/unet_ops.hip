@@ -149,20 +149,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 // GroupNorm for small feature maps (HW <= 256): ONE launch, one block per (group, batch); the group's data
 // (HW x cpg values, 4-byte pairs, L2-resident) is read twice by the same block. Replaces the stats + apply pair
 // whose two launches dominate at 16x16 / 8x8 latents.
+template <int MAXP>
 __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
                                                        const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C,
                                                        int G, float eps, int silu) {
     __shared__ float red[4];
+    // MAXP channel pairs per thread: HW * cpg / 2 <= 256 * MAXP (host-checked)
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = C / G, hp = cpg / 2;          // channel pairs per group
     const int n = HW * hp;
     const bf16_t* xb = x + (size_t)b * HW * C + g * cpg;
     bf16_t* yb = y + (size_t)b * HW * C + g * cpg;
+    // the group's data is read ONCE into registers (all loads independent and in flight together)
+    uint32_t v[MAXP];
+    int off[MAXP];
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+        const int i = threadIdx.x + u * 256;
+        const int ic = i < n ? i : 0;
+        const int px = ic / hp, cp = ic - px * hp;
+        off[u] = px * C + 2 * cp;
+        v[u] = i < n ? *reinterpret_cast<const uint32_t*>(xb + off[u]) : 0u;
+    }
     float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int px = i / hp, cp = i - px * hp;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + (size_t)px * C + 2 * cp);
-        const float lo = bf16lo_to_f32(v), hi = bf16hi_to_f32(v);
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+        const float lo = bf16lo_to_f32(v[u]), hi = bf16hi_to_f32(v[u]);   // padding entries are zeros
         s += lo + hi;
         q += lo * lo + hi * hi;
     }
@@ -170,18 +182,21 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     const float mu = block_sum<4>(s, red) / cnt;
     const float var = fmaxf(block_sum<4>(q, red) / cnt - mu * mu, 0.f);
     const float rs = rsqrtf(var + eps);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int px = i / hp, cp = i - px * hp;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(xb + (size_t)px * C + 2 * cp);
-        const uint32_t gv = *reinterpret_cast<const uint32_t*>(gamma + g * cpg + 2 * cp);
-        const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + 2 * cp);
-        float lo = (bf16lo_to_f32(v) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
-        float hi = (bf16hi_to_f32(v) - mu) * rs * bf16hi_to_f32(gv) + bf16hi_to_f32(bv);
-        if (silu) {
-            lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
-            hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+        const int i = threadIdx.x + u * 256;
+        if (i < n) {
+            const int cp2 = off[u] % C;   // = 2*cp (channel offset inside the group)
+            const uint32_t gv = *reinterpret_cast<const uint32_t*>(gamma + g * cpg + cp2);
+            const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + cp2);
+            float lo = (bf16lo_to_f32(v[u]) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
+            float hi = (bf16hi_to_f32(v[u]) - mu) * rs * bf16hi_to_f32(gv) + bf16hi_to_f32(bv);
+            if (silu) {
+                lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
+                hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
+            }
+            *reinterpret_cast<uint32_t*>(yb + off[u]) = pack_bf16x2(lo, hi);
         }
-        *reinterpret_cast<uint32_t*>(yb + (size_t)px * C + 2 * cp) = pack_bf16x2(lo, hi);
     }
 }
 
@@ -579,10 +594,14 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
                                int C, int G, float eps, int silu, void* stream) {
     SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
-    if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch
+    if ((long)HW * (C / G) <= 20480 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
         dim3 g0(G, B);
-        gn_small_kernel<<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                             (bf16_t*)y, HW, C, G, eps, silu);
+        if ((long)HW * (C / G) <= 10240)
+            gn_small_kernel<20><<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                                     (bf16_t*)y, HW, C, G, eps, silu);
+        else
+            gn_small_kernel<40><<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                                     (bf16_t*)y, HW, C, G, eps, silu);
         SPIDER_LAUNCH_OK();
         return 0;
     }
