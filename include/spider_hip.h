@@ -91,6 +91,17 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
                             int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream);
 
+/* General NHWC conv as implicit GEMM: rectangular / dilated kernels (w OHWI [Cout,kh,kw,Cin], Cin % 8 == 0), a fused
+ * nearest upsample to an explicit size up_h x up_w in (in, 2*in] (diffusers Upsample2D with `upsample_size`, reached when
+ * the AudioLDM latent height 125 is not a multiple of 8: custom_ad.py:490-504), fused activation (1 silu, 2 gelu,
+ * 3 quick-gelu, 5 leaky-relu(act_param), 6 relu, 7 tanh). 1-D convs (HiFi-GAN vocoder behind
+ * custom_ad.py:293-300) are Hin = kh = 1; the (3,1,1) temporal convs of UNet3D (custom_vd.py:671-676) are
+ * Hin = frames, Win = H*W, kh = 3, kw = 1. */
+int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                             float out_scale, void* ws, long ws_bytes, void* stream);
+
 /* fused attention (prefill causal GQA: modeling_llama3.py:202-237; UNet self/cross attention:
  * StoryDiffusion/utils/gradio_utils.py:400-472; consistent self-attention with the column keep vector of
  * cal_attn_mask_xl: Comic_Generation.py:129-196, gradio_utils.py:241-287). Strides in elements. */
@@ -116,6 +127,17 @@ int spider_swiglu_bf16(const void* x, void* y, int M, int inner, void* stream);
 int spider_concat_channels_bf16(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream);
 int spider_act_bf16(const void* x, void* y, long n, int act, void* stream);
 int spider_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+/* act_ex: 1 silu, 2 gelu(erf), 3 quick-gelu, 5 leaky-relu(param), 6 relu, 7 tanh (HiFi-GAN / CLAP pooler+projection) */
+int spider_act_ex_bf16(const void* x, void* y, long n, int act, float param, void* stream);
+/* y = (a + b) * scale  (HiFi-GAN: mean of the residual-block branches) */
+int spider_add_scaled_bf16(const void* a, const void* b, void* y, long n, float scale, void* stream);
+/* ConvTranspose1d = per-tap GEMM (spider_gemm_bf16 with fp32 output, cols [B,L_in,k,Cout]) + this overlap-add:
+ * y[b,t,:] = bias + sum_{i*stride - pad + j == t} cols[b,i,j,:]; L_out = (L_in-1)*stride - 2*pad + k
+ * (HiFi-GAN upsampler, SpeechT5HifiGan called from custom_ad.py:293-300). */
+int spider_col2im1d_f32_bf16(const float* cols, const void* bias, void* y, int B, int L_in, int k, int stride, int pad,
+                             int Cout, void* stream);
+/* y[r,:] = x[r,:] / max(||x[r,:]||_2, eps)  (F.normalize of the CLAP text embedding, custom_ad.py:217-219,272-273) */
+int spider_l2_normalize_rows_bf16(const void* x, void* y, int rows, int n, float eps, void* stream);
 int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                                  int Cout, int ks, void* stream);
 int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
@@ -128,8 +150,9 @@ int spider_latent_to_nhwc_bf16(const float* lat, void* out, int B, int C, int HW
 int spider_cfg_combine_f32(const float* eps2, float* out, int B, int C, int HW, float guidance, void* stream);
 /* scheduler.step as a linear update: out = sum_j host_coefs[j] * ins[j]; host_ins is a HOST array of n device ptrs */
 int spider_lincomb_f32(const float* const* host_ins, const float* host_coefs, int n, float* out, long total, void* stream);
-/* row softmax of fp32 scores -> bf16 probabilities (VAE mid-block single-head attention, d = 512) */
-int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, float scale, void* stream);
+/* row softmax of fp32 scores -> bf16 probabilities (VAE mid-block single-head attention, d = 512). Rows are n wide;
+ * the first n_valid columns are normalised, the rest (padding up to a multiple of 8 for the P.V GEMM) written as 0. */
+int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream);
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream);
 
 #ifdef __cplusplus

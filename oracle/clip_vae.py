@@ -130,8 +130,9 @@ def vae_param_shapes(c: VAECfg) -> dict:
     return S
 
 
-def vae_decode(c: VAECfg, w: dict, latents: torch.Tensor) -> torch.Tensor:
-    """latents [B,4,h,w] (scheduler space) -> image [B,3,8h,8w] in [0,1] (custom_sd.py:386-393)."""
+def vae_decode(c: VAECfg, w: dict, latents: torch.Tensor, to_image: bool = True) -> torch.Tensor:
+    """latents [B,4,h,w] (scheduler space) -> image [B,3,8h,8w] in [0,1] (custom_sd.py:386-393).
+    to_image=False: the raw decoder output, i.e. AudioLDM's mel spectrogram (custom_ad.py:287-291)."""
     gn = lambda n, x: F.group_norm(x, c.groups, w[n + ".weight"], w[n + ".bias"], 1e-6)
     conv = lambda n, x, pad=1: F.conv2d(x, w[n + ".weight"], w[n + ".bias"], padding=pad)
     lin = lambda n, x: F.linear(x, w[n + ".weight"], w[n + ".bias"])
@@ -157,4 +158,4 @@ def vae_decode(c: VAECfg, w: dict, latents: torch.Tensor) -> torch.Tensor:
         if i != n - 1:
             h = conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
     img = conv("decoder.conv_out", F.silu(gn("decoder.conv_norm_out", h)))
-    return (img / 2 + 0.5).clamp(0, 1)
+    return (img / 2 + 0.5).clamp(0, 1) if to_image else img

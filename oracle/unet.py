@@ -40,10 +40,31 @@ class UNetCfg:
     addition_time_dim: int = 0                                 # SDXL: 256 (text_time addition embedding)
     addition_in: int = 0                                       # SDXL: 2816
     mid_depth: Optional[int] = None
+    # AudioLDM (custom_ad.py:575-581 calls unet(x, t, encoder_hidden_states=None, class_labels=prompt_embeds)):
+    class_in: int = 0                                          # class_embed_type="simple_projection": Linear(class_in, T)
+    class_concat: bool = False                                 # class_embeddings_concat: emb = cat([temb, class_emb])
+    cross_dims: Optional[Tuple[int, ...]] = None               # per-down-block cross_attention_dim (None: cross_dim everywhere)
 
     @staticmethod
     def sd15():
         return UNetCfg()
+
+    @staticmethod
+    def audioldm():   # cvssp/audioldm-s-full-v2 unet/config.json (checkpoint-side values, SURVEY 8 marks them with a dagger)
+        return UNetCfg(8, 8, (128, 256, 384, 640), (False, True, True, True), (True, True, True, False), (1, 1, 1, 1),
+                       (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (128, 256, 384, 640))
+
+    @staticmethod
+    def tiny_audio():
+        return UNetCfg(8, 8, (64, 128, 128), (False, True, True), (True, True, False), (1, 1, 1), (2, 4, 4), 2, 0, 32,
+                       False, 0, 0, None, 48, True, (64, 128, 128))
+
+    def cross_dim_of(self, down_idx: int) -> int:
+        return self.cross_dims[down_idx] if self.cross_dims is not None else self.cross_dim
+
+    @property
+    def temb_in(self):   # width of the embedding each ResnetBlock2D.time_emb_proj consumes
+        return self.temb_dim * (2 if (self.class_in and self.class_concat) else 1)
 
     @staticmethod
     def sdxl():
@@ -86,18 +107,18 @@ def unet_param_shapes(cfg: UNetCfg) -> dict:
     def norm(n, c): S[n + ".weight"] = (c,); S[n + ".bias"] = (c,)
 
     def resnet(n, ci, co):
-        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci, 3); lin(n + ".time_emb_proj", co, T)
+        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci, 3); lin(n + ".time_emb_proj", co, cfg.temb_in)
         norm(n + ".norm2", co); conv(n + ".conv2", co, co, 3)
         if ci != co: conv(n + ".conv_shortcut", co, ci, 1)
 
-    def transformer(n, c, depth):
+    def transformer(n, c, depth, xd):
         norm(n + ".norm", c)
         if cfg.linear_proj: lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
         else: conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
             norm(b + ".norm1", c); norm(b + ".norm2", c); norm(b + ".norm3", c)
-            for a, kd in (("attn1", c), ("attn2", cfg.cross_dim)):
+            for a, kd in (("attn1", c), ("attn2", xd)):
                 lin(f"{b}.{a}.to_q", c, c, False); lin(f"{b}.{a}.to_k", c, kd, False); lin(f"{b}.{a}.to_v", c, kd, False)
                 lin(f"{b}.{a}.to_out.0", c, c)
             lin(b + ".ff.net.0.proj", 8 * c, c); lin(b + ".ff.net.2", c, 4 * c)
@@ -106,17 +127,19 @@ def unet_param_shapes(cfg: UNetCfg) -> dict:
     lin("time_embedding.linear_1", T, c0); lin("time_embedding.linear_2", T, T)
     if cfg.addition_in:
         lin("add_embedding.linear_1", T, cfg.addition_in); lin("add_embedding.linear_2", T, T)
+    if cfg.class_in:
+        lin("class_embedding", T, cfg.class_in)
     nb = len(cfg.block_out)
     ch = c0
     for i, co in enumerate(cfg.block_out):
         for j in range(cfg.layers_per_block):
             resnet(f"down_blocks.{i}.resnets.{j}", ch if j == 0 else co, co)
-            if cfg.down_attn[i]: transformer(f"down_blocks.{i}.attentions.{j}", co, cfg.depth[i])
+            if cfg.down_attn[i]: transformer(f"down_blocks.{i}.attentions.{j}", co, cfg.depth[i], cfg.cross_dim_of(i))
         ch = co
         if i != nb - 1: conv(f"down_blocks.{i}.downsamplers.0.conv", co, co, 3)
     cm = cfg.block_out[-1]
     resnet("mid_block.resnets.0", cm, cm)
-    transformer("mid_block.attentions.0", cm, cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1])
+    transformer("mid_block.attentions.0", cm, cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1], cfg.cross_dim_of(nb - 1))
     resnet("mid_block.resnets.1", cm, cm)
     rev = list(reversed(cfg.block_out))
     rdepth = list(reversed(cfg.depth))
@@ -127,7 +150,7 @@ def unet_param_shapes(cfg: UNetCfg) -> dict:
             skip = cin_skip if j == cfg.layers_per_block else co
             rin = prev if j == 0 else co
             resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, co)
-            if cfg.up_attn[i]: transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i])
+            if cfg.up_attn[i]: transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i], cfg.cross_dim_of(nb - 1 - i))
         prev = co
         if i != nb - 1: conv(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
     norm("conv_norm_out", c0); conv("conv_out", cfg.out_ch, c0, 3)
@@ -207,7 +230,8 @@ class UNetOracle:
             else:
                 h = self.attention(b + ".attn1", y, y, heads) + h
             y = F.layer_norm(h, (C,), self.w[b + ".norm2.weight"], self.w[b + ".norm2.bias"], 1e-5)
-            h = self.attention(b + ".attn2", y, enc, heads) + h
+            # encoder_hidden_states=None (AudioLDM): diffusers' Attention falls back to its own input as the K/V source
+            h = self.attention(b + ".attn2", y, enc if enc is not None else y, heads) + h
             y = F.layer_norm(h, (C,), self.w[b + ".norm3.weight"], self.w[b + ".norm3.bias"], 1e-5)
             p = self._lin(b + ".ff.net.0.proj", y)
             a, gate = p.chunk(2, -1)
@@ -218,7 +242,7 @@ class UNetOracle:
             h = self._conv(n + ".proj_out", h.reshape(B, H, W, C).permute(0, 3, 1, 2), pad=0)
         return h + res
 
-    def time_embed(self, t: torch.Tensor, B: int, added: Optional[dict] = None):
+    def time_embed(self, t: torch.Tensor, B: int, added: Optional[dict] = None, class_labels=None):
         cfg = self.cfg
         te = timestep_embedding(t.expand(B) if t.ndim == 0 else t, cfg.block_out[0]).to(self.dtype)
         emb = self._lin("time_embedding.linear_2", F.silu(self._lin("time_embedding.linear_1", te)))
@@ -226,15 +250,21 @@ class UNetOracle:
             tid = timestep_embedding(added["time_ids"].flatten(), cfg.addition_time_dim).reshape(B, -1)
             add = torch.cat([added["text_embeds"].float(), tid], -1).to(self.dtype)
             emb = emb + self._lin("add_embedding.linear_2", F.silu(self._lin("add_embedding.linear_1", add)))
+        if cfg.class_in:   # class_embed_type="simple_projection" (+ class_embeddings_concat)
+            ce = self._lin("class_embedding", class_labels.to(self.dtype))
+            emb = torch.cat([emb, ce], -1) if cfg.class_concat else emb + ce
         return emb
 
     @torch.no_grad()
-    def forward(self, sample, t, enc, added: Optional[dict] = None):
-        """sample [B,4,h,w] fp32, t scalar tensor, enc [B,77,cross] -> [B,4,h,w]."""
+    def forward(self, sample, t, enc, added: Optional[dict] = None, class_labels=None):
+        """sample [B,4,h,w] fp32, t scalar tensor, enc [B,77,cross] (None: AudioLDM, conditioning comes in through
+        class_labels [B, class_in]) -> [B,4,h,w]. Latent sizes that are not a multiple of 2^(levels-1) follow diffusers'
+        forward_upsample_size rule: every upsampler interpolates to the size of the next skip connection."""
         cfg = self.cfg
         B = sample.shape[0]
-        sample, enc = sample.to(self.dtype), enc.to(self.dtype)
-        temb = self.time_embed(torch.as_tensor(t), B, added)
+        sample = sample.to(self.dtype)
+        enc = enc.to(self.dtype) if enc is not None else None
+        temb = self.time_embed(torch.as_tensor(t), B, added, class_labels)
         h = self._conv("conv_in", sample)
         skips = [h]
         nb = len(cfg.block_out)
@@ -262,7 +292,7 @@ class UNetOracle:
                 if cfg.up_attn[i]:
                     h = self.transformer(f"up_blocks.{i}.attentions.{j}", h, enc, rheads[i], rdepth[i])
             if i != nb - 1:
-                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+                h = F.interpolate(h, size=skips[-1].shape[2:], mode="nearest")   # == scale_factor 2 on even sizes
                 h = self._conv(f"up_blocks.{i}.upsamplers.0.conv", h)
         h = F.silu(self._gn("conv_norm_out", h))
         return self._conv("conv_out", h).float()
@@ -384,13 +414,14 @@ class DDIMOracle:
 
 
 @torch.no_grad()
-def denoise_loop(unet: UNetOracle, sched, latents, enc_uncond_cond, guidance, steps, added=None):
-    """custom_sd.py:627-652 with CFG batch = 2x latents. enc_uncond_cond [2B,77,C] (uncond first)."""
+def denoise_loop(unet: UNetOracle, sched, latents, enc_uncond_cond, guidance, steps, added=None, class_labels=None):
+    """custom_sd.py:627-652 with CFG batch = 2x latents. enc_uncond_cond [2B,77,C] (uncond first). AudioLDM
+    (custom_ad.py:568-594): enc_uncond_cond=None and class_labels [2B, class_in] (uncond first)."""
     ts = sched.set_timesteps(steps)
     latents = latents * sched.init_noise_sigma
     for t in ts:
         x2 = torch.cat([latents] * 2)
-        e = unet.forward(x2, t, enc_uncond_cond, added)
+        e = unet.forward(x2, t, enc_uncond_cond, added, class_labels)
         eu, ec = e.chunk(2)
         eps = eu + guidance * (ec - eu)
         latents = sched.step(eps, t, latents)

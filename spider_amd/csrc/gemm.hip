@@ -39,13 +39,26 @@ struct GemmArgs {
     int M, N, K, lda, ldc;
     uint32_t a_bytes, w_bytes;   // buffer-descriptor ranges of A and W (< 4 GiB each)
     int rows_per_group;
-    int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu
+    int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu, 5 leaky-relu(act_param), 6 relu, 7 tanh
+    float act_param;
     int geglu;              // 1: W = [value rows (N) | gate rows (N)], out[m,n] = bf16(v) * bf16(gelu(bf16(g)))  (diffusers GEGLU)
     float out_scale;        // multiplies the final value (1/rescale_output_factor)
     int splits, kt_per_split;
-    // implicit-GEMM conv (NHWC): A is the image [B, Hin, Win, Cin]; K = ks*ks*Cin
-    int conv, Hin, Win, Cin, Hout, Wout, ks, stride, pad, ups;
+    // implicit-GEMM conv (NHWC): A is the image [B, Hin, Win, Cin]; K = kh*kw*Cin (tap-major, channel-minor).
+    // ups: the conv reads a virtual nearest-2x upsampled image cropped to lim_h x lim_w (= 2*Hin or 2*Hin-1, ...);
+    // without ups lim_h/lim_w = Hin/Win. cin64: a 64-wide K tile never straddles two taps (uniform tap per tile).
+    int conv, Hin, Win, Cin, Hout, Wout, kh, kw, stride, pad_h, pad_w, dil, ups, lim_h, lim_w, cin64;
 };
+
+__device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
+    if (p.act == 1) return silu_f(v);
+    if (p.act == 2) return gelu_erf_f(v);
+    if (p.act == 3) return quick_gelu_f(v);
+    if (p.act == 5) return v > 0.f ? v : v * p.act_param;
+    if (p.act == 6) return fmaxf(v, 0.f);
+    if (p.act == 7) return tanhf(v);
+    return v;
+}
 
 // bias / rowbias / activation / residual / scale on 4 consecutive columns of one row, then store
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v[4]) {
@@ -61,11 +74,9 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
             v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
         }
+        if (p.act) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (p.act == 1) v[e] = silu_f(v[e]);
-            else if (p.act == 2) v[e] = gelu_erf_f(v[e]);
-            else if (p.act == 3) v[e] = quick_gelu_f(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(p, v[e]);
         }
         if (p.res) {
             const u32x2 rq = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldc + n);
@@ -89,9 +100,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             float t = v[e];
             if (p.bias) t += bf16_to_f32(p.bias[n + e]);
             if (p.rowbias) t += bf16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
-            if (p.act == 1) t = silu_f(t);
-            else if (p.act == 2) t = gelu_erf_f(t);
-            else if (p.act == 3) t = quick_gelu_f(t);
+            t = apply_act(p, t);
             if (p.res) t = bf16_to_f32(f32_to_bf16(t)) + bf16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
             t *= p.out_scale;
             if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
@@ -176,14 +185,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         // outstanding loads exactly and waits only for the register set it is about to store)
         const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + chunk * 8)) >> 31) | (uint32_t)((kt1 - 1 - kt) >> 31);
         if (CONV) {
-            const int tap = (kt * BK) / p.Cin;
-            const uint32_t cbyte = (uint32_t)((kt * BK) % p.Cin + chunk * 8) * 2u;
-            const int ky = tap / p.ks, kx = tap % p.ks;
-            const int hlim = p.ups ? p.Hin * 2 : p.Hin, wlim = p.ups ? p.Win * 2 : p.Win;
+            // tap of this lane's 8 k-elements: uniform per tile when Cin % 64 == 0, per lane otherwise (Cin % 8 == 0
+            // keeps a 16-byte chunk inside one tap)
+            const int kk = p.cin64 ? kt * BK : kt * BK + chunk * 8;
+            const int tap = kk / p.Cin;
+            const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? chunk * 8 : 0)) * 2u;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int hlim = p.lim_h, wlim = p.lim_w;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
-                int iy = a_oy[i] * p.stride + ky - p.pad;
-                int ix = a_ox[i] * p.stride + kx - p.pad;
+                int iy = a_oy[i] * p.stride + ky * p.dil - p.pad_h;
+                int ix = a_ox[i] * p.stride + kx * p.dil - p.pad_w;
                 // sign bit set if any of iy, ix, hlim-1-iy, wlim-1-ix is negative -> halo mask
                 const uint32_t halo = (uint32_t)((iy | ix | (hlim - 1 - iy) | (wlim - 1 - ix)) >> 31);
                 if (p.ups) { iy >>= 1; ix >>= 1; }
@@ -416,7 +428,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     SPIDER_CHECK(ldc % 4 == 0 && ldc >= (act == 4 ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
     SPIDER_CHECK((C != nullptr) != (C32 != nullptr), "gemm: exactly one of C (bf16) / C32 (fp32) must be given");
     SPIDER_CHECK(!rowbias || rows_per_group > 0, "gemm: rowbias needs rows_per_group > 0");
-    SPIDER_CHECK(act >= 0 && act <= 4, "gemm: unknown activation");
+    SPIDER_CHECK(act >= 0 && act <= 7, "gemm: unknown activation");
     SPIDER_CHECK(act != 4 || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU epilogue needs bf16 output, even N, no res/rowbias");
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.C32 = (float*)C32;
@@ -425,6 +437,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     a.geglu = act == 4;
     a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU output has N/2 columns
     a.act = a.geglu ? 0 : act;
+    a.act_param = 0.1f;             // leaky-relu slope of the GEMM form (HiFi-GAN); the conv form takes it as an argument
     a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;
     SPIDER_CHECK((size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), "gemm: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)(M - 1) * lda * 2 + (size_t)K * 2);
@@ -432,31 +445,53 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     return launch(a, ws ? ws_bytes : 0, stream);
 }
 
-// NHWC conv2d as implicit GEMM. x [B, Hin, Win, Cin] bf16; w [Cout, ks, ks, Cin] bf16 (OHWI);
-// y [B, Hout, Wout, Cout]. ups=1 reads x through a fused nearest-2x upsample (Upsample2D + conv).
+// NHWC conv as implicit GEMM, general form. x [B, Hin, Win, Cin] bf16; w [Cout, kh, kw, Cin] bf16 (OHWI);
+// y [B, Hout, Wout, Cout] bf16. up_h/up_w > 0: x is read through a fused nearest-2x upsample cropped to
+// up_h x up_w (Upsample2D with an explicit output size, then the conv). 1-D convs are Hin = kh = 1; the
+// (3,1,1) temporal conv of UNet3D is Hin = frames, Win = H*W, kh = 3, kw = 1.
 // rowbias [B, Cout] is the per-image time-embedding add of ResnetBlock2D; res is [B,Hout,Wout,Cout].
-int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
-                            const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream) {
-    SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv2d: empty problem");
-    SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
-    SPIDER_CHECK(stride == 1 || stride == 2, "conv2d: stride must be 1 or 2");
-    SPIDER_CHECK(Cin % 64 == 0, "conv2d: Cin must be a multiple of 64 for the MFMA path (use conv2d_small)");
-    SPIDER_CHECK(Cout % 4 == 0, "conv2d: Cout must be a multiple of 4");
-    SPIDER_CHECK(!(ups && stride != 1), "conv2d: fused upsample requires stride 1");
-    const int Hs = ups ? Hin * 2 : Hin, Ws = ups ? Win * 2 : Win;
-    const int Hout = (Hs + 2 * pad - ks) / stride + 1, Wout = (Ws + 2 * pad - ks) / stride + 1;
+int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                             float out_scale, void* ws, long ws_bytes, void* stream) {
+    SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv: empty problem");
+    SPIDER_CHECK(kh >= 1 && kw >= 1 && kh * kw <= 64 && dil >= 1, "conv: kernel taps must be 1..64, dilation >= 1");
+    SPIDER_CHECK(stride == 1 || stride == 2, "conv: stride must be 1 or 2");
+    SPIDER_CHECK(Cin % 8 == 0, "conv: Cin must be a multiple of 8 for the MFMA path (use conv2d_small)");
+    SPIDER_CHECK(Cout % 4 == 0, "conv: Cout must be a multiple of 4");
+    SPIDER_CHECK(pad_h >= 0 && pad_w >= 0, "conv: negative padding");
+    SPIDER_CHECK(act == 0 || act == 1 || act == 2 || act == 3 || act == 5 || act == 6 || act == 7, "conv: unknown activation");
+    const int ups = (up_h > 0 || up_w > 0) ? 1 : 0;
+    if (ups) {
+        SPIDER_CHECK(stride == 1, "conv: fused upsample requires stride 1");
+        SPIDER_CHECK(up_h > Hin && up_h <= 2 * Hin && up_w > Win && up_w <= 2 * Win,
+                     "conv: upsampled size must lie in (in, 2*in] per axis");
+    }
+    const int Hs = ups ? up_h : Hin, Ws = ups ? up_w : Win;
+    const int Hout = (Hs + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wout = (Ws + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
+    SPIDER_CHECK(Hout > 0 && Wout > 0, "conv: kernel larger than the padded input");
     GemmArgs a{};
     a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.C = (bf16_t*)y; a.C32 = nullptr;
     a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
-    a.rows_per_group = Hout * Wout; a.M = B * Hout * Wout; a.N = Cout; a.K = ks * ks * Cin; a.lda = Cin; a.ldc = Cout;
-    a.act = 0; a.out_scale = out_scale; a.ws = (float*)ws;
-    a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.ks = ks; a.stride = stride;
-    a.pad = pad; a.ups = ups;
-    SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv2d: operands must be < 4 GiB");
+    a.rows_per_group = Hout * Wout; a.M = B * Hout * Wout; a.N = Cout; a.K = kh * kw * Cin; a.lda = Cin; a.ldc = Cout;
+    a.act = act; a.act_param = act_param; a.out_scale = out_scale; a.ws = (float*)ws;
+    a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.kh = kh; a.kw = kw; a.stride = stride;
+    a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil; a.ups = ups; a.lim_h = Hs; a.lim_w = Ws; a.cin64 = Cin % 64 == 0;
+    SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
     a.w_bytes = (uint32_t)((size_t)Cout * a.K * 2);
     return launch(a, ws ? ws_bytes : 0, stream);
+}
+
+// Square-kernel form used by the SD / SDXL UNet and the VAE (ResnetBlock2D convs, Down/Upsample2D, shortcuts).
+// ups=1 fuses the exact nearest-2x upsample.
+int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                            const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
+                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream) {
+    SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
+    SPIDER_CHECK(Cin % 64 == 0, "conv2d: Cin must be a multiple of 64 for the MFMA path (use conv2d_small)");
+    return spider_conv_nhwc_ex_bf16(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, ks, ks, stride, pad, pad, 1,
+                                    ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

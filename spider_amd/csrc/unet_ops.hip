@@ -373,8 +373,9 @@ __global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// elementwise unary on bf16 (act: 1 silu, 2 gelu, 3 quick-gelu), n multiple of 8
-__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t nvec, int act) {
+// elementwise unary on bf16 (act: 1 silu, 2 gelu, 3 quick-gelu, 5 leaky-relu(param), 6 relu, 7 tanh), n multiple of 8
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t nvec, int act,
+                                                  float param) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(x + idx * 8);
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
@@ -385,12 +386,73 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
             if (act == 1) { lo = silu_f(lo); hi = silu_f(hi); }
             else if (act == 2) { lo = gelu_erf_f(lo); hi = gelu_erf_f(hi); }
             else if (act == 3) { lo = quick_gelu_f(lo); hi = quick_gelu_f(hi); }
+            else if (act == 5) { lo = lo > 0.f ? lo : lo * param; hi = hi > 0.f ? hi : hi * param; }
+            else if (act == 6) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            else if (act == 7) { lo = tanhf(lo); hi = tanhf(hi); }
             o[j] = pack_bf16x2(lo, hi);
         }
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
     }
+}
+
+// y = bf16((a + b) * scale) elementwise
+__global__ __launch_bounds__(256) void add_scaled_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                         bf16_t* __restrict__ y, size_t nvec, float scale) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+        const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
+        const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
+        const uint32_t pw[4] = {p.x, p.y, p.z, p.w}, qw[4] = {q.x, q.y, q.z, q.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2((bf16lo_to_f32(pw[j]) + bf16lo_to_f32(qw[j])) * scale, (bf16hi_to_f32(pw[j]) + bf16hi_to_f32(qw[j])) * scale);
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
+    }
+}
+
+// ConvTranspose1d overlap-add (see spider_col2im1d_f32_bf16): one thread per (b, t, 4 output channels)
+__global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__ cols, const bf16_t* __restrict__ bias,
+                                                       bf16_t* __restrict__ y, int B, int L_in, int L_out, int k, int stride,
+                                                       int pad, int Cout) {
+    const int c4 = Cout / 4;
+    const size_t total = (size_t)B * L_out * c4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cq = (int)(idx % c4);
+        const int t = (int)((idx / c4) % L_out);
+        const int b = (int)(idx / ((size_t)c4 * L_out));
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        // taps j == (t + pad) mod stride, input position i = (t + pad - j) / stride
+        for (int j = (t + pad) % stride; j < k; j += stride) {
+            const int i = (t + pad - j) / stride;
+            if (t + pad - j < 0 || i >= L_in) continue;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(cols + (((size_t)b * L_in + i) * k + j) * Cout + cq * 4);
+            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        }
+        if (bias) {
+            const u32x2 bq = *reinterpret_cast<const u32x2*>(bias + cq * 4);
+            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
+            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+        }
+        u32x2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(y + (((size_t)b * L_out + t) * Cout) + cq * 4) = o;
+    }
+}
+
+// row-wise L2 normalisation, one block per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int n, float eps) {
+    __shared__ float red[4];
+    const bf16_t* xr = x + (size_t)blockIdx.x * n;
+    bf16_t* yr = y + (size_t)blockIdx.x * n;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = bf16_to_f32(xr[i]); ss += v * v; }
+    const float inv = 1.f / fmaxf(sqrtf(block_sum<4>(ss, red)), eps);
+    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_bf16(bf16_to_f32(xr[i]) * inv);
 }
 
 // y = bf16(a + b) elementwise
@@ -473,26 +535,32 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __re
     const int cvn = Cin / 8;
     for (size_t pix = (size_t)blockIdx.x * 4 + wave; pix < npix; pix += (size_t)gridDim.x * 4) {
         const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int i = lane; i < ks * ks * cvn; i += 64) {
             const int tap = i / cvn, cvi = i % cvn;
             const int iy = oy + tap / ks - pad, ix = ox + tap % ks - pad;
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             const u32x4 a = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * Cin + cvi * 8);
             const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-            for (int co = 0; co < Cout; ++co) {
-                const u32x4 wq = *reinterpret_cast<const u32x4*>(ws + (size_t)co * kk + tap * Cin + cvi * 8);
-                const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[co] += bf16lo_to_f32(aw[j]) * bf16lo_to_f32(ww[j]) + bf16hi_to_f32(aw[j]) * bf16hi_to_f32(ww[j]);
+            for (int co = 0; co < 8; ++co) {
+                if (co < Cout) {
+                    const u32x4 wq = *reinterpret_cast<const u32x4*>(ws + (size_t)co * kk + tap * Cin + cvi * 8);
+                    const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[co] += bf16lo_to_f32(aw[j]) * bf16lo_to_f32(ww[j]) + bf16hi_to_f32(aw[j]) * bf16hi_to_f32(ww[j]);
+                }
             }
         }
-        for (int co = 0; co < Cout; ++co) {
-            const float t = wave_sum(acc[co]) + (bias ? bf16_to_f32(bias[co]) : 0.f);
-            if (lane == 0) {
-                if (y32) y32[pix * Cout + co] = t;
-                else y16[pix * Cout + co] = f32_to_bf16(t);
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            if (co < Cout) {
+                const float t = wave_sum(acc[co]) + (bias ? bf16_to_f32(bias[co]) : 0.f);
+                if (lane == 0) {
+                    if (y32) y32[pix * Cout + co] = t;
+                    else y16[pix * Cout + co] = f32_to_bf16(t);
+                }
             }
         }
     }
@@ -559,10 +627,12 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 
 // Row softmax: y[r, :] = bf16(softmax(scale * x[r, :])), x fp32 [rows, n] (scores of the VAE's single-head
 // d=512 attention, diffusers AttnProcessor on AutoencoderKL.mid_block.attentions.0). One block per row.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int n, float scale) {
+// Columns n_valid..n-1 (row padding up to the 8-element granularity of the next GEMM) are written as zeros.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int ld, int n,
+                                                           float scale) {
     __shared__ float red[4];
-    const float* xr = x + (size_t)blockIdx.x * n;
-    bf16_t* yr = y + (size_t)blockIdx.x * n;
+    const float* xr = x + (size_t)blockIdx.x * ld;
+    bf16_t* yr = y + (size_t)blockIdx.x * ld;
     float m = -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, xr[i]);
     m = wave_max(m);
@@ -573,6 +643,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = threadIdx.x; i < n; i += 256) s += __expf(xr[i] * scale - m);
     const float inv = 1.f / block_sum<4>(s, red);
     for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_bf16(__expf(xr[i] * scale - m) * inv);
+    for (int i = n + threadIdx.x; i < ld; i += 256) yr[i] = 0;
 }
 
 inline int grid_for(size_t n) {
@@ -594,14 +665,11 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
                                int C, int G, float eps, int silu, void* stream) {
     SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
-    if ((long)HW * (C / G) <= 20480 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
-        dim3 g0(G, B);
-        if ((long)HW * (C / G) <= 10240)
-            gn_small_kernel<20><<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                                     (bf16_t*)y, HW, C, G, eps, silu);
-        else
-            gn_small_kernel<40><<<g0, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                                     (bf16_t*)y, HW, C, G, eps, silu);
+    if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
+        // (measured: a 40-pair variant for 20K-element groups is no faster than the stats + apply pair -- 64 blocks cannot
+        // pull enough bandwidth)
+        gn_small_kernel<20><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                                        (bf16_t*)y, HW, C, G, eps, silu);
         SPIDER_LAUNCH_OK();
         return 0;
     }
@@ -667,9 +735,45 @@ int spider_concat_channels_bf16(const void* a, const void* b, void* y, long rows
     return 0;
 }
 
+int spider_act_ex_bf16(const void* x, void* y, long n, int act, float param, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0, "act: n must be a multiple of 8");
+    SPIDER_CHECK(act == 1 || act == 2 || act == 3 || act == 5 || act == 6 || act == 7, "act: unknown activation");
+    act_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, (size_t)n / 8, act, param);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
 int spider_act_bf16(const void* x, void* y, long n, int act, void* stream) {
-    SPIDER_CHECK(n > 0 && n % 8 == 0 && act >= 1 && act <= 3, "act: n must be a multiple of 8, act in 1..3");
-    act_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, (size_t)n / 8, act);
+    SPIDER_CHECK(act >= 1 && act <= 3, "act: act in 1..3 (spider_act_ex_bf16 has the parameterised forms)");
+    return spider_act_ex_bf16(x, y, n, act, 0.f, stream);
+}
+
+int spider_add_scaled_bf16(const void* a, const void* b, void* y, long n, float scale, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0, "add_scaled: n must be a multiple of 8");
+    add_scaled_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+                                                                               (size_t)n / 8, scale);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// ConvTranspose1d, second half: overlap-add of the per-tap GEMM output. cols [B, L_in, k, Cout] fp32 (cols[b,i,j,:] =
+// x[b,i,:] . w[:, :, j]); y[b, t, :] = bias + sum over (i, j) with i*stride - pad + j == t. L_out = (L_in-1)*stride - 2*pad + k.
+int spider_col2im1d_f32_bf16(const float* cols, const void* bias, void* y, int B, int L_in, int k, int stride, int pad,
+                             int Cout, void* stream) {
+    SPIDER_CHECK(B > 0 && L_in > 0 && k >= 1 && stride >= 1 && pad >= 0 && Cout > 0 && Cout % 4 == 0, "col2im1d: bad shape (Cout % 4 == 0)");
+    const int L_out = (L_in - 1) * stride - 2 * pad + k;
+    SPIDER_CHECK(L_out > 0, "col2im1d: empty output");
+    const size_t total = (size_t)B * L_out * (Cout / 4);
+    col2im1d_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(cols, (const bf16_t*)bias, (bf16_t*)y, B, L_in, L_out, k,
+                                                                      stride, pad, Cout);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// y[r, :] = x[r, :] / max(||x[r, :]||_2, eps)   (F.normalize of the CLAP text embedding, custom_ad.py:217-219)
+int spider_l2_normalize_rows_bf16(const void* x, void* y, int rows, int n, float eps, void* stream) {
+    SPIDER_CHECK(rows > 0 && n > 0 && n <= 8192, "l2_normalize_rows: n must be 1..8192");
+    l2norm_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, n, eps);
     SPIDER_LAUNCH_OK();
     return 0;
 }
@@ -703,7 +807,7 @@ int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias,
 // conv with Cout <= 4 (conv_out). Exactly one of y32 (fp32) / y16 (bf16) is written, layout [B,H,W,Cout].
 int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
                                   int W, int Cin, int Cout, int ks, void* stream) {
-    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "conv_small_cout: Cout <= 4, Cin % 8 == 0");
+    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "conv_small_cout: Cout <= 8, Cin % 8 == 0");
     SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cout: kernel size must be 1 or 3");
     SPIDER_CHECK((y32 != nullptr) != (y16 != nullptr), "conv_small_cout: give exactly one output");
     SPIDER_CHECK((Cout * ks * ks * Cin) % 8 == 0, "conv_small_cout: weight count must be a multiple of 8");
@@ -743,9 +847,9 @@ int spider_lincomb_f32(const float* const* ins, const float* coefs, int n, float
     return 0;
 }
 
-int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, float scale, void* stream) {
-    SPIDER_CHECK(rows > 0 && n > 0 && scale > 0.f, "softmax_rows: bad shape");
-    softmax_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n, scale);
+int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream) {
+    SPIDER_CHECK(rows > 0 && n > 0 && n_valid > 0 && n_valid <= n && scale > 0.f, "softmax_rows: bad shape");
+    softmax_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n, n_valid, scale);
     SPIDER_LAUNCH_OK();
     return 0;
 }

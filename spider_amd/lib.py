@@ -39,6 +39,7 @@ SIGNATURES = {
     "spider_attn_decode_fused_bf16": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _l, _vp]),
     "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _l, _vp]),
+    "spider_conv_nhwc_ex_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _vp, _l, _vp]),
     "spider_attn_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _i, _i, _vp, _vp, _i, _i, _vp]),
     "spider_groupnorm_nchunk": (_i, [_i]),
     "spider_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
@@ -48,12 +49,16 @@ SIGNATURES = {
     "spider_concat_channels_bf16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "spider_act_bf16": (_i, [_vp, _vp, _l, _i, _vp]),
     "spider_add_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "spider_act_ex_bf16": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+    "spider_add_scaled_bf16": (_i, [_vp, _vp, _vp, _l, _f, _vp]),
+    "spider_col2im1d_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "spider_l2_normalize_rows_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "spider_conv2d_small_cin_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_conv2d_small_cout_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_latent_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "spider_cfg_combine_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "spider_lincomb_f32": (_i, [_vp, _vp, _i, _vp, _l, _vp]),
-    "spider_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "spider_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "spider_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }
 

@@ -15,7 +15,7 @@ import torch
 from . import lib as _lib
 
 BF16 = torch.bfloat16
-ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4}
+ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "leaky_relu": 5, "relu": 6, "tanh": 7}
 
 
 def _stream() -> int:
@@ -186,6 +186,46 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     return out
 
 
+def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1, up_size=None, act=None, act_param=0.0,
+            out_scale=1.0, out=None):
+    """General NHWC conv. x [B,H,W,Cin] bf16, w [Cout,kh,kw,Cin] bf16 -> [B,Ho,Wo,Cout]. up_size=(uh,uw): x is read through
+    a nearest upsample to that size (each in (in, 2*in]) before the conv."""
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    B, H, Wd, Cin = x.shape
+    Cout, kh, kw = w.shape[0], w.shape[1], w.shape[2]
+    assert w.shape[3] == Cin, f"conv: x has {Cin} channels, w expects {w.shape[3]}"
+    Hs, Ws = up_size if up_size is not None else (H, Wd)
+    Ho = (Hs + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Ws + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+    uh, uw = up_size if up_size is not None else (0, 0)
+    _lib.call("spider_conv_nhwc_ex_bf16", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout, kh, kw,
+              stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), _p(_workspace(x.device)),
+              WS_BYTES, _stream())
+    return out
+
+
+def conv1d(x, w, bias=None, res=None, pad=0, dil=1, act=None, act_param=0.0, out=None):
+    """x [B,L,Cin] bf16, w [Cout,k,Cin] bf16 (nn.Conv1d weight permuted to O,K,I) -> [B,Lo,Cout]."""
+    B, L, Cin = x.shape
+    y = conv_ex(x.view(B, 1, L, Cin), w.view(w.shape[0], 1, w.shape[1], Cin), bias=bias,
+                res=None if res is None else res.view(B, 1, res.shape[1], res.shape[2]), pad=(0, pad), dil=dil, act=act,
+                act_param=act_param, out=None if out is None else out.view(B, 1, out.shape[1], out.shape[2]))
+    return y.view(B, y.shape[2], y.shape[3])
+
+
+def conv_transpose1d(x, w_taps, bias, k: int, stride: int, pad: int):
+    """nn.ConvTranspose1d. x [B,L,Cin] bf16; w_taps [k*Cout, Cin] bf16 with row j*Cout+o = weight[:, o, j]
+    -> [B, (L-1)*stride - 2*pad + k, Cout]. Per-tap GEMM (fp32) + overlap-add."""
+    B, L, Cin = x.shape
+    Cout = w_taps.shape[0] // k
+    cols = gemm(x, w_taps, out_f32=True)                      # [B, L, k*Cout] fp32
+    out = torch.empty(B, (L - 1) * stride - 2 * pad + k, Cout, dtype=BF16, device=x.device)
+    _lib.call("spider_col2im1d_f32_bf16", _p(cols), _p(bias), _p(out), B, L, k, stride, pad, Cout, _stream())
+    return out
+
+
 def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_off=None, kv_beg=None,
               keep_bits=None, blk=0, q_off=0, out=None):
     """q [B,Lq,Hq*d], k/v [B,Lk,Hkv*d] (last dim contiguous; batch/row strides free) -> [B,Lq,Hq*d]."""
@@ -287,11 +327,30 @@ def concat_channels(a, b, out=None):
     return out
 
 
-def act(x, kind: str, out=None):
+def act(x, kind: str, param: float = 0.0, out=None):
     _chk(x, BF16, "x")
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("spider_act_bf16", _p(x), _p(out), x.numel(), ACT[kind], _stream())
+    _lib.call("spider_act_ex_bf16", _p(x), _p(out), x.numel(), ACT[kind], float(param), _stream())
+    return out
+
+
+def add_scaled(a, b, scale: float, out=None):
+    """bf16((a + b) * scale)"""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("spider_add_scaled_bf16", _p(a), _p(b), _p(out), a.numel(), float(scale), _stream())
+    return out
+
+
+def l2_normalize(x, eps: float = 1e-12, out=None):
+    """rows of x [..., n] divided by max(L2 norm, eps) (torch.nn.functional.normalize)."""
+    _chk(x, BF16, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    n = x.shape[-1]
+    _lib.call("spider_l2_normalize_rows_bf16", _p(x), _p(out), x.numel() // n, n, float(eps), _stream())
     return out
 
 
@@ -366,11 +425,12 @@ def nhwc_to_nchw(x, mul=1.0, add_=0.0, clamp01=False, out=None):
     return out
 
 
-def softmax_rows(x, scale=1.0, out=None):
-    """fp32 [rows, n] -> bf16 softmax(scale * x) per row."""
+def softmax_rows(x, scale=1.0, n_valid=None, out=None):
+    """fp32 [rows, n] -> bf16 softmax(scale * x) per row over the first n_valid (default n) columns; the rest -> 0."""
     _chk(x, torch.float32, "x")
     n = x.shape[-1]
     if out is None:
         out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    _lib.call("spider_softmax_rows_f32_bf16", _p(x), _p(out), x.numel() // n, n, float(scale), _stream())
+    _lib.call("spider_softmax_rows_f32_bf16", _p(x), _p(out), x.numel() // n, n, n if n_valid is None else n_valid, float(scale),
+              _stream())
     return out

@@ -22,11 +22,13 @@ import numpy as np
 import torch
 
 from . import ops
+from .clap import ClapTextEngine
 from .clip import CLIPTextEngine
 from .registry import registry
 from .schedulers import SCHEDULERS, PNDMScheduler
 from .unet import UNetEngine, denoise
 from .vae import VAEDecoderEngine
+from .vocoder import HifiGanEngine
 
 
 class PipelineOutput:
@@ -65,7 +67,7 @@ class StableDiffusionPipeline:
         sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device),
-                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),
+                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, scaling=0.18215),   # custom_sd.py:388
                    CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 64))
 
@@ -153,3 +155,161 @@ class StableDiffusionPipeline:
         if output_type == "pil":
             image = numpy_to_pil(image)
         return PipelineOutput(image) if return_dict else (image, None)
+
+
+class AudioPipelineOutput:
+    def __init__(self, audios):
+        self.audios = audios
+
+
+@registry.register_model("ad")
+class AudioLDMPipeline:
+    """AudioLDM text-to-audio with the reference's call contract (spider/models/custom_ad.py):
+
+        pipe = AudioLDMPipeline.from_pretrained(path, torch_dtype=...).to(device)
+        pipe(prompt=[...] | prompt_embeds=T[B,512], audio_length_in_s, num_inference_steps, guidance_scale,
+             negative_prompt, num_waveforms_per_prompt, generator, latents, output_type="np",
+             return_prompts_only=False) -> .audios   (np.ndarray [B, samples] at vocoder.sampling_rate)
+
+    __call__ :400-609 (length logic :490-504, denoising loop :568-594 with `encoder_hidden_states=None,
+    class_labels=prompt_embeds`), _encode_prompt :147-285 (CLAP text_embeds + F.normalize :217-219), check_inputs
+    :320-378, prepare_latents :381-401, decode_latents :287-291, mel_spectrogram_to_waveform :293-300. Numerics on the
+    HIP engines: ClapTextEngine, UNetEngine (class-embedding form), VAEDecoderEngine, HifiGanEngine."""
+
+    def __init__(self, vae: VAEDecoderEngine, text_encoder: Optional[ClapTextEngine], tokenizer, unet: UNetEngine, scheduler,
+                 vocoder: HifiGanEngine, sample_size: int = 128):
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.vocoder = vae, text_encoder, tokenizer, unet, vocoder
+        self.scheduler = scheduler
+        self.sample_size = sample_size
+        self.device = unet.device
+        self.vae_scale_factor = 2 ** (len(vae.cfg.block_out) - 1)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
+        """diffusers layout: unet/, vae/, text_encoder/, tokenizer/, vocoder/, scheduler/scheduler_config.json."""
+        from transformers import RobertaTokenizer
+        sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
+        sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"))
+        if sched_cls is None:
+            raise NotImplementedError(f"scheduler {sc.get('_class_name')!r}")
+        sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
+        ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
+        return cls(VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),
+                   ClapTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
+                   RobertaTokenizer.from_pretrained(os.path.join(path, "tokenizer")),
+                   UNetEngine.from_pretrained(os.path.join(path, "unet"), device), sched,
+                   HifiGanEngine.from_pretrained(os.path.join(path, "vocoder"), device), ucfg.get("sample_size", 128))
+
+    def to(self, device=None, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------ prompt encoding (custom_ad.py:147-285)
+    def _clap(self, text: List[str], max_length=None) -> torch.Tensor:
+        tk = self.tokenizer
+        enc = tk(text, padding="max_length", max_length=max_length or tk.model_max_length, truncation=True, return_tensors="pt")
+        return self.text_encoder.text_embeds(enc.input_ids, enc.attention_mask, normalize=True)
+
+    def _encode_prompt(self, prompt, num_waveforms_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None,
+                       negative_prompt_embeds=None) -> torch.Tensor:
+        if prompt is not None and isinstance(prompt, str):
+            prompt = [prompt]
+        batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._clap(prompt)
+        prompt_embeds = prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+        bs, dim = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_waveforms_per_prompt).view(bs * num_waveforms_per_prompt, dim)
+        if do_cfg and negative_prompt_embeds is None:
+            if negative_prompt is None:
+                uncond = [""] * batch_size
+            elif prompt is not None and type(prompt) is not type(negative_prompt) and not isinstance(negative_prompt, str):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+            elif isinstance(negative_prompt, str):
+                uncond = [negative_prompt]
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {batch_size}.")
+            else:
+                uncond = list(negative_prompt)
+            # the reference pads the unconditional text to prompt_embeds.shape[1] (= the embedding width, custom_ad.py:255);
+            # padding length does not change a masked encoder's output, so only the truncation limit matters
+            negative_prompt_embeds = self._clap(uncond, max_length=min(prompt_embeds.shape[1], self.tokenizer.model_max_length))
+        if do_cfg:
+            n = negative_prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+            n = n.repeat(1, num_waveforms_per_prompt).view(batch_size * num_waveforms_per_prompt, n.shape[1])
+            prompt_embeds = torch.cat([n, prompt_embeds])   # [uncond | cond] (custom_ad.py:283)
+        return prompt_embeds.contiguous()
+
+    def check_inputs(self, prompt, audio_length_in_s, vocoder_upsample_factor, callback_steps, negative_prompt=None,
+                     prompt_embeds=None, negative_prompt_embeds=None):
+        min_len = vocoder_upsample_factor * self.vae_scale_factor
+        if audio_length_in_s < min_len:
+            raise ValueError(f"`audio_length_in_s` has to be a positive value greater than or equal to {min_len}, but is {audio_length_in_s}.")
+        if self.vocoder.config.model_in_dim % self.vae_scale_factor != 0:
+            raise ValueError(f"The number of frequency bins in the vocoder's log-mel spectrogram has to be divisible by the VAE scale "
+                             f"factor, but got {self.vocoder.config.model_in_dim} bins and a scale factor of {self.vae_scale_factor}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly")
+
+    def prepare_latents(self, batch_size, channels, height, generator, latents=None):
+        shape = (batch_size, channels, height // self.vae_scale_factor, self.vocoder.config.model_in_dim // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if generator is not None and not isinstance(generator, list) else self.device
+            latents = torch.randn(shape, generator=generator if not isinstance(generator, list) else None, device=gdev,
+                                  dtype=torch.float32).to(self.device)
+        else:
+            latents = latents.to(self.device, torch.float32)
+        return (latents * self.scheduler.init_noise_sigma).contiguous()
+
+    def decode_latents(self, latents) -> torch.Tensor:
+        return self.vae.decode(latents, to_image=False)          # mel [B,1,frames,n_mel]; 1/scaling_factor folded into the VAE
+
+    def mel_spectrogram_to_waveform(self, mel: torch.Tensor) -> torch.Tensor:
+        if mel.dim() == 4:
+            mel = mel.squeeze(1)
+        return self.vocoder(mel).cpu().float()
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, audio_length_in_s: Optional[float] = None,
+                 num_inference_steps: int = 10, guidance_scale: float = 2.5, negative_prompt=None,
+                 num_waveforms_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, return_dict: bool = True, callback=None, callback_steps: int = 1,
+                 cross_attention_kwargs=None, output_type: Optional[str] = "np", return_prompts_only: bool = False):
+        vc = self.vocoder.config
+        vocoder_upsample_factor = float(np.prod(vc.upsample_rates)) / vc.sampling_rate
+        if audio_length_in_s is None:
+            audio_length_in_s = self.sample_size * self.vae_scale_factor * vocoder_upsample_factor
+        height = int(audio_length_in_s / vocoder_upsample_factor)
+        original_waveform_length = int(audio_length_in_s * vc.sampling_rate)
+        if height % self.vae_scale_factor != 0:
+            height = int(np.ceil(height / self.vae_scale_factor)) * self.vae_scale_factor
+        self.check_inputs(prompt, audio_length_in_s, vocoder_upsample_factor, callback_steps, negative_prompt, prompt_embeds,
+                          negative_prompt_embeds)
+        if isinstance(prompt, str):
+            batch_size = 1
+        elif isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0 and not return_prompts_only
+        embeds = self._encode_prompt(prompt, num_waveforms_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        if return_prompts_only:
+            return embeds
+        lat = self.prepare_latents(batch_size * num_waveforms_per_prompt, self.unet.cfg.in_ch, height, generator, latents)
+        lat = denoise(self.unet, self.scheduler, lat, None, guidance_scale, num_inference_steps, class_labels=embeds)
+        mel = self.decode_latents(lat)
+        audio = self.mel_spectrogram_to_waveform(mel)[:, :original_waveform_length]
+        if output_type == "np":
+            audio = audio.numpy()
+        return AudioPipelineOutput(audio) if return_dict else (audio,)

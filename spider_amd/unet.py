@@ -41,10 +41,26 @@ class UNetConfig:
     addition_time_dim: int = 0
     addition_in: int = 0
     mid_depth: Optional[int] = None
+    # AudioLDM form (custom_ad.py:575-581: encoder_hidden_states=None, class_labels=prompt_embeds)
+    class_in: int = 0              # class_embed_type="simple_projection": Linear(class_in, temb_dim)
+    class_concat: bool = False     # class_embeddings_concat: resnets see cat([temb, class_emb])
+    cross_dims: Optional[Tuple[int, ...]] = None   # per-down-block cross_attention_dim
 
     @staticmethod
     def sd15():
         return UNetConfig()
+
+    @staticmethod
+    def audioldm():   # cvssp/audioldm-s-full-v2 unet/config.json (checkpoint-side values; re-read by from_pretrained)
+        return UNetConfig(8, 8, (128, 256, 384, 640), (False, True, True, True), (True, True, True, False), (1, 1, 1, 1),
+                          (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (128, 256, 384, 640))
+
+    def cross_dim_of(self, down_idx: int) -> int:
+        return self.cross_dims[down_idx] if self.cross_dims is not None else self.cross_dim
+
+    @property
+    def temb_in(self):
+        return self.temb_dim * (2 if (self.class_in and self.class_concat) else 1)
 
     @staticmethod
     def sdxl():
@@ -59,13 +75,20 @@ class UNetConfig:
         heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * nb
         tl = c.get("transformer_layers_per_block", 1)
         depth = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * nb
+        xd = c.get("cross_attention_dim")
+        xds = tuple(xd) if isinstance(xd, (list, tuple)) else None
+        text_time = c.get("addition_embed_type") == "text_time"
+        simple_proj = c.get("class_embed_type") == "simple_projection"
+        if c.get("class_embed_type") not in (None, "simple_projection"):
+            raise NotImplementedError(f"class_embed_type={c['class_embed_type']!r}")
+        pdim = c.get("projection_class_embeddings_input_dim") or 0
         return UNetConfig(c["in_channels"], c["out_channels"], bo,
                           tuple(t.startswith("CrossAttn") for t in c["down_block_types"]),
                           tuple(t.startswith("CrossAttn") for t in c["up_block_types"]), depth, heads,
-                          c.get("layers_per_block", 2), c["cross_attention_dim"], c.get("norm_num_groups", 32),
+                          c.get("layers_per_block", 2), 0 if xds is not None else (xd or 0), c.get("norm_num_groups", 32),
                           bool(c.get("use_linear_projection", False)), c.get("addition_time_embed_dim") or 0,
-                          c.get("projection_class_embeddings_input_dim") or 0,
-                          depth[-1] if c.get("addition_embed_type") == "text_time" else None)
+                          pdim if text_time else 0, depth[-1] if text_time else None,
+                          pdim if simple_proj else 0, bool(c.get("class_embeddings_concat", False)), xds)
 
     @property
     def temb_dim(self):
@@ -98,6 +121,9 @@ class UNetEngine:
             self.w[n + ".attn1.qkv"] = torch.cat([self.w[n + ".attn1.to_q.weight"], self.w[n + ".attn1.to_k.weight"],
                                                   self.w[n + ".attn1.to_v.weight"]], 0).contiguous()
             self.w[n + ".attn2.kv"] = torch.cat([self.w[n + ".attn2.to_k.weight"], self.w[n + ".attn2.to_v.weight"]], 0).contiguous()
+            if self.w[n + ".attn2.to_k.weight"].shape[1] == self.w[n + ".attn2.to_q.weight"].shape[1]:
+                # encoder_hidden_states=None (AudioLDM): attn2 attends to its own input, one fused [3C,C] projection
+                self.w[n + ".attn2.qkv"] = torch.cat([self.w[n + ".attn2.to_q.weight"], self.w[n + ".attn2.kv"]], 0).contiguous()
         # resnet table: order of time_emb_proj consumers
         self.resnets = [k[:-len(".time_emb_proj.weight")] for k in self.w if k.endswith(".time_emb_proj.weight")]
         self.tproj_w = torch.cat([self.w[r + ".time_emb_proj.weight"] for r in self.resnets], 0).contiguous()
@@ -145,11 +171,13 @@ class UNetEngine:
         return cls(cfg, w, device)
 
     # ------------------------------------------------------------------ per-call preparation
-    def prepare(self, timesteps: torch.Tensor, enc: torch.Tensor, added: Optional[dict] = None):
+    def prepare(self, timesteps: torch.Tensor, enc: Optional[torch.Tensor], added: Optional[dict] = None,
+                class_labels: Optional[torch.Tensor] = None):
         """timesteps [n] (host), enc [B2, 77, cross] bf16 on device, added: SDXL {'text_embeds','time_ids'}.
-        Computes every step's per-resnet time projection and every cross-attention layer's K/V once."""
+        Computes every step's per-resnet time projection and every cross-attention layer's K/V once.
+        AudioLDM form: enc=None (attn2 attends to its own input) and class_labels [B2, class_in]."""
         cfg, dv = self.cfg, self.device
-        B2 = enc.shape[0]
+        B2 = enc.shape[0] if enc is not None else class_labels.shape[0]
         n = len(timesteps)
         te = timestep_embedding(torch.as_tensor(timesteps), cfg.block_out[0]).to(dv).to(BF16)          # [n, c0]
         h = ops.gemm(te, self.w["time_embedding.linear_1.weight"], bias=self.w["time_embedding.linear_1.bias"], act="silu")
@@ -161,6 +189,15 @@ class UNetEngine:
             aug = ops.gemm(a, self.w["add_embedding.linear_2.weight"], bias=self.w["add_embedding.linear_2.bias"])  # [B2, T]
             emb = (emb[:, None, :].float() + aug[None].float()).to(BF16).reshape(n * B2, -1).contiguous()
             per = B2
+        elif cfg.class_in:
+            ce = ops.gemm(class_labels.to(device=dv, dtype=BF16).contiguous(), self.w["class_embedding.weight"],
+                          bias=self.w["class_embedding.bias"])                                       # [B2, T]
+            if cfg.class_concat:
+                emb = torch.cat([emb[:, None, :].expand(n, B2, -1), ce[None].expand(n, B2, -1)], -1)
+            else:
+                emb = (emb[:, None, :].float() + ce[None].float()).to(BF16)
+            emb = emb.reshape(n * B2, -1).contiguous()
+            per = B2
         else:
             per = 1
         se = ops.act(emb.contiguous(), "silu")
@@ -170,7 +207,8 @@ class UNetEngine:
             tp = tp.expand(n, B2, self.tproj_total)
         # regroup to [n, concat_r(B2 * C_r)] so each resnet's rowbias block [B2, C_r] is contiguous
         self.tproj_steps = torch.cat([tp[:, :, o:o + c].reshape(n, B2 * c) for (o, c) in (self.tproj_off[r] for r in self.resnets)], 1).contiguous()
-        enc = enc.to(BF16).contiguous()
+        self.self_cross = enc is None
+        enc = enc.to(BF16).contiguous() if enc is not None else torch.empty(B2, 0, 0, dtype=BF16, device=dv)
         # Static buffers (the per-step time projections and the cross-attention K/V) persist across calls with the same
         # CFG batch, so the captured hipGraph of one UNet evaluation stays valid from one prompt to the next.
         if getattr(self, "B2", None) != B2 or getattr(self, "_enc_len", None) != enc.shape[1]:
@@ -180,11 +218,13 @@ class UNetEngine:
                 c = self.tproj_off[r][1]
                 self.tproj_view[r] = self.tproj_cur[off:off + B2 * c].view(B2, c)
                 off += B2 * c
-            self.kv = {l: torch.empty(B2, enc.shape[1], self.w[l + ".attn2.kv"].shape[0], dtype=BF16, device=dv) for l in self.cross_layers}
+            self.kv = {} if self.self_cross else {
+                l: torch.empty(B2, enc.shape[1], self.w[l + ".attn2.kv"].shape[0], dtype=BF16, device=dv) for l in self.cross_layers}
             self._graph = None
             self.B2, self._enc_len = B2, enc.shape[1]
-        for l in self.cross_layers:
-            ops.gemm(enc, self.w[l + ".attn2.kv"], out=self.kv[l])           # [B2, 77, 2C]
+        if not self.self_cross:
+            for l in self.cross_layers:
+                ops.gemm(enc, self.w[l + ".attn2.kv"], out=self.kv[l])           # [B2, 77, 2C]
 
     # ------------------------------------------------------------------ blocks
     def _gn(self, n, x, silu, eps=1e-5):
@@ -221,9 +261,13 @@ class UNetEngine:
                 o = self._self_attn(b, y, heads)
             h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
             y = ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
-            q = ops.gemm(y, w[b + ".attn2.to_q.weight"])
-            kv = self.kv[b]
-            o = ops.attention(q, kv[..., :C], kv[..., C:], heads)
+            if self.self_cross:
+                qkv = ops.gemm(y, w[b + ".attn2.qkv"])
+                o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+            else:
+                q = ops.gemm(y, w[b + ".attn2.to_q.weight"])
+                kv = self.kv[b]
+                o = ops.attention(q, kv[..., :C], kv[..., C:], heads)
             h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
             g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
@@ -261,7 +305,11 @@ class UNetEngine:
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], rdepth[i])
             if i != nb - 1:
-                h = ops.conv2d(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"], ups=True)
+                # Upsample2D to the size of the next skip connection (diffusers' forward_upsample_size rule; = exact 2x
+                # on latents that are multiples of 2^(levels-1), 2x-1 on e.g. the 125-row AudioLDM latent)
+                th, tw = skips[-1].shape[1], skips[-1].shape[2]
+                h = ops.conv_ex(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                                pad=(1, 1), up_size=(th, tw))
         a = self._gn("conv_norm_out", h, True)
         return ops.conv2d_small_cout(a, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
 
@@ -319,17 +367,17 @@ def _param_shapes(cfg: UNetConfig) -> dict:
         if bias: S[n + ".bias"] = (co,)
     def norm(n, c): S[n + ".weight"] = (c,); S[n + ".bias"] = (c,)
     def resnet(n, ci, co):
-        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci, 3); lin(n + ".time_emb_proj", co, T)
+        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci, 3); lin(n + ".time_emb_proj", co, cfg.temb_in)
         norm(n + ".norm2", co); conv(n + ".conv2", co, co, 3)
         if ci != co: conv(n + ".conv_shortcut", co, ci, 1)
-    def transformer(n, c, depth):
+    def transformer(n, c, depth, xd):
         norm(n + ".norm", c)
         if cfg.linear_proj: lin(n + ".proj_in", c, c); lin(n + ".proj_out", c, c)
         else: conv(n + ".proj_in", c, c, 1); conv(n + ".proj_out", c, c, 1)
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
             norm(b + ".norm1", c); norm(b + ".norm2", c); norm(b + ".norm3", c)
-            for a, kd in (("attn1", c), ("attn2", cfg.cross_dim)):
+            for a, kd in (("attn1", c), ("attn2", xd)):
                 lin(f"{b}.{a}.to_q", c, c, False); lin(f"{b}.{a}.to_k", c, kd, False); lin(f"{b}.{a}.to_v", c, kd, False)
                 lin(f"{b}.{a}.to_out.0", c, c)
             lin(b + ".ff.net.0.proj", 8 * c, c); lin(b + ".ff.net.2", c, 4 * c)
@@ -338,16 +386,18 @@ def _param_shapes(cfg: UNetConfig) -> dict:
     lin("time_embedding.linear_1", T, c0); lin("time_embedding.linear_2", T, T)
     if cfg.addition_in:
         lin("add_embedding.linear_1", T, cfg.addition_in); lin("add_embedding.linear_2", T, T)
+    if cfg.class_in:
+        lin("class_embedding", T, cfg.class_in)
     nb, ch = len(cfg.block_out), c0
     for i, co in enumerate(cfg.block_out):
         for j in range(cfg.layers_per_block):
             resnet(f"down_blocks.{i}.resnets.{j}", ch if j == 0 else co, co)
-            if cfg.down_attn[i]: transformer(f"down_blocks.{i}.attentions.{j}", co, cfg.depth[i])
+            if cfg.down_attn[i]: transformer(f"down_blocks.{i}.attentions.{j}", co, cfg.depth[i], cfg.cross_dim_of(i))
         ch = co
         if i != nb - 1: conv(f"down_blocks.{i}.downsamplers.0.conv", co, co, 3)
     cm = cfg.block_out[-1]
     resnet("mid_block.resnets.0", cm, cm)
-    transformer("mid_block.attentions.0", cm, cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1])
+    transformer("mid_block.attentions.0", cm, cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1], cfg.cross_dim_of(nb - 1))
     resnet("mid_block.resnets.1", cm, cm)
     rev, rdepth, prev = list(reversed(cfg.block_out)), list(reversed(cfg.depth)), cm
     for i, co in enumerate(rev):
@@ -355,14 +405,14 @@ def _param_shapes(cfg: UNetConfig) -> dict:
         for j in range(cfg.layers_per_block + 1):
             skip = cin_skip if j == cfg.layers_per_block else co
             resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else co) + skip, co)
-            if cfg.up_attn[i]: transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i])
+            if cfg.up_attn[i]: transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i], cfg.cross_dim_of(nb - 1 - i))
         prev = co
         if i != nb - 1: conv(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
     norm("conv_norm_out", c0); conv("conv_out", cfg.out_ch, c0, 3)
     return S
 
 
-def unet_flops(cfg: UNetConfig, h: int, w: int, text_len: int = 77) -> dict:
+def unet_flops(cfg: UNetConfig, h: int, w: int, text_len: int = 77, self_cross: bool = False) -> dict:
     """Exact multiply-add count (x2) of one UNet evaluation per sample at latent h x w, by category
     (convs 2*Cin*Cout*k^2*h*w, linears 2*N*Cin*Cout, attention cores 4*N*Lk*C) -- the layer-table sum that
     SURVEY.md section 8d asks for instead of the literature figure."""
@@ -371,18 +421,18 @@ def unet_flops(cfg: UNetConfig, h: int, w: int, text_len: int = 77) -> dict:
     fl = dict(conv=0.0, linear=0.0, attn_self=0.0, attn_cross=0.0)
     nb = len(cfg.block_out)
     hh, ww = h, w
-    sizes = {}
+    sizes, level = {}, []
     for i in range(nb):
         sizes[f"down_blocks.{i}."] = (hh, ww)
+        level.append((hh, ww))
         if i != nb - 1:
-            sizes[f"down_blocks.{i}.downsamplers"] = (hh // 2, ww // 2)
-            hh, ww = hh // 2, ww // 2
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2          # stride-2, pad-1, 3x3
+            sizes[f"down_blocks.{i}.downsamplers"] = (hh, ww)
     sizes["mid_block."] = (hh, ww)
     for i in range(nb):
-        sizes[f"up_blocks.{i}."] = (hh, ww)
+        sizes[f"up_blocks.{i}."] = level[nb - 1 - i]
         if i != nb - 1:
-            sizes[f"up_blocks.{i}.upsamplers"] = (hh * 2, ww * 2)
-            hh, ww = hh * 2, ww * 2
+            sizes[f"up_blocks.{i}.upsamplers"] = level[nb - 2 - i]
     sizes["conv_in"] = sizes["conv_out"] = (h, w)
 
     def size_of(name):
@@ -400,25 +450,26 @@ def unet_flops(cfg: UNetConfig, h: int, w: int, text_len: int = 77) -> dict:
             fl["conv"] += 2.0 * shp[0] * shp[1] * shp[2] * shp[3] * sh * sw
         elif "time_emb" in n or "add_embedding" in n:
             continue  # hoisted out of the step
-        elif ".attn2.to_k" in n or ".attn2.to_v" in n:
+        elif (".attn2.to_k" in n or ".attn2.to_v" in n) and not self_cross:
             continue  # hoisted: projected once per prompt
         else:
             fl["linear"] += 2.0 * shp[0] * shp[1] * sh * sw
             if n.endswith(".attn1.to_q.weight"):
                 fl["attn_self"] += 4.0 * (sh * sw) ** 2 * shp[0]
             if n.endswith(".attn2.to_q.weight"):
-                fl["attn_cross"] += 4.0 * (sh * sw) * text_len * shp[0]
+                fl["attn_cross"] += 4.0 * (sh * sw) * (sh * sw if self_cross else text_len) * shp[0]
     fl["total"] = sum(fl.values())
     return fl
 
 
-def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: torch.Tensor, guidance: float, steps: int,
-            added: Optional[dict] = None, use_graph: bool = True) -> torch.Tensor:
+def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: Optional[torch.Tensor], guidance: float, steps: int,
+            added: Optional[dict] = None, use_graph: bool = True, class_labels: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The reference's denoising loop (custom_sd.py:627-652) on device: latents fp32 NCHW [B,4,h,w] in HBM,
     enc [2B,77,C] (uncond first, as _encode_prompt concatenates them, custom_sd.py:372). Per step:
-    cat([latents]*2)+scale (1 launch) -> UNet graph replay -> CFG combine (1) -> scheduler update (1)."""
+    cat([latents]*2)+scale (1 launch) -> UNet graph replay -> CFG combine (1) -> scheduler update (1).
+    AudioLDM (custom_ad.py:568-594): enc=None, class_labels [2B, class_in] (uncond first)."""
     ts = scheduler.set_timesteps(steps)
-    unet.prepare(ts, enc, added)
+    unet.prepare(ts, enc, added, class_labels)
     latents = (latents * scheduler.init_noise_sigma).contiguous()
     do_cfg = guidance > 1.0
     for i, t in enumerate(ts):

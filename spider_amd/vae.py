@@ -30,6 +30,15 @@ class VAEConfig:
     def sd15():
         return VAEConfig()
 
+    @staticmethod
+    def audioldm():   # cvssp/audioldm-s-full-v2 vae/config.json: mel-spectrogram VAE, 8 latent channels, 1 output channel
+        return VAEConfig(8, 1, (128, 256, 512), 2, 32, 0.9227)
+
+    @staticmethod
+    def from_diffusers_dict(c: dict) -> "VAEConfig":
+        return VAEConfig(c.get("latent_channels", 4), c.get("out_channels", 3), tuple(c.get("block_out_channels", (128, 256, 512, 512))),
+                         c.get("layers_per_block", 2), c.get("norm_num_groups", 32), c.get("scaling_factor", 0.18215))
+
 
 def _shapes(c: VAEConfig) -> dict:
     S = {}
@@ -87,15 +96,22 @@ class VAEDecoderEngine:
         return cls(cfg, w, device)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
-        import glob, os
+    def from_pretrained(cls, path: str, device="cuda:0", scaling=None):
+        """diffusers layout: <path>/config.json + *.safetensors. `scaling` overrides the checkpoint's scaling_factor (the
+        reference's SD pipeline hard-codes 0.18215, custom_sd.py:388; its AudioLDM pipeline reads the config,
+        custom_ad.py:289)."""
+        import glob, json, os
         from safetensors import safe_open
+        cj = os.path.join(path, "config.json")
+        cfg = VAEConfig.from_diffusers_dict(json.load(open(cj))) if os.path.exists(cj) else VAEConfig.sd15()
+        if scaling is not None:
+            cfg.scaling = scaling
         w = {}
         for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(VAEConfig.sd15(), w, device)
+        return cls(cfg, w, device)
 
     def _gn(self, n, x, silu):
         return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, 1e-6, silu)
@@ -114,20 +130,26 @@ class VAEDecoderEngine:
         N = H * W_
         x = self._gn(a + ".group_norm", h, False).view(B, N, C)
         out = torch.empty_like(x)
+        N8 = (N + 7) // 8 * 8      # the P.V GEMM contracts over tokens: pad them to the 16-byte row granularity
         for b in range(B):
             xb = x[b]
+            xk = xb
+            if N8 != N:
+                xk = torch.zeros(N8, C, dtype=BF16, device=x.device)
+                xk[:N] = xb
             q = ops.gemm(xb, w[a + ".to_q.weight"], bias=w[a + ".to_q.bias"])
-            k = ops.gemm(xb, w[a + ".to_k.weight"], bias=w[a + ".to_k.bias"])
-            vT = ops.gemm(w[a + ".to_v.weight"], xb)                        # [C, N] = Wv . x^T (bias folded below)
-            s = ops.gemm(q, k, out_f32=True)                                # [N, N] fp32 scores
-            p = ops.softmax_rows(s, scale=C ** -0.5)
+            k = ops.gemm(xk, w[a + ".to_k.weight"], bias=w[a + ".to_k.bias"])
+            vT = ops.gemm(w[a + ".to_v.weight"], xk)                        # [C, N8] = Wv . x^T (bias folded below)
+            s = ops.gemm(q, k, out_f32=True)                                # [N, N8] fp32 scores
+            p = ops.softmax_rows(s, scale=C ** -0.5, n_valid=N)             # padded columns -> 0
             o = ops.gemm(p, vT, bias=w[a + ".to_v.bias"])                   # P.V + b_v (rows of P sum to 1)
             ops.gemm(o, w[a + ".to_out.0.weight"], bias=w[a + ".to_out.0.bias"], res=h.view(B, N, C)[b], out=out[b])
         return out.view(B, H, W_, C)
 
     @torch.no_grad()
-    def decode(self, latents: torch.Tensor) -> torch.Tensor:
-        """latents fp32 NCHW [B,4,h,w] (scheduler space) -> image fp32 NCHW [B,3,8h,8w] in [0,1]."""
+    def decode(self, latents: torch.Tensor, to_image: bool = True) -> torch.Tensor:
+        """latents fp32 NCHW [B,4,h,w] (scheduler space) -> image fp32 NCHW [B,3,8h,8w] in [0,1].
+        to_image=False returns the raw decoder output (AudioLDM's mel spectrogram, custom_ad.py:288-291)."""
         c, w = self.cfg, self.w
         z = ops.latent_to_nhwc(latents.contiguous())
         z = ops.conv2d_small_cin(z, w["post_quant_conv.weight_scaled"], w["post_quant_conv.bias"]) if c.latent % 8 == 0 else \
@@ -143,7 +165,7 @@ class VAEDecoderEngine:
             if i != n - 1:
                 h = ops.conv2d(h, w[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], ups=True)
         img = ops.conv2d_small_cout(self._gn("decoder.conv_norm_out", h, True), w["decoder.conv_out.weight"], w["decoder.conv_out.bias"])
-        return ops.nhwc_to_nchw(img, 0.5, 0.5, True)
+        return ops.nhwc_to_nchw(img, 0.5, 0.5, True) if to_image else ops.nhwc_to_nchw(img, 1.0, 0.0, False)
 
     def _post_quant(self, z):
         """4 -> 4 channel 1x1 conv: Cout = 4 fits the small-Cout kernel only when Cin % 8 == 0, so pad Cin to 8."""

@@ -366,3 +366,60 @@ def test_skinny_mfma_gemm(ops, dev, B, N, K):
         I = N // 2
         gg, uu = ref[:, :I], ref[:, I:]
         close(ops.gemv_swiglu(W.to(dev), x.to(dev)), F.silu(gg) * uu, 1.5e-2, 2e-2, "skinny swiglu", rel_to_std=True)
+
+
+# ------------------------------------------------------------------------------------------ general conv / vocoder kernels
+@pytest.mark.parametrize("B,H,W,Cin,Cout,kh,kw,stride,pad,dil,up", [
+    (2, 1, 300, 64, 128, 1, 7, 1, (0, 3), 1, None),      # Conv1d k=7 (HiFi-GAN conv_pre)
+    (1, 1, 257, 32, 32, 1, 11, 1, (0, 25), 5, None),     # Cin=32: per-lane taps; dilation 5
+    (1, 1, 100, 8, 16, 1, 3, 1, (0, 3), 3, None),        # Cin=8
+    (2, 6, 35, 64, 64, 3, 1, 1, (1, 0), 1, None),        # (3,1) temporal kernel over "frames"
+    (2, 8, 5, 128, 64, 3, 3, 1, (1, 1), 1, (15, 9)),     # upsample to 2n-1 (odd skip size), then 3x3
+    (1, 7, 9, 64, 64, 3, 3, 2, (1, 1), 1, None),         # stride 2 on odd sizes
+])
+def test_conv_ex(ops, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, up):
+    x, w, b = rnd(B, H, W, Cin, seed=1), rnd(Cout, kh, kw, Cin, seed=2, scale=(kh * kw * Cin) ** -0.5), rnd(Cout, seed=3)
+    y = ops.conv_ex(x.to(dev), w.to(dev), bias=b.to(dev), stride=stride, pad=pad, dil=dil, up_size=up)
+    xi = x.float().permute(0, 3, 1, 2)
+    if up is not None:
+        xi = F.interpolate(xi, size=up, mode="nearest")
+    ref = F.conv2d(xi, w.float().permute(0, 3, 1, 2), b.float(), stride=stride, padding=pad, dilation=dil).permute(0, 2, 3, 1)
+    close(y, ref, 2e-2, 1e-2, "conv_ex", rel_to_std=True)
+
+
+def test_conv_ex_fused_act_and_res(ops, dev):
+    x, w, b, r = rnd(1, 1, 90, 32, seed=1), rnd(32, 1, 3, 32, seed=2, scale=0.1), rnd(32, seed=3), rnd(1, 1, 90, 32, seed=4)
+    y = ops.conv_ex(x.to(dev), w.to(dev), bias=b.to(dev), pad=(0, 1), act="leaky_relu", act_param=0.1)
+    ref = F.leaky_relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=(0, 1)), 0.1).permute(0, 2, 3, 1)
+    close(y, ref, 2e-2, 1e-2, "conv+lrelu", rel_to_std=True)
+    y = ops.conv_ex(x.to(dev), w.to(dev), bias=b.to(dev), pad=(0, 1), res=r.to(dev), act="tanh")
+    ref = torch.tanh(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=(0, 1))).permute(0, 2, 3, 1) + r.float()
+    close(y, ref, 2e-2, 1e-2, "conv+tanh+res", rel_to_std=True)
+
+
+@pytest.mark.parametrize("L,Cin,Cout,k,stride", [(50, 64, 32, 16, 5), (33, 32, 16, 16, 4), (40, 16, 8, 8, 2), (20, 8, 4, 4, 2)])
+def test_conv_transpose1d(ops, dev, L, Cin, Cout, k, stride):
+    B, pad = 2, (k - stride) // 2
+    x, w, b = rnd(B, L, Cin, seed=1), rnd(Cin, Cout, k, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3)
+    taps = w.permute(2, 1, 0).reshape(k * Cout, Cin).contiguous()
+    y = ops.conv_transpose1d(x.to(dev), taps.to(dev), b.to(dev), k, stride, pad)
+    ref = F.conv_transpose1d(x.float().transpose(1, 2), w.float(), b.float(), stride=stride, padding=pad).transpose(1, 2)
+    close(y, ref, 2e-2, 1e-2, "conv_transpose1d", rel_to_std=True)
+
+
+def test_act_kinds_add_scaled_l2norm(ops, dev):
+    x, y = rnd(3, 264, seed=1, scale=2.0), rnd(3, 264, seed=2)
+    xf = x.float()
+    for kind, fn in (("leaky_relu", lambda t: F.leaky_relu(t, 0.1)), ("relu", F.relu), ("tanh", torch.tanh), ("silu", F.silu)):
+        close(ops.act(x.to(dev), kind, 0.1), fn(xf), 1e-2, 1e-2, kind)
+    close(ops.add_scaled(x.to(dev), y.to(dev), 1 / 3), (xf + y.float()) / 3, 1e-2, 1e-2, "add_scaled")
+    close(ops.l2_normalize(x.to(dev)), F.normalize(xf, dim=-1), 2e-3, 1e-2, "l2_normalize")
+    z = torch.zeros(2, 16, dtype=BF)
+    assert torch.equal(ops.l2_normalize(z.to(dev)).cpu(), z), "zero rows stay zero (eps clamp)"
+
+
+def test_conv_small_cout_8(ops, dev):
+    x, w, b = rnd(2, 9, 5, 64, seed=1), rnd(8, 3, 3, 64, seed=2, scale=0.05), rnd(8, seed=3)
+    y = ops.conv2d_small_cout(x.to(dev), w.to(dev), b.to(dev))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
+    close(y, ref, 2e-2, 1e-2, "conv_small_cout(8)", rel_to_std=True)

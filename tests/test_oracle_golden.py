@@ -230,3 +230,56 @@ def test_clip_oracle_matches_transformers_tiny():
         ref = model(input_ids=ids).last_hidden_state
     got = clip_text_forward(c, w, ids)
     assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4), float((got - ref).abs().max())
+
+
+# ------------------------------------------------------------------------------------------ AudioLDM side networks
+def _load_audio(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    return z, {n: torch.from_numpy(z[f"w{i}"]) for i, n in enumerate(z["names"])}
+
+
+def test_clap_text_oracle_matches_transformers_vectors():
+    """oracle/audio.py vs ClapTextModelWithProjection outputs (tests/golden/make_golden_audio.py), incl. padded rows"""
+    from oracle.audio import ClapTextCfg, clap_position_ids, clap_text_embeds
+    z, w = _load_audio("clap_text_ref.npz")
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    got = clap_text_embeds(w, ClapTextCfg.tiny(), ids, mask)
+    assert torch.allclose(got, torch.from_numpy(z["text_embeds"]), atol=1e-5, rtol=1e-5)
+    # a padded row equals the same prompt encoded without padding (what the HIP engine relies on)
+    n = int(mask[1].sum())
+    alone = clap_text_embeds(w, ClapTextCfg.tiny(), ids[1:2, :n], mask[1:2, :n])
+    assert torch.allclose(alone, got[1:2], atol=1e-5)
+    assert clap_position_ids(torch.tensor([[0, 5, 2, 1, 1]]), 1).tolist() == [[2, 3, 4, 1, 1]]
+
+
+def test_hifigan_oracle_matches_transformers_vectors():
+    from oracle.audio import HifiGanCfg, hifigan_forward
+    z, w = _load_audio("hifigan_ref.npz")
+    got = hifigan_forward(w, HifiGanCfg.tiny(), torch.from_numpy(z["mel"]))
+    ref = torch.from_numpy(z["wav"])
+    assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+    # length rule of the transposed convs: L -> (L-1)*r - 2*((k-r)//2) + k per stage
+    L = z["mel"].shape[1]
+    for r, k in zip((5, 4, 2), (16, 16, 8)):
+        L = (L - 1) * r - 2 * ((k - r) // 2) + k
+    assert got.shape[1] == L
+
+
+def test_audio_unet_oracle_shapes_and_upsample_rule():
+    """class-label conditioned UNet form on an odd latent (AudioLDM's 125-row case in miniature)"""
+    import torch.nn.functional as F
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights, unet_param_shapes
+    cfg = UNetCfg.tiny_audio()
+    S = unet_param_shapes(cfg)
+    assert S["class_embedding.weight"] == (cfg.temb_dim, cfg.class_in)
+    assert S["down_blocks.0.resnets.0.time_emb_proj.weight"][1] == 2 * cfg.temb_dim          # class_embeddings_concat
+    assert S["down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (128, 128)   # cross dim = block width
+    u = UNetOracle(cfg, random_unet_weights(cfg, 0))
+    g = torch.Generator().manual_seed(0)
+    x, cl = torch.randn(2, 8, 13, 4, generator=g), torch.randn(2, cfg.class_in, generator=g)
+    y = u.forward(x, torch.tensor(500), None, None, cl)
+    assert y.shape == x.shape and bool(torch.isfinite(y).all())
+    y2 = u.forward(x, torch.tensor(500), None, None, cl * 0.5)
+    assert not torch.allclose(y, y2), "class labels must condition the output"
+    a = torch.randn(1, 3, 32, 5, generator=g)   # nearest to 2n-1 == crop of the exact 2x (what the fused conv addressing assumes)
+    assert torch.equal(F.interpolate(a, size=(63, 9), mode="nearest"), F.interpolate(a, scale_factor=2.0, mode="nearest")[:, :, :63, :9])
