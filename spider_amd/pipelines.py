@@ -27,6 +27,7 @@ from .clip import CLIPTextEngine
 from .registry import registry
 from .schedulers import SCHEDULERS, PNDMScheduler
 from .unet import UNetEngine, denoise
+from .unet3d import UNet3DEngine, video_denoise
 from .vae import VAEDecoderEngine
 from .vocoder import HifiGanEngine
 
@@ -313,3 +314,106 @@ class AudioLDMPipeline:
         if output_type == "np":
             audio = audio.numpy()
         return AudioPipelineOutput(audio) if return_dict else (audio,)
+
+
+class TextToVideoSDPipelineOutput:
+    def __init__(self, frames):
+        self.frames = frames
+
+
+def tensor2vid(video: torch.Tensor) -> List[np.ndarray]:
+    """custom_vd.py:59-74. video [B,3,F,H,W] in [-1,1] -> F uint8 frames [H, B*W, 3] (the batch is tiled horizontally)."""
+    video = (video * 0.5 + 0.5).clamp_(0, 1)
+    i, c, f, h, w = video.shape
+    images = video.permute(2, 3, 0, 4, 1).reshape(f, h, i * w, c)
+    return [(im.cpu().numpy() * 255).astype("uint8") for im in images.unbind(0)]
+
+
+@registry.register_model("vd")
+class TextToVideoSDPipeline(StableDiffusionPipeline):
+    """Text-to-video (zeroscope / modelscope) with the reference's call contract (spider/models/custom_vd.py):
+
+        pipe = TextToVideoSDPipeline.from_pretrained(path, torch_dtype=...).to(device)
+        pipe(prompt=[...] | prompt_embeds=T[B,77,C], height, width, num_frames, num_inference_steps, guidance_scale,
+             negative_prompt, generator, latents, output_type="np"|"pt", return_prompts_only=False) -> .frames
+
+    __call__ :506-716 (denoising loop :664-697), _encode_prompt :223-379 (plain right truncation, unlike custom_sd),
+    prepare_latents :483-503, decode_latents :381-408, tensor2vid :59-74. Numerics on the HIP engines: CLIPTextEngine,
+    UNet3DEngine, VAEDecoderEngine (frames decoded as a batch of images)."""
+
+    def __init__(self, unet: UNet3DEngine, vae: Optional[VAEDecoderEngine], text_encoder: Optional[CLIPTextEngine], tokenizer,
+                 scheduler=None, sample_size: int = 32):
+        from .schedulers import DDIMScheduler
+        super().__init__(unet, vae, text_encoder, tokenizer, scheduler or DDIMScheduler(), sample_size)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
+        from transformers import CLIPTokenizer
+        sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
+        sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"))
+        if sched_cls is None:
+            raise NotImplementedError(f"scheduler {sc.get('_class_name')!r}")
+        sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
+        ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
+        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device),
+                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),       # scaling_factor from the config (:382)
+                   CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
+                   CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 32))
+
+    def _tokenize(self, prompt: List[str]) -> torch.Tensor:
+        tk = self.tokenizer
+        return tk(prompt, padding="max_length", max_length=tk.model_max_length, truncation=True, return_tensors="pt").input_ids
+
+    def prepare_latents(self, batch_size, channels, num_frames, height, width, generator, latents=None):
+        shape = (batch_size, channels, num_frames, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if generator is not None and not isinstance(generator, list) else self.device
+            latents = torch.randn(shape, generator=generator if not isinstance(generator, list) else None, device=gdev,
+                                  dtype=torch.float32).to(self.device)
+        else:
+            latents = latents.to(self.device, torch.float32)
+        return (latents * self.scheduler.init_noise_sigma).contiguous()
+
+    def decode_latents(self, latents) -> torch.Tensor:
+        """[B,4,F,h,w] -> video [B,3,F,8h,8w] fp32 in [-1,1] (custom_vd.py:381-408)."""
+        B, C, F_, h, w = latents.shape
+        flat = latents.permute(0, 2, 1, 3, 4).reshape(B * F_, C, h, w).contiguous()
+        frames = torch.cat([self.vae.decode(flat[i:i + 4], to_image=False) for i in range(0, B * F_, 4)])   # bounded VAE batches
+        return frames.view(B, F_, *frames.shape[1:]).permute(0, 2, 1, 3, 4).float()
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_frames: int = 16, num_inference_steps: int = 50, guidance_scale: float = 9.0, negative_prompt=None,
+                 eta: float = 0.0, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                 output_type: Optional[str] = "np", return_dict: bool = True, callback=None, callback_steps: int = 1,
+                 cross_attention_kwargs=None, return_prompts_only: bool = False):
+        height = height or self.sample_size * self.vae_scale_factor
+        width = width or self.sample_size * self.vae_scale_factor
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0 and not return_prompts_only
+        embeds = self._encode_prompt(prompt, 1, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        if return_prompts_only:
+            return embeds
+        lat = self.prepare_latents(batch_size, self.unet.cfg.in_ch, num_frames, height, width, generator, latents)
+        lat = video_denoise(self.unet, self.scheduler, lat, embeds, guidance_scale, num_inference_steps)
+        video = self.decode_latents(lat)
+        if output_type != "pt":
+            video = tensor2vid(video)
+        return TextToVideoSDPipelineOutput(video) if return_dict else (video,)

@@ -178,6 +178,8 @@ class UNetEngine:
         AudioLDM form: enc=None (attn2 attends to its own input) and class_labels [B2, class_in]."""
         cfg, dv = self.cfg, self.device
         B2 = enc.shape[0] if enc is not None else class_labels.shape[0]
+        frames = getattr(self, "frames", 1)      # UNet3D: every sample of the CFG batch is `frames` images
+        rows = B2 * frames
         n = len(timesteps)
         te = timestep_embedding(torch.as_tensor(timesteps), cfg.block_out[0]).to(dv).to(BF16)          # [n, c0]
         h = ops.gemm(te, self.w["time_embedding.linear_1.weight"], bias=self.w["time_embedding.linear_1.bias"], act="silu")
@@ -204,20 +206,23 @@ class UNetEngine:
         tp = ops.gemm(se, self.tproj_w, bias=self.tproj_b)                     # [n*per, total]
         tp = tp.view(n, per, self.tproj_total)
         if per == 1:
-            tp = tp.expand(n, B2, self.tproj_total)
-        # regroup to [n, concat_r(B2 * C_r)] so each resnet's rowbias block [B2, C_r] is contiguous
-        self.tproj_steps = torch.cat([tp[:, :, o:o + c].reshape(n, B2 * c) for (o, c) in (self.tproj_off[r] for r in self.resnets)], 1).contiguous()
+            tp = tp.expand(n, rows, self.tproj_total)
+        elif frames > 1:
+            tp = tp[:, :, None, :].expand(n, B2, frames, self.tproj_total).reshape(n, rows, self.tproj_total)
+        # regroup to [n, concat_r(rows * C_r)] so each resnet's rowbias block [rows, C_r] is contiguous
+        self.tproj_steps = torch.cat([tp[:, :, o:o + c].reshape(n, rows * c) for (o, c) in (self.tproj_off[r] for r in self.resnets)], 1).contiguous()
         self.self_cross = enc is None
         enc = enc.to(BF16).contiguous() if enc is not None else torch.empty(B2, 0, 0, dtype=BF16, device=dv)
         # Static buffers (the per-step time projections and the cross-attention K/V) persist across calls with the same
         # CFG batch, so the captured hipGraph of one UNet evaluation stays valid from one prompt to the next.
-        if getattr(self, "B2", None) != B2 or getattr(self, "_enc_len", None) != enc.shape[1]:
+        if getattr(self, "B2", None) != B2 or getattr(self, "_enc_len", None) != enc.shape[1] or getattr(self, "_rows", None) != rows:
             self.tproj_cur = torch.empty_like(self.tproj_steps[0])
             self.tproj_view, off = {}, 0
             for r in self.resnets:
                 c = self.tproj_off[r][1]
-                self.tproj_view[r] = self.tproj_cur[off:off + B2 * c].view(B2, c)
-                off += B2 * c
+                self.tproj_view[r] = self.tproj_cur[off:off + rows * c].view(rows, c)
+                off += rows * c
+            self._rows = rows
             self.kv = {} if self.self_cross else {
                 l: torch.empty(B2, enc.shape[1], self.w[l + ".attn2.kv"].shape[0], dtype=BF16, device=dv) for l in self.cross_layers}
             self._graph = None
@@ -246,6 +251,17 @@ class UNetEngine:
         qkv = ops.gemm(y, self.w[b + ".attn1.qkv"])
         return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
 
+    def _cross_attn(self, b, y, heads):
+        """attn2 of a BasicTransformerBlock: K/V of the text tokens were projected in prepare(); with
+        encoder_hidden_states=None (AudioLDM) it is a second self-attention."""
+        C = y.shape[-1]
+        if self.self_cross:
+            qkv = ops.gemm(y, self.w[b + ".attn2.qkv"])
+            return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+        q = ops.gemm(y, self.w[b + ".attn2.to_q.weight"])
+        kv = self.kv[b]
+        return ops.attention(q, kv[..., :C], kv[..., C:], heads)
+
     def _transformer(self, n, x, heads, depth):
         w = self.w
         B, H, W_, C = x.shape
@@ -261,13 +277,7 @@ class UNetEngine:
                 o = self._self_attn(b, y, heads)
             h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
             y = ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
-            if self.self_cross:
-                qkv = ops.gemm(y, w[b + ".attn2.qkv"])
-                o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
-            else:
-                q = ops.gemm(y, w[b + ".attn2.to_q.weight"])
-                kv = self.kv[b]
-                o = ops.attention(q, kv[..., :C], kv[..., C:], heads)
+            o = self._cross_attn(b, y, heads)
             h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
             g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU

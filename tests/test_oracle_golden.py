@@ -283,3 +283,40 @@ def test_audio_unet_oracle_shapes_and_upsample_rule():
     assert not torch.allclose(y, y2), "class labels must condition the output"
     a = torch.randn(1, 3, 32, 5, generator=g)   # nearest to 2n-1 == crop of the exact 2x (what the fused conv addressing assumes)
     assert torch.equal(F.interpolate(a, size=(63, 9), mode="nearest"), F.interpolate(a, scale_factor=2.0, mode="nearest")[:, :, :63, :9])
+
+
+def test_unet3d_oracle_structure_and_loop_reshapes():
+    """UNet3D restatement: parameter count of the published checkpoint shape, temporal mixing, and the equivalence the HIP
+    path relies on -- keeping latents as [B*F,C,h,w] for the whole loop == the reference's per-step reshapes
+    (custom_vd.py:684-692)."""
+    import math
+    from oracle.unet import DDIMOracle
+    from oracle.unet3d import UNet3DCfg, UNet3DOracle, random_unet3d_weights, tensor2vid, unet3d_param_shapes, video_denoise_loop
+    n = sum(math.prod(s) for s in unet3d_param_shapes(UNet3DCfg.zeroscope()).values())
+    assert abs(n / 1e9 - 1.411) < 0.01, n      # the "1.7b" text-to-video checkpoint: 1.41 B UNet parameters
+    cfg = UNet3DCfg.tiny()
+    u = UNet3DOracle(cfg, random_unet3d_weights(cfg, 0))
+    g = torch.Generator().manual_seed(0)
+    x, enc = torch.randn(2, 4, 3, 8, 12, generator=g), torch.randn(2, 77, cfg.cross_dim, generator=g)
+    y = u.forward(x, torch.tensor(500), enc)
+    assert y.shape == x.shape and bool(torch.isfinite(y).all())
+    x2 = x.clone(); x2[:, :, 2] += 1.0                      # perturb the LAST frame only
+    y2 = u.forward(x2, torch.tensor(500), enc)
+    assert not torch.allclose(y[:, :, 0], y2[:, :, 0], atol=1e-4), "temporal layers must mix information across frames"
+    # frames-as-batch loop == reshaping loop
+    lat0 = torch.randn(1, 4, 3, 8, 12, generator=g)
+    enc2 = torch.randn(2, 77, cfg.cross_dim, generator=g)
+    ref = video_denoise_loop(u, DDIMOracle(), lat0.clone(), enc2, 9.0, 2)
+    sched = DDIMOracle(); ts = sched.set_timesteps(2)
+    lat = lat0.permute(0, 2, 1, 3, 4).reshape(3, 4, 8, 12) * sched.init_noise_sigma
+    for t in ts:
+        l5 = lat.view(1, 3, 4, 8, 12).permute(0, 2, 1, 3, 4)
+        e = u.forward(torch.cat([l5] * 2), t, enc2)
+        eu, ec = e.chunk(2)
+        eps = (eu + 9.0 * (ec - eu)).permute(0, 2, 1, 3, 4).reshape(3, 4, 8, 12)
+        lat = sched.step(eps, t, lat)
+    assert torch.allclose(lat.view(1, 3, 4, 8, 12).permute(0, 2, 1, 3, 4), ref, atol=1e-5)
+    # tensor2vid: batch tiled horizontally, uint8
+    v = torch.zeros(2, 3, 2, 4, 5); v[1] = 1.0
+    fr = tensor2vid(v)
+    assert len(fr) == 2 and fr[0].shape == (4, 10, 3) and fr[0][:, :5].max() == 127 and fr[0][:, 5:].min() == 255
