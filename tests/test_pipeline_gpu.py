@@ -74,3 +74,24 @@ def test_spider_decoder_image_path(dev):
     dec2 = SpiderDecoder(diffusion_modules={}, pipelines=dict(IMAGE=pipe), get_prompt_embed_for_diffusion=True)
     a, p2, _ = dec2.generate({"llm_text_all": ["<IMAGE>a red car</IMAGE>"]}, *routing.new_outputs())
     assert len(p2["IMAGE"]) == 1
+
+
+def test_spider_decoder_audio_and_video_paths(dev):
+    """routing -> decode_audio / decode_video with the reference's defaults (spider_decoder.py:122,145): 40 steps,
+    5.0 s of audio, 16 frames; tiny engines, real HIP pipelines (registry names 'ad' / 'vd')."""
+    from helpers import tiny_audio_pipe, tiny_video_pipe
+    from spider_amd import routing
+    from spider_amd.registry import registry
+    from spider_amd.pipelines import AudioLDMPipeline, TextToVideoSDPipeline
+    from spider_amd.spider_decoder import SpiderDecoder
+    assert registry.get_model_class("ad") is AudioLDMPipeline and registry.get_model_class("vd") is TextToVideoSDPipeline
+    dec = SpiderDecoder(diffusion_modules={}, pipelines=dict(AUDIO=tiny_audio_pipe(dev), VIDEO=tiny_video_pipe(dev)))
+    txt = "Here you go. <AUDIO>rain on a tin roof</AUDIO> and <VIDEO>waves at sunset</VIDEO>"
+    a, p, pt = dec.generate({"llm_text_all": [txt]}, *routing.new_outputs())
+    assert pt["AUDIO"] == ["rain on a tin roof"] and pt["VIDEO"] == ["waves at sunset"]
+    assert len(p["AUDIO"]) == 1 and p["AUDIO"][0].shape == (80000,) and np.isfinite(p["AUDIO"][0]).all()
+    assert len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
+    # prompt-embeds control path (spider_decoder.py:126-135, :149-158)
+    dec2 = SpiderDecoder(diffusion_modules={}, pipelines=dict(AUDIO=tiny_audio_pipe(dev)), get_prompt_embed_for_diffusion=True)
+    _, p2, _ = dec2.generate({"llm_text_all": ["<AUDIO>rain on a tin roof</AUDIO>"]}, *routing.new_outputs())
+    assert p2["AUDIO"][0].shape == (80000,)
