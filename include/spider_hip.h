@@ -131,6 +131,14 @@ int spider_add_bf16(const void* a, const void* b, void* y, long n, void* stream)
 int spider_act_ex_bf16(const void* x, void* y, long n, int act, float param, void* stream);
 /* y = (a + b) * scale  (HiFi-GAN: mean of the residual-block branches) */
 int spider_add_scaled_bf16(const void* a, const void* b, void* y, long n, float scale, void* stream);
+/* y = alpha*a + beta*b: the 0.1 / 0.9 blend of projected LLM states with text-encoder embeddings (spider.py:420,432,444) */
+int spider_axpby_bf16(const void* a, const void* b, void* y, long n, float alpha, float beta, void* stream);
+/* TextFcLayerMoE router input: mean over tokens, x [B,T,C] -> [B,C] (spider/models/layers.py:254) */
+int spider_mean_tokens_bf16(const void* x, void* y, int B, int T, int C, void* stream);
+/* TextFcLayerMoE mixing: r = sigmoid(logits[b,:E]) / sum, y[b,...] = sum_e r[e] * x_e[b,...]; host_xs is a HOST array of E
+ * device pointers [B, per_batch]; logits rows are ld wide (layers.py:255-267) */
+int spider_moe_combine_bf16(const void* const* host_xs, int E, const void* logits, int ld, void* y, int B, long per_batch,
+                            void* stream);
 /* ConvTranspose1d = per-tap GEMM (spider_gemm_bf16 with fp32 output, cols [B,L_in,k,Cout]) + this overlap-add:
  * y[b,t,:] = bias + sum_{i*stride - pad + j == t} cols[b,i,j,:]; L_out = (L_in-1)*stride - 2*pad + k
  * (HiFi-GAN upsampler, SpeechT5HifiGan called from custom_ad.py:293-300). */

@@ -414,6 +414,57 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(const bf16_t* __restric
     }
 }
 
+// y = bf16(alpha * a + beta * b) elementwise
+__global__ __launch_bounds__(256) void axpby_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                    bf16_t* __restrict__ y, size_t nvec, float alpha, float beta) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+        const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
+        const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
+        const uint32_t pw[4] = {p.x, p.y, p.z, p.w}, qw[4] = {q.x, q.y, q.z, q.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(alpha * bf16lo_to_f32(pw[j]) + beta * bf16lo_to_f32(qw[j]),
+                               alpha * bf16hi_to_f32(pw[j]) + beta * bf16hi_to_f32(qw[j]));
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
+    }
+}
+
+// y[b, c] = mean over t of x[b, t, c]   (TextFcLayerMoE router input, layers.py:254)
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int T, int C) {
+    const size_t total = (size_t)B * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const size_t b = idx / C;
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += bf16_to_f32(x[(b * T + t) * C + c]);
+        y[idx] = f32_to_bf16(s / (float)T);
+    }
+}
+
+// TextFcLayerMoE mixing (layers.py:255-267): r = sigmoid(logits[b, :]) / sum, out[b, t, :] = sum_e r[e] * x_e[b, t, :]
+struct MoeCombine {
+    const bf16_t* x[8];
+    int E;
+};
+__global__ __launch_bounds__(256) void moe_combine_kernel(MoeCombine mc, const bf16_t* __restrict__ logits, int ld, bf16_t* __restrict__ y,
+                                                          int B, size_t per_batch) {
+    const size_t total = (size_t)B * per_batch;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t b = idx / per_batch;
+        float r[8], rs = 0.f;
+        for (int e = 0; e < mc.E; ++e) {
+            r[e] = 1.f / (1.f + __expf(-bf16_to_f32(logits[b * ld + e])));
+            rs += r[e];
+        }
+        float acc = 0.f;
+        for (int e = 0; e < mc.E; ++e) acc += bf16_to_f32(f32_to_bf16(bf16_to_f32(mc.x[e][idx]) * bf16_to_f32(f32_to_bf16(r[e] / rs))));
+        y[idx] = f32_to_bf16(acc);
+    }
+}
+
 // ConvTranspose1d overlap-add (see spider_col2im1d_f32_bf16): one thread per (b, t, 4 output channels)
 __global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__ cols, const bf16_t* __restrict__ bias,
                                                        bf16_t* __restrict__ y, int B, int L_in, int L_out, int k, int stride,
@@ -752,6 +803,34 @@ int spider_add_scaled_bf16(const void* a, const void* b, void* y, long n, float 
     SPIDER_CHECK(n > 0 && n % 8 == 0, "add_scaled: n must be a multiple of 8");
     add_scaled_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
                                                                                (size_t)n / 8, scale);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_axpby_bf16(const void* a, const void* b, void* y, long n, float alpha, float beta, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0, "axpby: n must be a multiple of 8");
+    axpby_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+                                                                          (size_t)n / 8, alpha, beta);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_mean_tokens_bf16(const void* x, void* y, int B, int T, int C, void* stream) {
+    SPIDER_CHECK(B > 0 && T > 0 && C > 0, "mean_tokens: bad shape");
+    mean_tokens_kernel<<<grid_for((size_t)B * C), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, T, C);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// host_xs: HOST array of E device pointers, each [B, per_batch] bf16; logits [B, ld >= E] bf16 (router outputs before the sigmoid)
+int spider_moe_combine_bf16(const void* const* host_xs, int E, const void* logits, int ld, void* y, int B, long per_batch,
+                            void* stream) {
+    SPIDER_CHECK(E >= 1 && E <= 8 && ld >= E && B > 0 && per_batch > 0, "moe_combine: 1..8 experts, ld >= E");
+    MoeCombine mc{};
+    mc.E = E;
+    for (int e = 0; e < E; ++e) mc.x[e] = (const bf16_t*)host_xs[e];
+    moe_combine_kernel<<<grid_for((size_t)B * per_batch), 256, 0, (hipStream_t)stream>>>(mc, (const bf16_t*)logits, ld, (bf16_t*)y, B,
+                                                                                        (size_t)per_batch);
     SPIDER_LAUNCH_OK();
     return 0;
 }

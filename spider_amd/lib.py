@@ -51,6 +51,9 @@ SIGNATURES = {
     "spider_add_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
     "spider_act_ex_bf16": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "spider_add_scaled_bf16": (_i, [_vp, _vp, _vp, _l, _f, _vp]),
+    "spider_axpby_bf16": (_i, [_vp, _vp, _vp, _l, _f, _f, _vp]),
+    "spider_mean_tokens_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "spider_moe_combine_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _l, _vp]),
     "spider_col2im1d_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_l2_normalize_rows_bf16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "spider_conv2d_small_cin_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -344,6 +344,42 @@ def add_scaled(a, b, scale: float, out=None):
     return out
 
 
+def axpby(a, b, alpha: float, beta: float, out=None):
+    """bf16(alpha * a + beta * b)"""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("spider_axpby_bf16", _p(a), _p(b), _p(out), a.numel(), float(alpha), float(beta), _stream())
+    return out
+
+
+def mean_tokens(x, out=None):
+    """x [B,T,C] bf16 -> [B,C] mean over T"""
+    _chk(x, BF16, "x")
+    B, T, Cn = x.shape
+    if out is None:
+        out = torch.empty(B, Cn, dtype=BF16, device=x.device)
+    _lib.call("spider_mean_tokens_bf16", _p(x), _p(out), B, T, Cn, _stream())
+    return out
+
+
+def moe_combine(xs, logits, out=None):
+    """xs: list of E tensors [B, ...] bf16; logits [B, ld >= E] bf16 (first E columns used) -> sum_e r_e * xs[e] with
+    r = sigmoid(logits) / sum(sigmoid(logits))."""
+    for t in xs:
+        _chk(t, BF16, "expert output")
+    _chk(logits, BF16, "logits")
+    B, ld = logits.shape
+    E = len(xs)
+    assert ld >= E and all(t.shape == xs[0].shape for t in xs) and xs[0].shape[0] == B
+    if out is None:
+        out = torch.empty_like(xs[0])
+    ptrs = (C.c_void_p * E)(*[t.data_ptr() for t in xs])
+    _lib.call("spider_moe_combine_bf16", ptrs, E, _p(logits), ld, _p(out), B, xs[0].numel() // B, _stream())
+    return out
+
+
 def l2_normalize(x, eps: float = 1e-12, out=None):
     """rows of x [..., n] divided by max(L2 norm, eps) (torch.nn.functional.normalize)."""
     _chk(x, BF16, "x")

@@ -343,6 +343,69 @@ def gen_story():
     print("story fixtures:", len(out), "arrays; final cur_step", ns["cur_step"])
 
 
+def gen_moe():
+    """Trained-Spider output side: the reference's own TextFcLayerMoE / Mlp class bodies (spider/models/layers.py) and
+    Spider.preparing_output_embeds_infer (spider/models/spider.py:1413-1463) executed here on seeded inputs."""
+    from torch import nn
+    from oracle.moe_proj import random_moe_weights
+    ns = {"torch": torch, "nn": nn}
+    extract_defs(f"{REF}/spider/models/layers.py", ["Mlp", "TextFcLayerMoE"], ns)
+    in_dim = 64
+    mods = {"IMAGE": dict(alignment_output_tokens=5, alignment_output_dim=64), "AUDIO": dict(alignment_output_tokens=1, alignment_output_dim=32)}
+    m = ns["TextFcLayerMoE"](in_dim, mods, mode="moe_transformer", reconstruct_loss=False, device="cpu").eval()
+    w = random_moe_weights(in_dim, mods, seed=31)
+    missing, unexpected = m.load_state_dict(w, strict=True)
+    g = torch.Generator().manual_seed(32)
+    out = dict(in_dim=np.array(in_dim), seed=np.array(31), mods=json.dumps(mods))
+    with torch.no_grad():
+        # batch 1 only: `x_expert * routing_weights[:, :, expert]` (layers.py:265) broadcasts [B,T,512] with [B,1], which
+        # is only well-formed for B == 1 -- the reference decodes one caption at a time (spider.py:1536-1541)
+        for tag, (B, T, mod) in {"a": (1, 1, "IMAGE"), "b": (1, 7, "IMAGE"), "c": (1, 2, "AUDIO")}.items():
+            x = torch.randn(B, T, in_dim, generator=g).bfloat16().float()
+            out[f"{tag}_x"] = x.numpy(); out[f"{tag}_mod"] = np.array(mod); out[f"{tag}_y"] = m(x, modality=mod).numpy()
+
+    # ---- preparing_output_embeds_infer with a stub `self`
+    ns2 = {"torch": torch}
+    extract_defs(f"{REF}/spider/models/spider.py", ["preparing_output_embeds_infer"], ns2)
+    fn = ns2["preparing_output_embeds_infer"]
+    H = 8
+    BEG, END = {"IMAGE": 90, "AUDIO": 92}, {"IMAGE": 91, "AUDIO": 93}
+
+    class Tok:
+        def __call__(self, text, return_tensors="pt", add_special_tokens=False):
+            mod = text.strip("</>")
+            ids = torch.tensor([[END[mod] if text.startswith("</") else BEG[mod]]])
+            class R:
+                input_ids = ids
+                def to(self, d): return self
+            return R()
+
+    class Self:
+        device = "cpu"
+        llama_tokenizer = Tok()
+        using_lora = False
+        output_alignment_modules = {"IMAGE": {"alignment_layer": [-1, 2]}, "AUDIO": {"alignment_layer": [-1]}}
+        modality_tokens = {"IMAGE": 1, "AUDIO": 2}
+        def embed_tokens(self, ids, using_lora=False):
+            return ids.float().unsqueeze(-1).expand(*ids.shape, H) * 0.5
+    # generated ids (sequences[0]); [1:] is what the function scans
+    seq = [1, 7, 8, 90, 11, 12, 13, 50, 91, 9, 92, 21, 22, 60, 61, 93, 90, 31, 51, 91, 2]
+    L = 4
+    hs = tuple(tuple(torch.full((1, 1, H), float(step * 10 + layer)) for layer in range(L)) for step in range(len(seq)))
+    class Outputs:
+        sequences = torch.tensor([seq])
+        hidden_states = hs
+    cases = []
+    for mod, mi in (("IMAGE", 0), ("IMAGE", 1), ("AUDIO", 0)):
+        r = fn(Self(), {"TaskPrompt": [f"[{mod}]"]}, Outputs(), modality=mod, targets=None, modality_i=mi)
+        cases.append(dict(modality=mod, modality_i=mi, hidden=[t.tolist() for t in r[1]], inputs=[t.tolist() for t in r[2]],
+                          hidden_text=[t.tolist() for t in r[3]], inputs_text=[t.tolist() for t in r[4]]))
+    out["capture"] = json.dumps(dict(seq=seq, H=H, L=L, begin=BEG, end=END, alignment_layer=Self.output_alignment_modules,
+                                     modality_tokens=Self.modality_tokens, cases=cases))
+    np.savez_compressed(f"{OUT}/moe_proj_ref.npz", **out)
+    print("moe_proj_ref.npz", {k: v.shape for k, v in out.items() if k.endswith("_y")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     gen_llama()

@@ -320,3 +320,66 @@ def test_unet3d_oracle_structure_and_loop_reshapes():
     v = torch.zeros(2, 3, 2, 4, 5); v[1] = 1.0
     fr = tensor2vid(v)
     assert len(fr) == 2 and fr[0].shape == (4, 10, 3) and fr[0][:, :5].max() == 127 and fr[0][:, 5:].min() == 255
+
+
+# ------------------------------------------------------------------------------------------ trained-Spider output side (N3)
+def _moe_golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "moe_proj_ref.npz"))
+    return z, json.loads(str(z["mods"])), json.loads(str(z["capture"]))
+
+
+def test_moe_projector_oracle_matches_reference():
+    """oracle/moe_proj.py vs the reference's own TextFcLayerMoE (executed by tests/golden/make_golden.py::gen_moe)"""
+    from oracle.moe_proj import moe_forward, moe_param_shapes, random_moe_weights
+    z, mods, _ = _moe_golden()
+    w = random_moe_weights(int(z["in_dim"]), mods, int(z["seed"]))
+    assert sum(v.numel() for v in w.values()) > 80e6 and set(w) == set(moe_param_shapes(int(z["in_dim"]), mods))
+    for t in "abc":
+        y = moe_forward(w, torch.from_numpy(z[f"{t}_x"]), str(z[f"{t}_mod"]))
+        assert torch.allclose(y, torch.from_numpy(z[f"{t}_y"]), atol=2e-5, rtol=1e-4), t
+
+
+class _FakeLLM:
+    device = torch.device("cpu")
+
+    def embed_tokens(self, ids):
+        return ids.float().unsqueeze(-1).expand(*ids.shape, 8) * 0.5
+
+
+class _SignalTok:
+    pad_token_id, bos_token_id = 0, 1
+
+    def __init__(self, begin, end):
+        self.begin, self.end = begin, end
+
+    def __call__(self, text, return_tensors="pt", add_special_tokens=False):
+        mod = text.strip("</>")
+        class R:
+            input_ids = torch.tensor([[self.end[mod] if text.startswith("</") else self.begin[mod]]])
+        return R()
+
+
+def test_signal_token_capture_matches_reference():
+    """product TrainedSpider.preparing_output_embeds_infer and the oracle's span arithmetic vs the reference's function run on
+    a stub model (spider.py:1413-1463)"""
+    from oracle.moe_proj import capture_spans
+    from spider_amd.spider_trained import TrainedSpider
+    _, _, cap = _moe_golden()
+    seq, H, L = cap["seq"], cap["H"], cap["L"]
+    hs = tuple(tuple(torch.full((1, 1, H), float(step * 10 + layer)) for layer in range(L)) for step in range(len(seq)))
+    class Outputs:
+        sequences = torch.tensor([seq])
+        hidden_states = hs
+    ts = TrainedSpider(_FakeLLM(), _SignalTok(cap["begin"], cap["end"]), [], cap["alignment_layer"], cap["modality_tokens"])
+    for case in cap["cases"]:
+        mod, mi = case["modality"], case["modality_i"]
+        m, h, i_, ht, it = ts.preparing_output_embeds_infer({"TaskPrompt": [f"[{mod}]"]}, Outputs(), modality=mod, modality_i=mi)
+        assert m == mod
+        for got, ref in ((h, case["hidden"]), (i_, case["inputs"]), (ht, case["hidden_text"]), (it, case["inputs_text"])):
+            assert len(got) == len(ref)
+            for g, r in zip(got, ref):
+                assert torch.equal(g.float(), torch.tensor(r)), (mod, mi)
+        (lo, hi), (tlo, thi) = capture_spans(seq[1:], cap["begin"][mod], cap["end"][mod], cap["modality_tokens"][mod], mi)
+        assert [v[0] for v in case["hidden"][0][0]] == [float(s * 10 + (L - 1)) for s in range(lo, hi)]
+        assert [v[0] for v in case["hidden_text"][0][0]] == [float(s * 10 + (L - 1)) for s in range(tlo, thi)]
+    assert TrainedSpider.split_placeholder("<IMAGE><IMAGE-Placeholder></IMAGE> a dog") == ["<IMAGE>", "<IMAGE-Placeholder>", "</IMAGE> a dog"]

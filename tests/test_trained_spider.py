@@ -1,0 +1,117 @@
+"""GPU: trained-Spider output side on the HIP kernels: TextFcLayerMoE against the vectors
+produced by the reference's own class (tests/golden/moe_proj_ref.npz), and the decode flow of Spider.generate
+(spider/models/spider.py:1526-1621: capture -> project -> 0.1/0.9 blend -> prompt_embeds pipelines).
+Tolerance: the projector chains 3 x (4+4) transformer layers in bf16 -> rel L2 < 3e-2 against the fp32 reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b).norm() / b.norm())
+
+
+def _golden():
+    z = np.load(os.path.join(GOLD, "moe_proj_ref.npz"))
+    return z, json.loads(str(z["mods"]))
+
+
+def test_moe_projector_matches_reference_vectors(dev):
+    from oracle.moe_proj import random_moe_weights
+    from spider_amd.moe_proj import TextFcLayerMoE
+    z, mods = _golden()
+    eng = TextFcLayerMoE(int(z["in_dim"]), mods, device=dev, weights=random_moe_weights(int(z["in_dim"]), mods, int(z["seed"])))
+    for t in "abc":
+        got = eng(torch.from_numpy(z[f"{t}_x"]), modality=str(z[f"{t}_mod"]))
+        ref = torch.from_numpy(z[f"{t}_y"])
+        assert got.shape == ref.shape
+        assert _rel(got, ref) < 3e-2, (t, _rel(got, ref))
+    with pytest.raises(ValueError):
+        eng(torch.zeros(2, 1, int(z["in_dim"])), modality="IMAGE")
+    with pytest.raises(KeyError):
+        eng(torch.zeros(1, 1, int(z["in_dim"])), modality="VIDEO")
+    with pytest.raises(NotImplementedError):
+        TextFcLayerMoE(64, mods, mode="moe_aligner", weights={})
+
+
+def test_moe_combine_axpby_mean_kernels(dev):
+    from spider_amd import ops
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(2, 5, 64, generator=g).bfloat16() for _ in range(3)]
+    lg = torch.randn(2, 4, generator=g).bfloat16()
+    r = torch.sigmoid(lg[:, :3].float()); r = r / r.sum(-1, keepdim=True)
+    ref = sum(x.float() * r[:, e, None, None] for e, x in enumerate(xs))
+    got = ops.moe_combine([x.to(dev) for x in xs], lg.to(dev))
+    assert torch.allclose(got.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+    a, b = torch.randn(3, 64, generator=g).bfloat16(), torch.randn(3, 64, generator=g).bfloat16()
+    assert torch.allclose(ops.axpby(a.to(dev), b.to(dev), 0.1, 0.9).float().cpu(), 0.1 * a.float() + 0.9 * b.float(), atol=2e-2)
+    x = torch.randn(2, 7, 64, generator=g).bfloat16()
+    assert torch.allclose(ops.mean_tokens(x.to(dev)).float().cpu(), x.float().mean(1), atol=1e-2)
+
+
+class _Tok:
+    """signal-token aware stand-in for the LLM tokenizer"""
+    pad_token_id, bos_token_id = 0, 1
+    SIG = {"<IMAGE>": 90, "</IMAGE>": 91, "[IMAGE0]": 94, "[END]": 95, "[INPUT]": 96, "[IMAGE]": 97}
+
+    def __call__(self, text, return_tensors="pt", add_special_tokens=False):
+        ids = [self.SIG[text]] if text in self.SIG else [3 + (sum(map(ord, w)) % 80) for w in text.split()]
+        class R:
+            input_ids = torch.tensor([ids])
+        return R()
+
+    canned = "[OUTPUT]<IMAGE>a red car [IMAGE0]</IMAGE>[END]"
+
+    def decode(self, ids, skip_special_tokens=True):
+        return self.canned
+
+
+def test_trained_spider_decode_flow(dev):
+    """capture -> TextFcLayerMoE -> blend -> prompt_embeds pipeline, against the oracle projector + blend"""
+    from test_pipeline_gpu import _pipe
+    from oracle.moe_proj import blend, moe_forward, random_moe_weights
+    from spider_amd import routing
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    from spider_amd.moe_proj import TextFcLayerMoE
+    from spider_amd.spider_trained import TrainedSpider
+    pipe, _ = _pipe(dev)                                           # tiny SD pipeline, CLIP width 64, 77 tokens
+    cfg = LLMConfig(vocab=128, hidden=64, layers=2, n_q=2, n_kv=1, head_dim=128, inter=128)
+    llm = LlamaEngine.random_init(cfg, dev, max_batch=1, max_len=256)
+    mods = {"IMAGE": dict(alignment_output_tokens=77, alignment_output_dim=64, alignment_layer=[-1])}
+    w = random_moe_weights(64, mods, seed=41)
+    ts = TrainedSpider(llm, _Tok(), [TextFcLayerMoE(64, mods, device=dev, weights=w)], mods, {"IMAGE": 1}, pipelines=dict(IMAGE=pipe))
+    seq = [1, 7, 90, 11, 12, 13, 94, 91, 95]
+    g = torch.Generator().manual_seed(3)
+    hs = tuple(tuple((torch.randn(1, 1, 64, generator=g) * 0.5).bfloat16().to(dev) for _ in range(cfg.layers + 1)) for _ in seq)
+    class Outputs:
+        sequences = torch.tensor([seq])
+        hidden_states = hs
+    samples = {"TaskPrompt": ["[IMAGE]"], "Question": ["draw a red car"]}
+    m, h, i_, ht, it = ts.preparing_output_embeds_infer(samples, Outputs(), modality="IMAGE", modality_i=0)
+    # targets = seq[1:]; </IMAGE> sits at index 6 -> the [IMAGE0] step is index 5, caption span 2..4
+    assert torch.equal(h[0], hs[5][-1]) and ht[0].shape == (1, 3, 64)
+    proj = ts.decode_image(samples, h, i_, ht, it, return_embeds_only=True)
+    x = (h[0].float() + i_[0].float()).cpu()
+    ref = moe_forward(w, x.bfloat16().float(), "IMAGE")
+    assert _rel(proj, ref) < 3e-2
+    answers, predictions, ptext = ts.decode_outputs(samples, Outputs(), *routing.new_outputs())
+    assert answers == ["[OUTPUT]<IMAGE>a red car [IMAGE0]</IMAGE>[END]"] and ptext["IMAGE"] == ["a red car [IMAGE0]"]
+    assert len(predictions["IMAGE"]) == 1 and predictions["IMAGE"][0].size == (64, 64)
+    # the blended prompt embedding the pipeline received == oracle blend of (projected, CLIP embeds)
+    cond = pipe(["a red car [IMAGE0]"], return_prompts_only=True).float().cpu()
+    p, c = torch.broadcast_tensors(proj.float().cpu(), cond)
+    from spider_amd import ops
+    got = ops.axpby(proj, pipe(["a red car [IMAGE0]"], return_prompts_only=True).to(torch.bfloat16).contiguous(), 0.1, 0.9)
+    assert _rel(got, blend(p, c)) < 1e-2
+    # full generate on a random tiny LLM: contract + left padding + stopping; no tags are expected in random text
+    ts.llama_tokenizer.canned = "[OUTPUT] a random reply without signal tags"
+    a2, p2, t2 = ts.generate({"TaskPrompt": ["[IMAGE]"], "Question": ["draw a red car"]}, *routing.new_outputs())
+    assert a2 == ["[OUTPUT] a random reply without signal tags"] and p2["IMAGE"] == [] and t2["IMAGE"] == []
+    with pytest.raises(NotImplementedError):
+        ts.generate({"TaskPrompt": ["[IMAGE]"], "Question": ["<IMAGE><IMAGE-Placeholder></IMAGE> what is this"]}, *routing.new_outputs())
