@@ -371,8 +371,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     const int t128 = ((a.M + 127) / 128) * ((ncols + 127) / 128);
     const int t64 = ((a.M + 63) / 64) * ((ncols + 63) / 64);
     // Measured on MI355X (scripts/bench_gemm.py): K-heavy problems (3x3 convs, down_proj) want 128^2 tiles plus
-    // split-K up to ~768 blocks; everything else with < 384 big tiles is faster on 64^2 tiles (more blocks, all
-    // resident), split only when even those leave CUs idle.
+    // split-K up to ~768 blocks; everything else with < 384 big tiles (or a short K) is faster on 64^2 tiles (more
+    // blocks, all resident), split only when even those leave CUs idle.
     bool small;
     int splits = 1;
     if (nk >= 44 && t128 >= 24) {
@@ -381,7 +381,10 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         if (splits < nk / 32) splits = nk / 32;    // ... and never leave one block with hundreds of K tiles (down_proj)
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
-    } else if (t128 >= 384) {
+    } else if (t128 >= 384 && !(nk <= 10 || (t128 < 768 && nk <= 20))) {
+        // big tiles only pay once K is long enough to amortise their prologue / 64-accumulator epilogue: measured
+        // (scripts/bench_gemm_k.py) 64^2 wins for K <= 640 at every M x N (8192x2560x320: 47.6 vs 66.4 us) and up to
+        // K = 1280 while the 128^2 grid is under ~3 rounds of the chip (2048x5120x960: 41 vs 55 us)
         small = false;
     } else {
         small = true;
