@@ -38,6 +38,7 @@ struct GemmArgs {
     float* ws;              // split-K workspace [splits, M, N] fp32
     int M, N, K, lda, ldc;
     uint32_t a_bytes, w_bytes;   // buffer-descriptor ranges of A and W (< 4 GiB each)
+    uint32_t c_bytes, rb_bytes;  // ranges of C / res ([M, ldc] bf16) and rowbias, for the branch-free epilogue (0: not usable)
     int rows_per_group;
     int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu, 5 leaky-relu(act_param), 6 relu, 7 tanh
     float act_param;
@@ -61,7 +62,12 @@ __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
 }
 
 // bias / rowbias / activation / residual / scale on 4 consecutive columns of one row, then store
+// EPI selects what is compiled in: 0 = bias / rowbias / residual / scale only, 1 = + activation, 2 = GEGLU (kernel-level).
+// One kernel carrying every epilogue was > 50 KB of code (the transcendental bodies inlined per output fragment), i.e.
+// most of the instruction cache two CUs share, for paths the UNet's convs and projections never take.
+template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v[4]) {
+    constexpr bool ACT = EPI == 1 || EPI == 3;
     const int grp = p.rowbias ? m / p.rows_per_group : 0;
     if (n + 3 < p.N) {
         if (p.bias) {
@@ -74,7 +80,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
             v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
         }
-        if (p.act) {
+        if (ACT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(p, v[e]);
         }
@@ -100,7 +106,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             float t = v[e];
             if (p.bias) t += bf16_to_f32(p.bias[n + e]);
             if (p.rowbias) t += bf16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
-            t = apply_act(p, t);
+            if (ACT) t = apply_act(p, t);
             if (p.res) t = bf16_to_f32(f32_to_bf16(t)) + bf16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
             t *= p.out_scale;
             if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
@@ -109,8 +115,58 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
     }
 }
 
-template <int BM, int BN, bool CONV>
+// Lean epilogue of the common case (bf16 output, N % 4 == 0, operands < 2 GiB): operands go through buffer descriptors
+// with 32-bit offsets; rows / columns outside the problem get an all-ones offset (loads return 0, the store is dropped),
+// so there is no divergent control flow and no 64-bit address arithmetic per fragment -- only the scalar
+// "is this operand present" branches. (Reading absent operands through zero-range descriptors instead was measured
+// slower: 48 useless memory instructions per thread.)
+struct EpiRsrc {
+    __amdgpu_buffer_rsrc_t bias, rowbias, res, c;
+};
+
+__device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemmArgs& p) {
+    EpiRsrc r;
+    r.bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
+    r.rowbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.rowbias), 0, p.rowbias ? (int)p.rb_bytes : 0, 0x00020000);
+    r.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, p.res ? (int)p.c_bytes : 0, 0x00020000);
+    r.c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+    return r;
+}
+
+template <bool ACT>
+__device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& r, int m, int n, uint32_t rb_row_byte, float v[4]) {
+    const uint32_t inv = (uint32_t)(((p.M - 1 - m) | (p.N - 1 - n)) >> 31);       // all ones outside the problem
+    const uint32_t off = (((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n) * 2u) | inv;
+    const uint32_t noff = ((uint32_t)n * 2u) | inv;
+    // operand presence is uniform (scalar branches); a missing operand costs nothing, a present one is one 8-byte load
+    if (p.bias) {
+        const u32x2 bq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.bias, noff, 0, 0));
+        v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x); v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+    }
+    if (p.rowbias) {
+        const u32x2 rb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.rowbias, (rb_row_byte + (uint32_t)n * 2u) | inv, 0, 0));
+        v[0] += bf16lo_to_f32(rb.x); v[1] += bf16hi_to_f32(rb.x); v[2] += bf16lo_to_f32(rb.y); v[3] += bf16hi_to_f32(rb.y);
+    }
+    if (ACT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(p, v[e]);
+    }
+    if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
+        const u32x2 rq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.res, off, 0, 0));
+        v[0] = bf16_to_f32(f32_to_bf16(v[0])) + bf16lo_to_f32(rq.x); v[1] = bf16_to_f32(f32_to_bf16(v[1])) + bf16hi_to_f32(rq.x);
+        v[2] = bf16_to_f32(f32_to_bf16(v[2])) + bf16lo_to_f32(rq.y); v[3] = bf16_to_f32(f32_to_bf16(v[3])) + bf16hi_to_f32(rq.y);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+    u32x2 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
+}
+
+template <int BM, int BN, bool CONV, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+    constexpr bool GEGLU = EPI == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
     constexpr int TILE_ELEMS = (BM + BN) * LDS_STRIDE;  // [A tile BM rows | W tile BN rows]
@@ -120,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int ncols = p.geglu ? 2 * p.N : p.N;   // GEGLU: a BN-wide W tile yields BN/2 output columns
+    const int ncols = GEGLU ? 2 * p.N : p.N;   // GEGLU: a BN-wide W tile yields BN/2 output columns
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (ncols + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = bid % tiles_m, tn = bid / tiles_m;  // m fastest: neighbours share the W tile
@@ -160,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     for (int i = 0; i < WC; ++i) {
         int n = n0 + lrow + 32 * i;
         bool ok;
-        if (p.geglu) {
+        if (GEGLU) {
             // each wave column holds BN/4 value rows followed by the BN/4 gate rows of the same output columns, so a
             // lane finds value and gate of one output element in its own accumulators (tiles j and j + NT/2)
             const int rr = lrow + 32 * i, wn_ = rr / (BN / 2), within = rr % (BN / 2);
@@ -276,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 
     // ---- GEGLU epilogue: value tile j and gate tile j + NT/2 of the same lane ----
-    if (p.geglu) {
+    if (GEGLU) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
@@ -309,6 +365,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
+    if (EPI <= 1 && p.splits == 1) {
+        const EpiRsrc er = make_epi_rsrc(p);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            uint32_t rb_row = 0;
+            if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
+            }
+        }
+        return;
+    }
+    if (EPI <= 1) {   // split-K partial sums of the fast instantiations (N % 4 == 0): plain fp32 vector stores
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<f32x4*>(p.ws + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
@@ -323,13 +408,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                 else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
             } else {
-                epilogue_store(p, m, n, v);
+                epilogue_store<EPI>(p, m, n, v);     // EPI 3: ragged N / fp32 output / operands >= 4 GiB
             }
         }
     }
 }
 
 // split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
+template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
     const int n4 = (p.N + 3) / 4;
     const size_t total = (size_t)p.M * n4;
@@ -345,7 +431,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
                 for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[e];
             }
         }
-        epilogue_store(p, m, n, v);
+        epilogue_store<EPI>(p, m, n, v);
     }
 }
 
@@ -353,14 +439,34 @@ template <int BM, int BN>
 void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16_t);
     dim3 grid(tiles, a.splits);
-    if (a.conv) gemm_kernel<BM, BN, true><<<grid, 256, smem, st>>>(a);
-    else gemm_kernel<BM, BN, false><<<grid, 256, smem, st>>>(a);
+    // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    const int epi = a.geglu ? 2 : (!fast_ok ? 3 : (a.act ? 1 : 0));
+    if (a.conv) {
+        if (epi == 3) gemm_kernel<BM, BN, true, 3><<<grid, 256, smem, st>>>(a);
+        else if (epi == 1) gemm_kernel<BM, BN, true, 1><<<grid, 256, smem, st>>>(a);
+        else gemm_kernel<BM, BN, true, 0><<<grid, 256, smem, st>>>(a);
+    } else {
+        if (epi == 3) gemm_kernel<BM, BN, false, 3><<<grid, 256, smem, st>>>(a);
+        else if (epi == 2) gemm_kernel<BM, BN, false, 2><<<grid, 256, smem, st>>>(a);
+        else if (epi == 1) gemm_kernel<BM, BN, false, 1><<<grid, 256, smem, st>>>(a);
+        else gemm_kernel<BM, BN, false, 0><<<grid, 256, smem, st>>>(a);
+    }
 }
 
 // Tile / split-K choice: fill >= ~2 blocks per CU (512) when the problem allows it, keep >= 4 K tiles per split.
 int env_int(const char* name) {
     const char* v = getenv(name);
     return v ? atoi(v) : 0;
+}
+
+// byte ranges of C / res and rowbias for the buffer-descriptor epilogue; 0 disables it (operands >= 2 GiB)
+void set_epilogue_ranges(GemmArgs& a) {
+    const size_t cb = (size_t)(a.M - 1) * a.ldc * 2 + (size_t)a.N * 2;
+    const size_t rb = a.rowbias ? (size_t)((a.M + a.rows_per_group - 1) / a.rows_per_group) * a.N * 2 : 0;
+    const bool ok = cb < ((size_t)1 << 31) && rb < ((size_t)1 << 31);
+    a.c_bytes = ok ? (uint32_t)cb : 0;
+    a.rb_bytes = ok ? (uint32_t)rb : 0;
 }
 
 int launch(GemmArgs a, long ws_bytes, void* stream) {
@@ -381,10 +487,9 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         if (splits < nk / 32) splits = nk / 32;    // ... and never leave one block with hundreds of K tiles (down_proj)
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
-    } else if (t128 >= 384 && !(nk <= 10 || (t128 < 768 && nk <= 20))) {
-        // big tiles only pay once K is long enough to amortise their prologue / 64-accumulator epilogue: measured
-        // (scripts/bench_gemm_k.py) 64^2 wins for K <= 640 at every M x N (8192x2560x320: 47.6 vs 66.4 us) and up to
-        // K = 1280 while the 128^2 grid is under ~3 rounds of the chip (2048x5120x960: 41 vs 55 us)
+    } else if (t128 >= 384) {
+        // (re-measured with the per-epilogue instantiations, scripts/bench_gemm_k.py: once the 128^2 kernel's code fits
+        // the instruction cache it wins for every K >= 320 at these sizes -- 8192x2560x320: 40.8 vs 45.1 us)
         small = false;
     } else {
         small = true;
@@ -411,7 +516,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         const size_t total = (size_t)a.M * ((a.N + 3) / 4);
         size_t g = (total + 255) / 256;
         if (g > 2048) g = 2048;
-        splitk_reduce_kernel<<<(int)g, 256, 0, st>>>(a);
+        if (a.act) splitk_reduce_kernel<1><<<(int)g, 256, 0, st>>>(a);
+        else splitk_reduce_kernel<0><<<(int)g, 256, 0, st>>>(a);
         SPIDER_LAUNCH_OK();
     }
     return 0;
@@ -445,6 +551,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     SPIDER_CHECK((size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), "gemm: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)(M - 1) * lda * 2 + (size_t)K * 2);
     a.w_bytes = (uint32_t)((size_t)N * K * 2);
+    set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
 
@@ -483,6 +590,7 @@ int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* 
     SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
     a.w_bytes = (uint32_t)((size_t)Cout * a.K * 2);
+    set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
 
