@@ -669,6 +669,21 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     const int per = (len_old + nsplit - 1) / nsplit;
     const int t0 = beg + split * per, t1 = min(t_new, t0 + per);
 
+    // cache rows of this lane group, requested first: nothing below depends on them until the score loop
+    const bf16_t* kbase = kc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+    const bf16_t* vbase = vc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
+    auto load_rows = [&](int tb_, u32x4 (&kr)[4], u32x4 (&vr)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(tb_ + 16 * u, t1 - 1);      // clamped rows are loaded but not used
+            kr[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
+            vr[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
+        }
+    };
+    const int tb0 = t0 + wave * 4 + sub;
+    u32x4 kq[4], vq[4];
+    if (tb0 < t1) load_rows(tb0, kq, vq);
+
     const bf16_t* row = qkv + (size_t)b * (n_q + 2 * n_kv) * D;
     const float* c = cs + (size_t)pos[b] * D;
     float cosv[8], sinv[8];
@@ -708,9 +723,6 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
     }
-    const bf16_t* kbase = kc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
-    const bf16_t* vbase = vc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
-
     auto update = [&](const float (&kf)[8], const float (&vf)[8]) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -731,15 +743,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         }
     };
 
-    // 4 cache rows per lane group in flight (K and V): a one-row-per-iteration loop serialises the HBM round trips
-    for (int tb = t0 + wave * 4 + sub; tb < t1; tb += 64) {
-        u32x4 kq[4], vq[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = min(tb + 16 * u, t1 - 1);       // clamped rows are loaded but not used
-            kq[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
-            vq[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
-        }
+    // 4 cache rows per lane group in flight (K and V). The first (at T ~ 1.5k and 32 splits: the only) chunk was requested at
+    // the top of the kernel, before the q loads and RoPE; later chunks are requested one iteration ahead.
+    for (int tb = tb0; tb < t1; tb += 64) {
+        u32x4 kn[4], vn[4];
+        const bool more = tb + 64 < t1;
+        if (more) load_rows(tb + 64, kn, vn);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (tb + 16 * u < t1) {                       // uniform within the 16-lane row group
@@ -752,6 +761,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
                 }
                 update(kf, vf);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { kq[u] = kn[u]; vq[u] = vn[u]; }
         }
     }
     // the current token: last split, wave 0, row sub-group 0 (16 lanes) -- from registers, and appended to the cache

@@ -19,6 +19,7 @@ Decode = 5 weight-streaming launches per layer (+1 tiny split-KV combine), captu
 """
 from __future__ import annotations
 
+import os
 import math
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -259,7 +260,10 @@ class LlamaEngine:
     def _make_state(self, B: int, want_hidden: bool, want_logits: bool) -> dict:
         c, dv = self.cfg, self.device
         nq_d = c.n_q * c.head_dim
-        nsplit = max(1, min(32, 256 // max(1, B * c.n_kv)))
+        # one split-KV block per CU (256): measured on Qwen-7B shapes at T~1.6k: 2.93 / 2.90 / 3.14 ms per token at 32 / 64 / 96 splits
+        nsplit = max(1, min(64, 256 // max(1, B * c.n_kv)))
+        if os.environ.get("SPIDER_ATTN_NSPLIT"):       # tuning aid
+            nsplit = int(os.environ["SPIDER_ATTN_NSPLIT"])
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dv)
         bf = lambda *s: torch.empty(*s, dtype=BF16, device=dv)
         npart = ops.lm_head_nparts(c.vocab)
