@@ -57,6 +57,13 @@ int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w,
 int spider_rope_kv_append_bf16(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out,
                                void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
                                void* stream);
+/* Multimodal RoPE of the Qwen2.5-Omni thinker (transformers apply_multimodal_rotary_pos_emb, reached from
+ * Qwen2_5OmniModel.generate, qwen2.5omni_infer.py:3 / qwen2.5omni_spider_web.py:468): pos3 is [3, B*S]
+ * (temporal, height, width); the first sec_t rotary pairs follow component 0, the next sec_h component 1, the rest
+ * component 2 (mrope_section 16/24/24 at head_dim 128). sec_t = sec_h = 0 degenerates to spider_rope_kv_append_bf16. */
+int spider_rope_kv_append_mrope_bf16(const void* qkv, const int* pos3, const int* slot, const float* cos_sin, void* q_out,
+                                     void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
+                                     int sec_t, int sec_h, void* stream);
 
 /* decode attention, one query token per sequence, GQA, fp32 online softmax, split over the KV length
  * (eager_attention_forward + repeat_kv, modeling_llama3.py:202-237). Valid cache slots per sequence:

@@ -421,10 +421,14 @@ template <int D>
 __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ pos,
                                                       const int* __restrict__ slot, const float* __restrict__ cs,
                                                       bf16_t* __restrict__ q_out, bf16_t* __restrict__ kc,
-                                                      bf16_t* __restrict__ vc, int S, int n_q, int n_kv, int T_max) {
-    const int row = blockIdx.x;
+                                                      bf16_t* __restrict__ vc, int S, int n_q, int n_kv, int T_max,
+                                                      int mrope_s0, int mrope_s1) {
+    // mrope_s1 > 0: multimodal RoPE -- pos is [3, rows] (temporal, height, width) and rotary pair i takes its angle from
+    // component 0 (i < s0), 1 (i < s1) or 2 (transformers apply_multimodal_rotary_pos_emb, mrope_section = [s0, s1-s0, rest])
+    const int row = blockIdx.x, rows = gridDim.x;
     const int b = row / S;
     const int p = pos[row], sl = slot[row];
+    const int p1 = mrope_s1 > 0 ? pos[rows + row] : p, p2 = mrope_s1 > 0 ? pos[2 * rows + row] : p;
     const int nh = n_q + 2 * n_kv;
     const bf16_t* src = qkv + (size_t)row * nh * D;
     const float* c = cs + (size_t)p * D;
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__
         const float x1 = bf16_to_f32(src[h * D + i]);
         const float x2 = bf16_to_f32(src[h * D + HALF + i]);
         if (h < n_q + n_kv) {
-            const float co = c[i], si = c[HALF + i];
+            const float* ci = mrope_s1 > 0 ? cs + (size_t)(i < mrope_s0 ? p : (i < mrope_s1 ? p1 : p2)) * D : c;
+            const float co = ci[i], si = ci[HALF + i];
             const float o1 = bf16_to_f32(f32_to_bf16(x1 * co)) + bf16_to_f32(f32_to_bf16(-x2 * si));
             const float o2 = bf16_to_f32(f32_to_bf16(x2 * co)) + bf16_to_f32(f32_to_bf16(x1 * si));
             if (h < n_q) {
@@ -1097,19 +1102,32 @@ int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w,
     return 0;
 }
 
+// pos3 [3, B*S] (temporal, height, width position of every token); sec_t / sec_h: rotary pairs of the half head dim that
+// follow the temporal / height component, the remaining d/2 - sec_t - sec_h follow the width component (Qwen2.5-Omni:
+// 16 / 24 / 24). Text tokens carry three equal components, for which this is exactly spider_rope_kv_append_bf16.
+int spider_rope_kv_append_mrope_bf16(const void* qkv, const int* pos3, const int* slot, const float* cos_sin, void* q_out,
+                                     void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
+                                     int sec_t, int sec_h, void* stream) {
+    SPIDER_CHECK(B > 0 && S > 0 && n_q > 0 && n_kv > 0 && T_max > 0, "rope_kv_append: bad shape");
+    SPIDER_CHECK(d == 128 || d == 64, "rope_kv_append: head_dim must be 64 or 128");
+    SPIDER_CHECK(sec_t >= 0 && sec_h >= 0 && sec_t + sec_h <= d / 2 && (sec_t + sec_h > 0 || (sec_t == 0 && sec_h == 0)),
+                 "rope_kv_append: mrope sections must fit the half head dim");
+    const int s0 = sec_t, s1 = sec_t + sec_h;    // s1 == 0: plain 1-D RoPE, pos3 is then [B*S]
+    if (d == 128)
+        rope_kv_kernel<128><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos3, slot, cos_sin, (bf16_t*)q_out,
+                                                                    (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max, s0, s1);
+    else
+        rope_kv_kernel<64><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos3, slot, cos_sin, (bf16_t*)q_out,
+                                                                   (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max, s0, s1);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
 int spider_rope_kv_append_bf16(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out,
                                void* k_cache, void* v_cache, int B, int S, int n_q, int n_kv, int d, int T_max,
                                void* stream) {
-    SPIDER_CHECK(B > 0 && S > 0 && n_q > 0 && n_kv > 0 && T_max > 0, "rope_kv_append: bad shape");
-    SPIDER_CHECK(d == 128 || d == 64, "rope_kv_append: head_dim must be 64 or 128");
-    if (d == 128)
-        rope_kv_kernel<128><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos, slot, cos_sin, (bf16_t*)q_out,
-                                                                    (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max);
-    else
-        rope_kv_kernel<64><<<B * S, 256, 0, (hipStream_t)stream>>>((const bf16_t*)qkv, pos, slot, cos_sin, (bf16_t*)q_out,
-                                                                   (bf16_t*)k_cache, (bf16_t*)v_cache, S, n_q, n_kv, T_max);
-    SPIDER_LAUNCH_OK();
-    return 0;
+    return spider_rope_kv_append_mrope_bf16(qkv, pos, slot, cos_sin, q_out, k_cache, v_cache, B, S, n_q, n_kv, d, T_max, 0, 0,
+                                            stream);
 }
 
 #define ATTN_DEC_LAUNCH(G_)                                                                                     \

@@ -46,6 +46,7 @@ class LLMConfig:
     qkv_bias: bool = False
     max_pos: int = 8192
     tie_embeddings: bool = False
+    mrope_section: Optional[tuple] = None   # Qwen2.5-Omni thinker: (16, 24, 24) rotary pairs follow (t, h, w) positions
 
     @staticmethod
     def llama3_8b():   # DeepSeek-R1-Distill-Llama-8B (r1_llama3_8B_infer.py:4, demo/inference_api.py:92-95)
@@ -55,7 +56,7 @@ class LLMConfig:
 
     @staticmethod
     def qwen25_7b():   # Qwen2.5-Omni-7B thinker text decoder (qwen2.5omni_spider_web.py:368-384)
-        return LLMConfig(3584, 28, 28, 4, 128, 18944, 152064, 1000000.0, None, 1e-6, True, 8192)
+        return LLMConfig(3584, 28, 28, 4, 128, 18944, 152064, 1000000.0, None, 1e-6, True, 8192, False, (16, 24, 24))
 
     @staticmethod
     def from_hf_dict(c: dict) -> "LLMConfig":
@@ -67,7 +68,8 @@ class LLMConfig:
                          c["vocab_size"], float(c.get("rope_theta", 10000.0)), c.get("rope_scaling"),
                          float(c.get("rms_norm_eps", 1e-6)),
                          bool(c.get("attention_bias", c.get("model_type", "").startswith("qwen"))),
-                         int(c.get("max_position_embeddings", 8192)), bool(c.get("tie_word_embeddings", False)))
+                         int(c.get("max_position_embeddings", 8192)), bool(c.get("tie_word_embeddings", False)),
+                         tuple((c.get("rope_scaling") or {}).get("mrope_section") or ()) or None)
 
 
 def rope_inv_freq(cfg: LLMConfig) -> torch.Tensor:
@@ -198,16 +200,18 @@ class LlamaEngine:
 
     # ------------------------------------------------------------------ prefill
     def _prefill(self, h: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, kv_beg: Optional[torch.Tensor],
-                 B: int, S: int, hidden_out: Optional[list]):
-        """h [B*S, H] bf16; writes KV slots, returns the final residual stream [B*S, H]."""
+                 B: int, S: int, hidden_out: Optional[list], mrope: bool = False):
+        """h [B*S, H] bf16; pos [B*S] (or [3, B*S] with mrope); writes KV slots, returns the final residual stream [B*S, H]."""
         c = self.cfg
+        sec = c.mrope_section if mrope else None
         if hidden_out is not None:
             hidden_out.append(h.view(B, S, -1).clone())
         for l, lw in enumerate(self.layers):
             x = ops.rmsnorm(h, lw["ln1"], c.eps)
             qkv = ops.gemm(x, lw["w_qkv"], bias=lw["b_qkv"])
             q = torch.empty(B, S, c.n_q, c.head_dim, dtype=BF16, device=self.device)
-            ops.rope_kv_append(qkv, pos, slot, self.cos_sin, q, self.k_cache[l], self.v_cache[l], B, S, c.n_q, c.n_kv, c.head_dim)
+            ops.rope_kv_append(qkv, pos, slot, self.cos_sin, q, self.k_cache[l], self.v_cache[l], B, S, c.n_q, c.n_kv, c.head_dim,
+                               mrope_section=sec)
             a = ops.attention_cache(q, self.k_cache[l], self.v_cache[l], Lk=S, causal=True, kv_off=0, kv_beg=kv_beg)
             h = ops.gemm(a.view(B * S, -1), lw["w_o"], res=h)
             x = ops.rmsnorm(h, lw["ln2"], c.eps)
@@ -287,10 +291,14 @@ class LlamaEngine:
                  stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None,
                  output_hidden_states: bool = False, return_dict_in_generate: bool = False,
                  num_beams: int = 1, do_sample: bool = False, use_cache: bool = True, output_attentions: bool = False,
-                 use_graph: bool = True, sync_every: int = 1, return_logits: bool = False, **unused):
+                 use_graph: bool = True, sync_every: int = 1, return_logits: bool = False,
+                 position_ids: Optional[torch.Tensor] = None, **unused):
         """Greedy decode. Left-padded batches are described by attention_mask (0 = pad), as
         prepare_generation_embedding does (spider.py:1658-1661). `sync_every` > 1 checks the stop
-        conditions only every N tokens (one device->host copy per check instead of per token)."""
+        conditions only every N tokens (one device->host copy per check instead of per token).
+        position_ids [3, B, S]: multimodal (t, h, w) rotary positions of the prompt (Qwen2.5-Omni thinker with image / audio
+        embeddings spliced into inputs_embeds; cfg.mrope_section required). Generated tokens continue at
+        max(position_ids) + 1 on all three components, as transformers' rope_deltas bookkeeping does."""
         if num_beams != 1 or do_sample:
             raise NotImplementedError("the reference path is greedy: num_beams=1, do_sample=False (spider.py:1471-1477)")
         c, dv = self.cfg, self.device
@@ -316,7 +324,19 @@ class LlamaEngine:
 
         hidden_steps: Optional[List] = [] if output_hidden_states else None
         step0: Optional[list] = [] if output_hidden_states else None
-        h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
+        if position_ids is not None:
+            if c.mrope_section is None:
+                raise ValueError("position_ids with 3 components need a model with mrope_section (Qwen2.5-Omni thinker)")
+            if tuple(position_ids.shape) != (3, B, S):
+                raise ValueError(f"position_ids must be [3, {B}, {S}], got {tuple(position_ids.shape)}")
+            if has_pad:
+                raise NotImplementedError("multimodal position_ids together with left padding")
+            pos3 = position_ids.to(device=dv, dtype=torch.int32).contiguous()
+            h = self._prefill(h0.view(B * S, -1), pos3.view(3, -1), slot2d.view(-1), None, B, S, step0, mrope=True)
+            next_pos = pos3.amax(dim=(0, 2)) + 1
+        else:
+            h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
+            next_pos = pos2d[:, -1] + 1
 
         # decode state (static buffers + captured hipGraph) is cached per (batch, outputs): repeated generate() calls
         # replay the same graph instead of re-capturing ~200 launches
@@ -332,7 +352,7 @@ class LlamaEngine:
             step0[-1] = ops.rmsnorm(h, self.norm, c.eps).view(B, S, -1)
             hidden_steps.append(tuple(step0))
         st["cur_ids"].copy_(st["next_ids"])
-        st["pos"].copy_(pos2d[:, -1] + 1)
+        st["pos"].copy_(next_pos)
         st["slot"].fill_(S)
         st["kv_end"].fill_(S + 1)
 

@@ -109,16 +109,20 @@ def lm_head_argmax(W, x, norm_w=None, eps=0.0, out_ids=None, logits=None, ws=Non
     return out_ids
 
 
-def rope_kv_append(qkv, pos, slot, cos_sin, q_out, k_cache, v_cache, B, S, n_q, n_kv, d):
+def rope_kv_append(qkv, pos, slot, cos_sin, q_out, k_cache, v_cache, B, S, n_q, n_kv, d, mrope_section=None):
+    """pos [B*S] int32, or [3, B*S] with mrope_section=(t, h, w) rotary pairs per component (Qwen2.5-Omni: 16, 24, 24)."""
     _chk(qkv, BF16, "qkv"); _chk(pos, torch.int32, "pos"); _chk(slot, torch.int32, "slot")
     _chk(cos_sin, torch.float32, "cos_sin"); _chk(q_out, BF16, "q_out")
     _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache")
     T_max = k_cache.shape[2]
-    assert qkv.numel() == B * S * (n_q + 2 * n_kv) * d and pos.numel() == B * S and slot.numel() == B * S
+    sec_t, sec_h = (mrope_section[0], mrope_section[1]) if mrope_section is not None else (0, 0)
+    assert qkv.numel() == B * S * (n_q + 2 * n_kv) * d and slot.numel() == B * S
+    assert pos.numel() == (3 if mrope_section is not None else 1) * B * S
+    assert mrope_section is None or sum(mrope_section) == d // 2
     assert k_cache.shape[0] >= B and k_cache.shape[1] == n_kv and k_cache.shape[3] == d
     assert cos_sin.shape[1] == d
-    _lib.call("spider_rope_kv_append_bf16", _p(qkv), _p(pos), _p(slot), _p(cos_sin), _p(q_out), _p(k_cache),
-              _p(v_cache), B, S, n_q, n_kv, d, T_max, _stream())
+    _lib.call("spider_rope_kv_append_mrope_bf16", _p(qkv), _p(pos), _p(slot), _p(cos_sin), _p(q_out), _p(k_cache),
+              _p(v_cache), B, S, n_q, n_kv, d, T_max, sec_t, sec_h, _stream())
     return q_out
 
 

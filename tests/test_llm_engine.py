@@ -110,3 +110,44 @@ def test_engine_left_padding_and_stopping(dev):
     assert out.shape[1] == 10 + first + 1
     out = eng.generate(input_ids=ids, max_new_tokens=8, eos_token_id=stop_tok)
     assert out.shape[1] == 10 + first + 1
+
+
+def test_mrope_prefill_and_decode_match_oracle(dev):
+    """Qwen2.5-Omni thinker multimodal RoPE (mrope_section 16/24/24): a prompt of embeddings whose middle span carries image-like
+    (t, h, w) positions; engine vs oracle (oracle pinned to transformers' Qwen2_5OmniThinkerTextModel in tests/test_oracle_golden.py)."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, 331, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
+    w = LlamaOracle.random_weights(ocfg, seed=5, std=0.08)
+    oracle = LlamaOracle(ocfg, w)
+    eng = LlamaEngine(LLMConfig(**ocfg.__dict__), w, dev, max_batch=1, max_len=128)
+    g = torch.Generator().manual_seed(6)
+    S = 20
+    emb = (torch.randn(1, S, 256, generator=g) * 0.5).bfloat16().float()
+    # 4 text tokens, a 3x4 "image" (t fixed, h/w grid), 4 text tokens continuing after the largest image position
+    t = [0, 1, 2, 3] + [4] * 12 + [8, 9, 10, 11]
+    hh = [0, 1, 2, 3] + [4 + r for r in range(3) for _ in range(4)] + [8, 9, 10, 11]
+    ww = [0, 1, 2, 3] + [4 + c for _ in range(3) for c in range(4)] + [8, 9, 10, 11]
+    pos3 = torch.tensor([t, hh, ww])[:, None, :]
+    logits, kv, hs = oracle.forward(None, pos3, None, None, inputs_embeds=emb, all_hidden=True)
+    ref_tok = [int(logits[0, -1].argmax())]
+    p = int(pos3.max()) + 1
+    for n in range(5):
+        lg, kv, _ = oracle.forward(torch.tensor([[ref_tok[-1]]]), torch.tensor([[p + n]]), kv, None)
+        ref_tok.append(int(lg[0, -1].argmax()))
+    out = eng.generate(inputs_embeds=emb.to(dev), position_ids=pos3, max_new_tokens=6, return_dict_in_generate=True,
+                       output_hidden_states=True, return_logits=True)
+    got_h = out.hidden_states[0][-1].float().cpu()
+    rel = float((got_h - hs[-1]).norm() / hs[-1].norm())
+    assert rel < 2e-2, rel
+    # 1-D positions on the same embeddings give a different state: the 3 components are really used
+    out1 = eng.generate(inputs_embeds=emb.to(dev), max_new_tokens=2, return_dict_in_generate=True, output_hidden_states=True)
+    assert float((out1.hidden_states[0][-1].float().cpu() - hs[-1]).norm() / hs[-1].norm()) > 5 * rel
+    gen = out.sequences[0].tolist()
+    first_div = next((i for i, (a, b) in enumerate(zip(gen, ref_tok)) if a != b), None)
+    if first_div is not None:   # only a near-tie of the oracle's own logits may flip a greedy token
+        lg = out.logits[0, first_div].float().cpu()
+        top2 = lg.topk(2).values
+        assert float(top2[0] - top2[1]) < 0.08, (gen, ref_tok)
+    with pytest.raises(ValueError):
+        eng.generate(inputs_embeds=emb.to(dev), position_ids=pos3[:, :, :5], max_new_tokens=2)

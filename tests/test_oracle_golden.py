@@ -383,3 +383,25 @@ def test_signal_token_capture_matches_reference():
         assert [v[0] for v in case["hidden"][0][0]] == [float(s * 10 + (L - 1)) for s in range(lo, hi)]
         assert [v[0] for v in case["hidden_text"][0][0]] == [float(s * 10 + (L - 1)) for s in range(tlo, thi)]
     assert TrainedSpider.split_placeholder("<IMAGE><IMAGE-Placeholder></IMAGE> a dog") == ["<IMAGE>", "<IMAGE-Placeholder>", "</IMAGE> a dog"]
+
+
+def test_mrope_oracle_matches_transformers_qwen25_omni_text_model():
+    """multimodal RoPE restatement vs transformers' Qwen2_5OmniThinkerTextModel (tiny random, 3-row position ids)"""
+    from transformers.models.qwen2_5_omni import modeling_qwen2_5_omni as m
+    hc = m.Qwen2_5OmniTextConfig(vocab_size=200, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                                 num_key_value_heads=1, max_position_embeddings=512, rope_theta=1000000.0, rms_norm_eps=1e-6,
+                                 rope_scaling={"mrope_section": [16, 24, 24], "rope_type": "default", "type": "default"})
+    torch.manual_seed(0)
+    model = m.Qwen2_5OmniThinkerTextModel(hc).eval()
+    ocfg = LlamaCfg(256, 2, 2, 1, 128, 512, 200, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
+    w = {("model." + k): v.detach().float() for k, v in model.state_dict().items()}
+    w["lm_head.weight"] = w["model.embed_tokens.weight"]
+    x = torch.randn(2, 9, 256)
+    pos = torch.stack([torch.tensor([0, 1, 2, 2, 2, 2, 6, 7, 8]), torch.tensor([0, 1, 2, 2, 3, 3, 6, 7, 8]),
+                       torch.tensor([0, 1, 2, 3, 2, 3, 6, 7, 8])])[:, None, :].expand(3, 2, 9).contiguous()
+    with torch.no_grad():
+        ref = model(inputs_embeds=x, position_ids=pos).last_hidden_state
+    _, _, hs = LlamaOracle(ocfg, w).forward(None, pos, None, None, inputs_embeds=x, all_hidden=True)
+    assert torch.allclose(hs[-1], ref, atol=2e-5, rtol=1e-4)
+    _, _, hs1 = LlamaOracle(ocfg, w).forward(None, pos[0], None, None, inputs_embeds=x, all_hidden=True)
+    assert not torch.allclose(hs1[-1], ref, atol=1e-4), "1-D positions must differ from the 3-component ones"
