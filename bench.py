@@ -292,7 +292,7 @@ def main():
         wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
         tok_s = extra["llm_decode_tokens_per_s"] / a.batch
         extra["llm_decode_hbm_frac"] = round((wbytes + 2 * c.layers * c.n_kv * c.head_dim * 2 * (a.prompt_len + a.new_tokens // 2)) * tok_s / 1e9 / HBM_PEAK_GBS, 4)
-        cpu = None if args.no_cpu_baseline else cpu_baseline(args)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # reported at N=1 only
         total = world * args.batch * args.steps
         line = {
             "metric": "multimodal responses/sec (text->text+image)", "value": round(total / dt, 4), "unit": "responses/s",

@@ -10,7 +10,7 @@ os.makedirs(P, exist_ok=True)
 
 
 def newest(pat):
-    f = sorted(glob.glob(pat, recursive=True))
+    f = sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)
     return f[-1] if f else None
 
 
