@@ -67,9 +67,23 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// x * rcp(...) instead of x / (...): an IEEE fp32 division is a ~10-instruction sequence, v_rcp_f32 is 1 ulp
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+// exact-erf GELU (torch F.gelu default, diffusers GEGLU / CLIP-H / CLAP). erf through Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, two orders below bf16 resolution): branch-free, 2 transcendentals + 7 FMAs, where libdevice's
+// erff is a ~50-instruction divergent polynomial -- it was ~25 % of the fused GEGLU GEMM's time.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.f - p * t * __expf(-ax * ax);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x)); }
 
 // XCD-aware bijective remap of a linear block id: blocks that share an XCD (id % 8) get a
 // contiguous chunk of the logical grid, so neighbouring tiles hit the same L2.
