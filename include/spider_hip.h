@@ -118,6 +118,19 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
                      int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
                      const int* kv_beg, const void* keep_bits, int blk, int q_off, void* stream);
 
+/* packed variable-length attention: the per-segment SDPA loop over cu_seqlens of transformers'
+ * Qwen2_5OmniVisionAttention / Qwen2_5OmniAudioAttention (window / full-frame / audio-chunk segments), reached from the
+ * reference through Qwen2_5OmniModel.generate(**inputs) with images / audios (qwen2.5omni_spider_web.py:461-468).
+ * q/k/v/o: [total_rows, heads, d] views (row strides in elements, head stride d). tiles: device int[n_tiles][4] =
+ * {q_start, q_len (1..128), k_start, k_len}; the caller guarantees every range lies inside [0, total_rows). */
+int spider_attn_varlen_bf16(const void* q, const void* k, const void* v, void* o, long q_rs, long k_rs, long v_rs, long o_rs,
+                            int total_rows, int Hq, int Hkv, int d, float scale, const int* tiles, int n_tiles, void* stream);
+
+/* in-place half-rotation RoPE with a per-row angle table: transformers apply_rotary_pos_emb_vision of the Qwen2.5-Omni
+ * vision tower (same call path as above). x: bf16 rows of heads*d contiguous elements, row_stride apart;
+ * cos_sin: fp32 [rows, d] = [cos(d/2) | sin(d/2)]. */
+int spider_rope_rows_bf16(void* x, const float* cos_sin, long row_stride, int rows, int heads, int d, void* stream);
+
 /* ======================= UNet elementwise / normalisation (HBM-bound) ======================= */
 
 /* GroupNorm(+SiLU) on NHWC (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out).

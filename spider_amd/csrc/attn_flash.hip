@@ -33,6 +33,10 @@ struct AttnArgs {
     const int* kv_beg;                    // [B] or null: keys < kv_beg[b] are masked (left padding)
     const unsigned long long* keep_bits;  // [ceil(Lk/64)] or null: bit j%64 of word j/64 = key j kept
     int blk, q_off;                       // image block length / query row offset for the "own block" rule
+    // packed variable-length mode (Qwen2.5-Omni vision windows / audio chunks: cu_seqlens segments of one packed
+    // sequence): one record {q_start, q_len <= 128, k_start, k_len} per block instead of the regular 128-row grid
+    const int* tiles;
+    int n_tiles;
 };
 
 template <int DP>
@@ -55,9 +59,13 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     const int h32 = lane >> 5, l32 = lane & 31;
     const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
     const int hk = hq / (p.Hq / p.Hkv);
-    const int q0 = qt * 128;
+    int q0 = qt * 128, lq_end = p.Lq, seg_kbeg = 0, lk_end = p.Lk;
+    if (p.tiles) {
+        const int* rec = p.tiles + 4 * qt;
+        q0 = rec[0]; lq_end = rec[0] + rec[1]; seg_kbeg = rec[2]; lk_end = rec[2] + rec[3];
+    }
     const int qi = q0 + wave * 32 + l32;  // this lane's query row
-    const bool q_ok = qi < p.Lq;
+    const bool q_ok = qi < lq_end;
 
     const bf16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
     const bf16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     }
 
     // ---- key range for this query tile ----
-    const int kbeg = p.kv_beg ? p.kv_beg[b] : 0;
-    int kend = p.Lk;
+    const int kbeg = p.kv_beg ? p.kv_beg[b] : seg_kbeg;
+    int kend = lk_end;
     if (p.causal) kend = min(kend, q0 + 128 + p.kv_off);
     const int t_begin = kbeg / 64;
     const int t_end = (kend + 63) / 64;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             const int c = tid + i * 256;
             const int row = c / C::CPR, ch = c % C::CPR;
             const int key = t * 64 + row;
-            const bool ok = (c < 64 * C::CPR) && key < p.Lk && ch * 8 < p.d;
+            const bool ok = (c < 64 * C::CPR) && key < lk_end && ch * 8 < p.d;
             rk[i] = ok ? *reinterpret_cast<const u32x4*>(kb + (long)key * p.k_rs + ch * 8) : zero;
             rv[i] = ok ? *reinterpret_cast<const u32x4*>(vb + (long)key * p.v_rs + ch * 8) : zero;
         }
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         // Fast path (wave-uniform): a tile entirely inside [kbeg, Lk), below the causal diagonal of every row of
         // this wave and without a keep vector needs no per-element predicates: max, one fma + exp2, add.
         const int wave_q0 = q0 + wave * 32;
-        const bool full_tile = (t * 64 >= kbeg) && (t * 64 + 64 <= p.Lk) && !p.keep_bits &&
+        const bool full_tile = (t * 64 >= kbeg) && (t * 64 + 64 <= lk_end) && !p.keep_bits &&
                                (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off);
         float psum = 0.f, alpha;
         if (full_tile) {
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 for (int r = 0; r < 16; ++r) {
                     const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h32;
                     const int key = t * 64 + kk;
-                    bool ok = key < p.Lk && key >= kbeg;
+                    bool ok = key < lk_end && key >= kbeg;
                     if (p.causal) ok = ok && key <= caus_max;
                     if (p.keep_bits) ok = ok && (((kbits >> kk) & 1ull) || (key >= own_lo && key < own_hi));
                     vis |= ok ? (1u << (kt * 16 + r)) : 0u;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
 template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
-    dim3 grid((a.Lq + 127) / 128, a.Hq, a.B);
+    dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
     const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
     attn_flash_kernel<DP><<<grid, 256, smem, (hipStream_t)stream>>>(a);
     SPIDER_LAUNCH_OK();
@@ -307,6 +315,30 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
     a.scale_log2e = scale * 1.4426950408889634f;
     a.causal = causal; a.kv_off = kv_off; a.kv_beg = kv_beg;
     a.keep_bits = (const unsigned long long*)keep_bits; a.blk = keep_bits ? blk : 0; a.q_off = q_off;
+    if (d <= 64) return launch<64>(a, stream);
+    if (d <= 96) return launch<96>(a, stream);
+    if (d <= 128) return launch<128>(a, stream);
+    return launch<160>(a, stream);
+}
+
+// Packed variable-length attention (no mask tensor): q/k/v/o are [total_rows, heads, d] views with the given row
+// strides (head stride = d); `tiles` is a device int[n_tiles][4] = {q_start, q_len (1..128), k_start, k_len}: the
+// block computes softmax(q[q_start : q_start+q_len] k[k_start : k_start+k_len]^T * scale) v[...]. The host cuts each
+// cu_seqlens segment into <= 128-row query tiles that all see the segment's keys -- the per-segment SDPA loop of
+// transformers' Qwen2_5OmniVisionAttention / Qwen2_5OmniAudioAttention (reached through Qwen2_5OmniModel.generate,
+// qwen2.5omni_spider_web.py:468) without materialising a block-diagonal mask.
+int spider_attn_varlen_bf16(const void* q, const void* k, const void* v, void* o, long q_rs, long k_rs, long v_rs, long o_rs,
+                            int total_rows, int Hq, int Hkv, int d, float scale, const int* tiles, int n_tiles, void* stream) {
+    SPIDER_CHECK(total_rows > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && n_tiles > 0 && tiles, "attn_varlen: bad shape");
+    SPIDER_CHECK(d > 0 && d % 8 == 0 && d <= 160, "attn_varlen: head_dim must be a multiple of 8 and <= 160");
+    SPIDER_CHECK(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0, "attn_varlen: row strides must keep 16-byte alignment");
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q_hs = a.k_hs = a.v_hs = a.o_hs = d;
+    a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
+    a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Lq = total_rows; a.Lk = total_rows; a.d = d;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.tiles = tiles; a.n_tiles = n_tiles;
     if (d <= 64) return launch<64>(a, stream);
     if (d <= 96) return launch<96>(a, stream);
     if (d <= 128) return launch<128>(a, stream);

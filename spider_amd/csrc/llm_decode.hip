@@ -28,6 +28,47 @@ __global__ __launch_bounds__(256) void embed_kernel(const bf16_t* __restrict__ t
 }
 
 // ----------------------------------------------------------------------------------------------
+// In-place half-rotation RoPE on packed rows with a per-row angle table (vision tower):
+//   x[r, h, i]       = bf16(x1 * cos[r, i] - x2 * sin[r, i])        x1 = x[r, h, i], x2 = x[r, h, i + d/2]
+//   x[r, h, i + d/2] = bf16(x2 * cos[r, i] + x1 * sin[r, i])
+// = transformers apply_rotary_pos_emb_vision (fp32 arithmetic, cos/sin = cos,sin(freqs) with the d/2 angles repeated
+// for both halves, result cast back to the tensor dtype). cs [rows, d] fp32 = [cos(d/2) | sin(d/2)].
+// One thread per 8 rotary pairs (two 16-byte accesses).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_rows_kernel(bf16_t* __restrict__ x, const float* __restrict__ cs, long row_stride,
+                                                        int rows, int heads, int d) {
+    const int half = d >> 1, cpr = half >> 3;                 // 8-pair chunks per head
+    const long total = (long)rows * heads * cpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cpr);
+        const int h = (int)((idx / cpr) % heads);
+        const long r = idx / ((long)cpr * heads);
+        bf16_t* p = x + r * row_stride + (long)h * d + c * 8;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(p);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(p + half);
+        const float* cr = cs + r * d + c * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cr + half), s1 = *reinterpret_cast<const f32x4*>(cr + half + 4);
+        const float co[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float si[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        const uint32_t lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+        uint32_t ol[4], oh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = bf16lo_to_f32(lw[j]), a1 = bf16hi_to_f32(lw[j]);
+            const float b0 = bf16lo_to_f32(hw[j]), b1 = bf16hi_to_f32(hw[j]);
+            ol[j] = pack_bf16x2(a0 * co[2 * j] - b0 * si[2 * j], a1 * co[2 * j + 1] - b1 * si[2 * j + 1]);
+            oh[j] = pack_bf16x2(b0 * co[2 * j] + a0 * si[2 * j], b1 * co[2 * j + 1] + a1 * si[2 * j + 1]);
+        }
+        u32x4 vl, vh;
+        vl.x = ol[0]; vl.y = ol[1]; vl.z = ol[2]; vl.w = ol[3];
+        vh.x = oh[0]; vh.y = oh[1]; vh.z = oh[2]; vh.w = oh[3];
+        *reinterpret_cast<u32x4*>(p) = vl;
+        *reinterpret_cast<u32x4*>(p + half) = vh;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // RMSNorm (+ optional residual add):  h = x (+ res);  res_out = bf16(h);  y = bf16(w * bf16(h * rsqrt(mean(h^2)+eps)))
 // One block (256 threads) per row. Double rounding mirrors `self.weight * hidden_states.to(input_dtype)`.
 // ----------------------------------------------------------------------------------------------
@@ -1046,6 +1087,19 @@ extern "C" {
 int spider_embed_bf16(const void* table, const int* ids, void* out, int rows, int H, int V, void* stream) {
     SPIDER_CHECK(rows > 0 && H > 0 && H % 8 == 0 && V > 0, "embed: bad shape (H must be a multiple of 8)");
     embed_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)table, ids, (bf16_t*)out, H, V);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// x: bf16 [rows, row_stride] with heads*d contiguous elements at the start of each row (a q or k column slice of a fused
+// projection output); cos_sin: fp32 [rows, d] = [cos(d/2) | sin(d/2)] per row. In place.
+int spider_rope_rows_bf16(void* x, const float* cos_sin, long row_stride, int rows, int heads, int d, void* stream) {
+    SPIDER_CHECK(rows > 0 && heads > 0 && d > 0 && d % 16 == 0, "rope_rows: head_dim must be a multiple of 16");
+    SPIDER_CHECK(row_stride % 8 == 0 && row_stride >= (long)heads * d, "rope_rows: row stride must be >= heads*d and keep 16-byte alignment");
+    const long total = (long)rows * heads * (d / 16);
+    long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    rope_rows_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>((bf16_t*)x, cos_sin, row_stride, rows, heads, d);
     SPIDER_LAUNCH_OK();
     return 0;
 }

@@ -254,6 +254,48 @@ def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_of
     return out
 
 
+def varlen_tiles(cu_seqlens, device) -> torch.Tensor:
+    """cu_seqlens (python ints / tensor, [n_seg + 1]) -> int32 [n_tiles, 4] records {q_start, q_len <= 128, k_start, k_len}
+    for attention_varlen: every segment is cut into query tiles of at most 128 rows that all see the whole segment."""
+    cu = [int(v) for v in (cu_seqlens.tolist() if hasattr(cu_seqlens, "tolist") else cu_seqlens)]
+    rec = []
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b < a:
+            raise ValueError("cu_seqlens must be non-decreasing")
+        for q0 in range(a, b, 128):
+            rec.append((q0, min(128, b - q0), a, b - a))
+    if not rec:
+        raise ValueError("cu_seqlens describes no rows")
+    return torch.tensor(rec, dtype=torch.int32, device=device)
+
+
+def attention_varlen(q, k, v, n_heads, tiles, n_kv_heads=None, scale=None, out=None):
+    """Packed segments: q [T,Hq*d], k/v [T,Hkv*d] (last dim contiguous, row stride free); tiles from varlen_tiles()."""
+    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    T, Cq = q.shape
+    Hq, Hkv = n_heads, (n_kv_heads or n_heads)
+    d = Cq // Hq
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and k.shape[0] == T and v.shape[0] == T
+    assert tiles.dtype == torch.int32 and tiles.dim() == 2 and tiles.shape[1] == 4 and tiles.is_contiguous()
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    if out is None:
+        out = torch.empty(T, Cq, dtype=BF16, device=q.device)
+    _lib.call("spider_attn_varlen_bf16", _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+              T, Hq, Hkv, d, float(scale), _p(tiles), tiles.shape[0], _stream())
+    return out
+
+
+def rope_rows_(x, cos_sin, n_heads):
+    """In-place half-rotation RoPE. x [T, n_heads*d] bf16 view (row stride free), cos_sin [T, d] fp32 = [cos | sin]."""
+    _chk(x, BF16, "x", False); _chk(cos_sin, torch.float32, "cos_sin")
+    T, Cx = x.shape
+    d = Cx // n_heads
+    assert x.stride(1) == 1 and tuple(cos_sin.shape) == (T, d)
+    _lib.call("spider_rope_rows_bf16", _p(x), _p(cos_sin), x.stride(0), T, n_heads, d, _stream())
+    return x
+
+
 def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=None, kv_beg=None, out=None):
     """Prefill attention against the KV cache. q [B,S,n_q,d]; caches [B,n_kv,T_max,d]; keys [0, Lk)."""
     _chk(q, BF16, "q"); _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache")

@@ -405,3 +405,52 @@ def test_mrope_oracle_matches_transformers_qwen25_omni_text_model():
     assert torch.allclose(hs[-1], ref, atol=2e-5, rtol=1e-4)
     _, _, hs1 = LlamaOracle(ocfg, w).forward(None, pos[0], None, None, inputs_embeds=x, all_hidden=True)
     assert not torch.allclose(hs1[-1], ref, atol=1e-4), "1-D positions must differ from the 3-component ones"
+
+
+# ---------------------------------------------------------------------------------------------- Qwen2.5-Omni input towers (N4)
+def _load_towers():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen_towers_ref.npz"))
+    vw = {str(n): torch.from_numpy(z[f"vw{i}"]) for i, n in enumerate(z["v_names"])}
+    aw = {str(n): torch.from_numpy(z[f"aw{i}"]) for i, n in enumerate(z["a_names"])}
+    return z, vw, aw
+
+
+def test_vision_tower_oracle_matches_transformers_vectors():
+    """oracle/qwen_towers.py:vision_forward against transformers' own Qwen2_5OmniVisionEncoder (fixture made by
+    tests/golden/make_golden_towers.py): ragged windows, a 2-frame clip and an exactly divisible grid in one packed call."""
+    from oracle.qwen_towers import VisionCfg, vision_forward
+    z, vw, _ = _load_towers()
+    last, pooled = vision_forward(VisionCfg.tiny(), vw, torch.from_numpy(z["v_pixel_values"]), z["v_grid"].tolist())
+    assert torch.allclose(last, torch.from_numpy(z["v_last_hidden"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(pooled, torch.from_numpy(z["v_pooler"]), atol=2e-5, rtol=1e-5)
+
+
+def test_audio_tower_oracle_matches_transformers_vectors():
+    """oracle/qwen_towers.py:audio_forward against transformers' Qwen2_5OmniAudioEncoder: three audios (2 full chunks +
+    tail, exactly one chunk, odd post-CNN length whose last frame the stride-2 pooling drops)."""
+    from oracle.qwen_towers import AudioCfg, audio_forward, audio_output_lengths
+    z, _, aw = _load_towers()
+    got = audio_forward(AudioCfg.tiny(), aw, torch.from_numpy(z["a_features"]), z["a_lens"].tolist())
+    assert got.shape[0] == sum(audio_output_lengths(z["a_lens"].tolist()))
+    assert torch.allclose(got, torch.from_numpy(z["a_out"]), atol=2e-5, rtol=1e-5)
+
+
+def test_rope_index_oracle_matches_transformers_vectors():
+    """get_rope_index restatement, bit-exact (integer work): image, audio+image, video, left-padded batch, and a video with
+    its audio track interleaved (use_audio_in_video, the flag qwen2.5omni_spider_web.py:468 passes)."""
+    import importlib.util
+    from oracle.qwen_towers import OmniTokenIds, get_rope_index
+    spec = importlib.util.spec_from_file_location("mgt", os.path.join(os.path.dirname(__file__), "golden", "make_golden_towers.py"))
+    mgt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgt)
+    z, _, _ = _load_towers()
+    for i, cse in enumerate(mgt.rope_cases()):
+        ids = torch.tensor(cse["ids"])
+        mask = torch.tensor(cse["mask"]) if "mask" in cse else torch.ones_like(ids)
+        pos, delta = get_rope_index(OmniTokenIds(), 2, ids, cse["img"], cse["vid"], mask, cse["av"], cse["aud"], cse["spg"])
+        assert np.array_equal(pos.numpy(), z[f"r{i}_pos"]), f"case {i}"
+        assert np.array_equal(delta.numpy(), z[f"r{i}_delta"]), f"case {i}"
+    # text-only prompts take the cumulative-mask branch
+    am = torch.tensor([[0, 0, 1, 1, 1]])
+    pos, delta = get_rope_index(OmniTokenIds(), 2, torch.tensor([[0, 0, 5, 6, 7]]), None, None, am)
+    assert pos[:, 0].tolist() == [[1, 1, 0, 1, 2]] * 3 and int(delta) == 0
