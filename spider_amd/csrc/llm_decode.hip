@@ -57,8 +57,14 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(bf16_t* __restrict__ x, 
         for (int j = 0; j < 4; ++j) {
             const float a0 = bf16lo_to_f32(lw[j]), a1 = bf16hi_to_f32(lw[j]);
             const float b0 = bf16lo_to_f32(hw[j]), b1 = bf16hi_to_f32(hw[j]);
-            ol[j] = pack_bf16x2(a0 * co[2 * j] - b0 * si[2 * j], a1 * co[2 * j + 1] - b1 * si[2 * j + 1]);
-            oh[j] = pack_bf16x2(b0 * co[2 * j] + a0 * si[2 * j], b1 * co[2 * j + 1] + a1 * si[2 * j + 1]);
+            // separately rounded products, then one add -- the operation order of `t * cos + rotate_half(t) * sin` -- so the
+            // result is bit-identical to the fp32 torch expression. The empty asm hides each product from the backend's
+            // mul+add -> fma contraction (-ffp-contract=fast ignores the source-level contract pragma).
+            float p0 = a0 * co[2 * j], p1 = b0 * si[2 * j], p2 = a1 * co[2 * j + 1], p3 = b1 * si[2 * j + 1];
+            float r0 = b0 * co[2 * j], r1 = a0 * si[2 * j], r2 = b1 * co[2 * j + 1], r3 = a1 * si[2 * j + 1];
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+            ol[j] = pack_bf16x2(p0 - p1, p2 - p3);
+            oh[j] = pack_bf16x2(r0 + r1, r2 + r3);
         }
         u32x4 vl, vh;
         vl.x = ol[0]; vl.y = ol[1]; vl.z = ol[2]; vl.w = ol[3];
