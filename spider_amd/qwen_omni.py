@@ -124,6 +124,28 @@ def _load_safetensors(path: str, prefixes: Sequence[str]) -> Dict[str, torch.Ten
     return w
 
 
+def _cache_get(cache: dict, key, make, limit: int = 8):
+    """Small per-engine cache (insertion-ordered, oldest entry evicted) of index plans + captured graphs per input geometry."""
+    if key not in cache:
+        if len(cache) >= limit:
+            cache.pop(next(iter(cache)))
+        cache[key] = make()
+    return cache[key]
+
+
+def _capture(device, ent: dict, fn) -> None:
+    """Warm `fn` on a side stream, then capture it; ent gets "graph" and "out" (the static outputs)."""
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream(device).wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ent["out"] = fn()
+    ent["graph"] = g
+
+
 # ---------------------------------------------------------------------------------------------- host index logic (exact)
 def vision_position_ids(grid: Sequence[Tuple[int, int, int]], merge: int) -> torch.Tensor:
     """(h, w) coordinate of every patch in the processor's block-major order (vision_utils.get_vision_position_ids)."""
@@ -205,6 +227,7 @@ class VisionTowerEngine:
         self.m2 = (g("merger.mlp.2.weight"), g("merger.mlp.2.bias"))
         d = H // c.heads
         self.inv_freq = 1.0 / (10000.0 ** (torch.arange(0, d // 2, 2, dtype=torch.float) / (d // 2)))
+        self._cache: dict = {}
 
     @classmethod
     def random_init(cls, cfg: VisionTowerConfig, device="cuda:0", seed=0):
@@ -252,16 +275,9 @@ class VisionTowerEngine:
                     cos_sin=torch.cat([ang.cos(), ang.sin()], 1).contiguous().to(dv),
                     tiles_win=ops.varlen_tiles(cu_win, dv), tiles_full=ops.varlen_tiles(cu_full, dv))
 
-    @torch.no_grad()
-    def forward(self, pixel_values: torch.Tensor, grid_thw, return_last_hidden: bool = False):
-        """pixel_values [patches, C*Tp*P*P]; grid_thw [[t, h, w], ...] in patches -> pooler_output [patches / merge^2,
-        out_hidden] bf16 in the processor's original order (and last_hidden_state in window order on request)."""
+    def _run(self, px: torch.Tensor, p: dict):
         c = self.cfg
-        p = self.plan(grid_thw)
         T, H, nh = p["T"], c.hidden, c.heads
-        if tuple(pixel_values.shape) != (T, c.patch_dim):
-            raise ValueError(f"pixel_values must be [{T}, {c.patch_dim}] for grid_thw, got {tuple(pixel_values.shape)}")
-        px = pixel_values.to(device=self.device, dtype=BF16).contiguous()
         x = ops.embed(ops.gemm(px, self.w_patch), p["gather"])                     # patch embedding, window order
         for l, bw in enumerate(self.blocks):
             h = ops.rmsnorm(x, bw["n1"], c.eps)
@@ -277,8 +293,31 @@ class VisionTowerEngine:
         unit = c.merge * c.merge
         m = ops.rmsnorm(x, self.ln_q, c.eps).view(T // unit, unit * H)
         m = ops.gemm(ops.gemm(m, self.m0[0], bias=self.m0[1], act="gelu"), self.m2[0], bias=self.m2[1])
-        pooled = ops.embed(m, p["reverse"])
-        return (x, pooled) if return_last_hidden else pooled
+        return x, ops.embed(m, p["reverse"])
+
+    @torch.no_grad()
+    def forward(self, pixel_values: torch.Tensor, grid_thw, return_last_hidden: bool = False, use_graph: bool = True):
+        """pixel_values [patches, C*Tp*P*P]; grid_thw [[t, h, w], ...] in patches -> pooler_output [patches / merge^2,
+        out_hidden] bf16 in the processor's original order (and last_hidden_state in window order on request).
+        The index plan and the captured hipGraph (~420 launches) are cached per grid_thw: a repeated image size costs one
+        copy + one graph replay."""
+        c = self.cfg
+        key = tuple(tuple(int(v) for v in g) for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw))
+        ent = _cache_get(self._cache, key, lambda: {"plan": self.plan(key)})
+        p = ent["plan"]
+        if tuple(pixel_values.shape) != (p["T"], c.patch_dim):
+            raise ValueError(f"pixel_values must be [{p['T']}, {c.patch_dim}] for grid_thw, got {tuple(pixel_values.shape)}")
+        px = pixel_values.to(device=self.device, dtype=BF16).contiguous()
+        if not use_graph:
+            last, pooled = self._run(px, p)
+        else:
+            if "graph" not in ent:
+                ent["px"] = px.clone()
+                _capture(self.device, ent, lambda: self._run(ent["px"], p))
+            ent["px"].copy_(px)
+            ent["graph"].replay()
+            last, pooled = (t.clone() for t in ent["out"])
+        return (last, pooled) if return_last_hidden else pooled
 
     __call__ = forward
 
@@ -313,6 +352,7 @@ class AudioTowerEngine:
                 w1=g(b + "fc1.weight"), b1=g(b + "fc1.bias"), w2=g(b + "fc2.weight"), b2=g(b + "fc2.bias")))
         self.ln_post = (g("ln_post.weight"), g("ln_post.bias"))
         self.proj = (g("proj.weight"), g("proj.bias"))
+        self._cache: dict = {}
 
     @classmethod
     def random_init(cls, cfg: AudioTowerConfig, device="cuda:0", seed=0):
@@ -351,55 +391,68 @@ class AudioTowerEngine:
         B, L2, D = e.shape
         return ops.add(e, self.pos[:L2][None].expand(B, L2, D).contiguous())
 
-    @torch.no_grad()
-    def forward(self, input_features: torch.Tensor, feature_lens: Sequence[int]) -> torch.Tensor:
-        """input_features [mel, total_frames] (audios concatenated along time, as get_audio_features hands them over);
-        feature_lens: mel frames per audio. -> [sum(out_len), out_dim] bf16."""
+    def plan(self, lens: Tuple[int, ...]) -> dict:
         c, dv = self.cfg, self.device
-        lens = [int(v) for v in (feature_lens.tolist() if hasattr(feature_lens, "tolist") else feature_lens)]
-        if input_features.dim() != 2 or input_features.shape[0] != c.mel or input_features.shape[1] != sum(lens):
-            raise ValueError(f"input_features must be [{c.mel}, {sum(lens)}], got {tuple(input_features.shape)}")
-        if min(lens) < 3:
-            raise ValueError("every audio needs at least 3 mel frames (stride-2 conv + stride-2 pooling)")
         chunks = audio_chunk_lengths(lens, c.n_window)
         if (max(chunks) - 1) // 2 + 1 > c.max_pos:
             raise ValueError("chunk longer than the position table")
-        f = input_features.to(device=dv, dtype=BF16).t().contiguous()              # [frames, mel]
-        full = 2 * c.n_window
-        starts = [0]
+        starts, cu = [0], [0]
         for L in chunks:
             starts.append(starts[-1] + L)
-        full_ids = [i for i, L in enumerate(chunks) if L == full]
-        emb: List[Optional[torch.Tensor]] = [None] * len(chunks)
-        if full_ids:   # all full chunks as one batch
-            batch = torch.stack([f[starts[i]:starts[i] + full] for i in full_ids], 0)
-            e = self._cnn(batch)
-            for j, i in enumerate(full_ids):
-                emb[i] = e[j]
-        for i, L in enumerate(chunks):
-            if emb[i] is None:
-                emb[i] = self._cnn(f[starts[i]:starts[i] + L][None].contiguous())[0]
-        cu = [0]
-        for e in emb:
-            cu.append(cu[-1] + e.shape[0])
-        x = torch.cat(emb, 0).contiguous()
-        tiles = ops.varlen_tiles(cu, dv)
-        D, nh = c.d_model, c.heads
-        for lw in self.layers:
-            h = ops.layernorm(x, *lw["ln1"], c.eps)
-            qkv = ops.gemm(h, lw["w_qkv"], bias=lw["b_qkv"])
-            a = ops.attention_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], nh, tiles)
-            x = ops.gemm(a, lw["w_o"], bias=lw["b_o"], res=x)
-            h = ops.layernorm(x, *lw["ln2"], c.eps)
-            x = ops.gemm(ops.gemm(h, lw["w1"], bias=lw["b1"], act="gelu"), lw["w2"], bias=lw["b2"], res=x)
+            cu.append(cu[-1] + (L - 1) // 2 + 1)
         idx, off = [], 0
         for L in lens:   # stride-2 average pooling of consecutive post-CNN frames, per audio (an odd last frame is dropped)
             after = (L - 1) // 2 + 1
             idx += [off + 2 * i for i in range((after - 2) // 2 + 1)]
             off += after
         i0 = torch.tensor(idx, dtype=torch.int32, device=dv)
-        pooled = ops.add_scaled(ops.embed(x, i0), ops.embed(x, i0 + 1), 0.5)
+        return dict(chunks=chunks, starts=starts, tiles=ops.varlen_tiles(cu, dv), pool0=i0, pool1=i0 + 1)
+
+    def _run(self, f: torch.Tensor, p: dict) -> torch.Tensor:
+        """f [frames, mel] bf16."""
+        c = self.cfg
+        chunks, starts, full = p["chunks"], p["starts"], 2 * c.n_window
+        full_ids = [i for i, L in enumerate(chunks) if L == full]
+        emb: List[Optional[torch.Tensor]] = [None] * len(chunks)
+        if full_ids:   # all full chunks as one batch
+            e = self._cnn(torch.stack([f[starts[i]:starts[i] + full] for i in full_ids], 0))
+            for j, i in enumerate(full_ids):
+                emb[i] = e[j]
+        for i, L in enumerate(chunks):
+            if emb[i] is None:
+                emb[i] = self._cnn(f[starts[i]:starts[i] + L][None].contiguous())[0]
+        x = torch.cat(emb, 0).contiguous()
+        D, nh = c.d_model, c.heads
+        for lw in self.layers:
+            h = ops.layernorm(x, *lw["ln1"], c.eps)
+            qkv = ops.gemm(h, lw["w_qkv"], bias=lw["b_qkv"])
+            a = ops.attention_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], nh, p["tiles"])
+            x = ops.gemm(a, lw["w_o"], bias=lw["b_o"], res=x)
+            h = ops.layernorm(x, *lw["ln2"], c.eps)
+            x = ops.gemm(ops.gemm(h, lw["w1"], bias=lw["b1"], act="gelu"), lw["w2"], bias=lw["b2"], res=x)
+        pooled = ops.add_scaled(ops.embed(x, p["pool0"]), ops.embed(x, p["pool1"]), 0.5)
         return ops.gemm(ops.layernorm(pooled, *self.ln_post, c.eps), self.proj[0], bias=self.proj[1])
+
+    @torch.no_grad()
+    def forward(self, input_features: torch.Tensor, feature_lens: Sequence[int], use_graph: bool = True) -> torch.Tensor:
+        """input_features [mel, total_frames] (audios concatenated along time, as get_audio_features hands them over);
+        feature_lens: mel frames per audio. -> [sum(out_len), out_dim] bf16. Plan + hipGraph cached per feature_lens."""
+        c, dv = self.cfg, self.device
+        lens = tuple(int(v) for v in (feature_lens.tolist() if hasattr(feature_lens, "tolist") else feature_lens))
+        if input_features.dim() != 2 or input_features.shape[0] != c.mel or input_features.shape[1] != sum(lens):
+            raise ValueError(f"input_features must be [{c.mel}, {sum(lens)}], got {tuple(input_features.shape)}")
+        if min(lens) < 3:
+            raise ValueError("every audio needs at least 3 mel frames (stride-2 conv + stride-2 pooling)")
+        ent = _cache_get(self._cache, lens, lambda: {"plan": self.plan(lens)})
+        f = input_features.to(device=dv, dtype=BF16).t().contiguous()              # [frames, mel]
+        if not use_graph:
+            return self._run(f, ent["plan"])
+        if "graph" not in ent:
+            ent["f"] = f.clone()
+            _capture(dv, ent, lambda: self._run(ent["f"], ent["plan"]))
+        ent["f"].copy_(f)
+        ent["graph"].replay()
+        return ent["out"].clone()
 
     __call__ = forward
 
