@@ -55,7 +55,10 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     res = {}
-    for cfg in ([(0, 0), (128, 1), (64, 1)] if os.environ.get("QUICK") else [(0, 0), (128, 1), (128, 2), (128, 4), (128, 8), (64, 1), (64, 2), (64, 4), (64, 8), (64, 16)]):
+    cfgs = [(0, 0), (128, 1), (64, 1)] if os.environ.get("QUICK") else [(0, 0), (128, 1), (128, 2), (128, 4), (128, 8), (64, 1), (64, 2), (64, 4), (64, 8), (64, 16)]
+    if os.environ.get("GEMM_CFGS"):   # e.g. GEMM_CFGS="0:0,160:1,161:2" (tile 160/161/129 = the LDS-DMA kernel, see gemm.hip)
+        cfgs = [tuple(int(v) for v in c.split(":")) for c in os.environ["GEMM_CFGS"].split(",")]
+    for cfg in cfgs:
         env = dict(os.environ, PYTHONPATH=".")
         if cfg != (0, 0):
             env["SPIDER_GEMM_TILE"], env["SPIDER_GEMM_SPLITS"] = str(cfg[0]), str(cfg[1])

@@ -49,6 +49,7 @@ struct GemmArgs {
     // ups: the conv reads a virtual nearest-2x upsampled image cropped to lim_h x lim_w (= 2*Hin or 2*Hin-1, ...);
     // without ups lim_h/lim_w = Hin/Win. cin64: a 64-wide K tile never straddles two taps (uniform tap per tile).
     int conv, Hin, Win, Cin, Hout, Wout, kh, kw, stride, pad_h, pad_w, dil, ups, lim_h, lim_w, cin64;
+    int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -162,6 +163,58 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
+}
+
+// ---- epilogue shared by the GEMM kernels: lane holds C[mb + i*16 + (lane&15)][nb + j*16 + (lane>>4)*4 + 0..3] ----
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT], int mb, int nb, int split, int lane) {
+    if (EPI <= 1 && p.splits == 1) {
+        const EpiRsrc er = make_epi_rsrc(p);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = mb + i * 16 + (lane & 15);
+            uint32_t rb_row = 0;
+            if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = nb + j * 16 + (lane >> 4) * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
+            }
+        }
+        return;
+    }
+    if (EPI <= 1) {   // split-K partial sums of the fast instantiations (N % 4 == 0): plain fp32 vector stores
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = mb + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = nb + j * 16 + (lane >> 4) * 4;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<f32x4*>(p.ws + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mb + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nb + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.splits > 1) {
+                float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+                if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
+            } else {
+                epilogue_store<EPI>(p, m, n, v);     // EPI 3: ragged N / fp32 output / operands >= 4 GiB
+            }
+        }
+    }
 }
 
 template <int BM, int BN, bool CONV, int EPI>
@@ -364,54 +417,175 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         return;
     }
 
-    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    if (EPI <= 1 && p.splits == 1) {
-        const EpiRsrc er = make_epi_rsrc(p);
+    write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), split, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the large problems: 128 x BN x 64 tiles (BN = 160 or 128), 512 threads = 8 waves (4 along M x 2
+// along N, wave tile 32 x BN/2), ONE block per CU. Operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`,
+// no VGPR staging, no ds_write pass) into a ring of NS stages; the prefetch of tiles kt+1 .. kt+NS-1 stays in flight
+// across the single raw s_barrier per K tile behind a counted `s_waitcnt vmcnt(N)`. Why a second structure: the
+// register-staged 128^2 kernel above spends, per K tile and CU, 512 cycles of L1 bandwidth + ~420 cycles of ds_write
+// transfer + 256 of ds_read for 512 cycles of MFMA -- all co-limited behind two barriers; here the ds_write pass is
+// gone, the wave tile needs 14 (BN=160) ds_read_b128 per 20 MFMAs, and two waves per SIMD let one wave's DMA issue
+// overlap the other's MFMAs.
+//   * LDS-DMA writes lane l's 16 bytes at (wave-uniform base) + 16*l: the image must be linear in lane order, so the
+//     XOR chunk swizzle of the image is applied on the SOURCE side (lane at slot c of row r fetches global chunk
+//     c ^ ((r>>1)&7)); the fragment reads use the same involution as the kernel above.
+//   * out-of-range buffer offsets make the DMA write ZEROS (probed on MI355X, scripts/exp/glds_oob_probe.hip), so the
+//     conv halo, the M/N/K tails and the tiles past this split's K range need no branches and the vmcnt count is exact.
+//   * W pieces (8 rows x 128 B per wave instruction): BN/8 = 20 does not divide over 8 waves -- waves 0-3 issue 3, waves
+//     4-7 issue 2 (a wave-uniform branch) and each half waits with its own count.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, int NS, bool CONV, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int BM = 128;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE = ROWS * 128;                 // bytes per stage: [A tile 128 rows | W tile BN rows], 128-byte rows
+    constexpr int MT = 2, NT = BN / 32;               // 16x16 MFMA tiles per wave (wave tile 32 x BN/2)
+    constexpr int AJ = BM / 64;                       // A pieces per wave (8 rows each, 8 waves)
+    constexpr int WP = BN / 8;                        // W pieces in all
+    constexpr int WJ = (WP + 7) / 8;                  // W pieces per wave, upper bound
+    constexpr bool W_RAGGED = (WP % 8) != 0;          // last W piece only on waves < WP % 8
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+
+    // this lane's slot in a piece: row prow of 8, 16-byte slot `slot` of 8; the global chunk it fetches is slot ^ swizzle(row)
+    const int prow = lane >> 3, slot = lane & 7;
+    uint32_t a_base[AJ], a_inv[AJ], a_gch[AJ];
+    int a_oy[AJ], a_ox[AJ];
+    uint32_t w_base[WJ], w_inv[WJ], w_gch[WJ];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            uint32_t rb_row = 0;
-            if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
-            }
+    for (int j = 0; j < AJ; ++j) {
+        const int R = (j * 8 + wave) * 8 + prow;
+        const int m = m0 + R;
+        const bool ok = m < p.M;
+        const int mc = ok ? m : 0;
+        a_gch[j] = (uint32_t)(slot ^ ((R >> 1) & 7));
+        a_inv[j] = ok ? 0u : 0xFFFFFFFFu;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = mc / hw, rem = mc % hw;
+            a_oy[j] = rem / p.Wout;
+            a_ox[j] = rem % p.Wout;
+            a_base[j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+        } else {
+            a_base[j] = (uint32_t)mc * (uint32_t)p.lda * 2u + a_gch[j] * 16u;
+            a_oy[j] = a_ox[j] = 0;
         }
-        return;
-    }
-    if (EPI <= 1) {   // split-K partial sums of the fast instantiations (N % 4 == 0): plain fp32 vector stores
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                if (m < p.M && n < p.N)
-                    *reinterpret_cast<f32x4*>(p.ws + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
-            }
-        }
-        return;
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int j = 0; j < WJ; ++j) {
+        const int R = (j * 8 + wave) * 8 + prow;      // row inside the W tile (rows >= BN: ragged last piece, never issued)
+        const int n = n0 + R;
+        const bool ok = n < p.N && R < BN;
+        w_gch[j] = (uint32_t)(slot ^ ((R >> 1) & 7));   // BM = 128 rows precede the W tile: (128 + R) >> 1 & 7 == R >> 1 & 7
+        w_inv[j] = ok ? 0u : 0xFFFFFFFFu;
+        w_base[j] = ok ? (uint32_t)n * (uint32_t)p.K * 2u + w_gch[j] * 16u : 0u;
+    }
+
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
+
+    // DMA of K tile kt into ring stage `stage` (wave-uniform); tiles >= kt1 / chunks >= K are all-ones offsets -> zeros
+    auto issue = [&](int kt, int stage) {
+        char* sb = smem + stage * STAGE;
+        const uint32_t kbyte = (uint32_t)kt * (BK * 2);
+        const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.splits > 1) {
-                float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
-                if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
+        for (int j = 0; j < AJ; ++j) {
+            const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)a_gch[j] * 8)) >> 31) | t_inv;
+            uint32_t off;
+            if (CONV) {
+                const int kk = p.cin64 ? kt * BK : kt * BK + (int)a_gch[j] * 8;
+                const int tap = kk / p.Cin;
+                const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? (int)a_gch[j] * 8 : 0)) * 2u;
+                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                int iy = a_oy[j] * p.stride + ky * p.dil - p.pad_h;
+                int ix = a_ox[j] * p.stride + kx * p.dil - p.pad_w;
+                const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                off = (a_base[j] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[j] | k_inv;
             } else {
-                epilogue_store<EPI>(p, m, n, v);     // EPI 3: ragged N / fp32 output / operands >= 4 GiB
+                off = (a_base[j] + kbyte) | a_inv[j] | k_inv;
             }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
         }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            if (W_RAGGED && j == WJ - 1 && wave >= WP % 8) break;
+            const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)w_gch[j] * 8)) >> 31) | t_inv;
+            const uint32_t off = (w_base[j] + kbyte) | w_inv[j] | k_inv;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (BM / 8 + j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int a_rd = (wm * 32 + frow) * 128, w_rd = (BM + wn * (BN / 2) + frow) * 128;
+    auto compute = [&](int stage) {
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fg) ^ fswz) * 16;
+            bf16x8 af[MT], wf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_rd + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_rd + j * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // pieces per tile issued by this wave (vmcnt bookkeeping)
+    constexpr int L_HI = AJ + WJ, L_LO = AJ + WJ - (W_RAGGED ? 1 : 0);
+    const bool lo_half = W_RAGGED && wave >= WP % 8;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(kt0 + s, s);
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // tile kt is the oldest of the NS-1 tiles in flight: leave the NS-2 younger ones outstanding
+        if (lo_half) wait_vmcnt<(NS - 2) * L_LO>(); else wait_vmcnt<(NS - 2) * L_HI>();
+        __builtin_amdgcn_s_barrier();          // every wave's share of tile kt has landed; stage (kt-1) % NS is free again
+        int nxt = stage + NS - 1;
+        if (nxt >= NS) nxt -= NS;
+        // the two waves that share a SIMD (w and w + 4) run out of phase: one issues its DMA pieces (~100 cycles of issue
+        // stall each) while the other is in its MFMA cluster; in lockstep both would stall, then both compute
+        if (wave < 4 && p.dbg != 2) issue(kt + NS - 1, nxt);
+        if (p.dbg != 1) compute(stage);
+        if (wave >= 4 && p.dbg != 2) issue(kt + NS - 1, nxt);
+        if (++stage == NS) stage = 0;
     }
+    wait_vmcnt<0>();                            // the masked tail DMAs must not outlive the workgroup's LDS allocation
+
+    write_out<MT, NT, EPI>(p, acc, m0 + wm * 32, n0 + wn * (BN / 2), split, lane);
 }
 
 // split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
@@ -451,6 +625,34 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
         else if (epi == 2) gemm_kernel<BM, BN, false, 2><<<grid, 256, smem, st>>>(a);
         else if (epi == 1) gemm_kernel<BM, BN, false, 1><<<grid, 256, smem, st>>>(a);
         else gemm_kernel<BM, BN, false, 0><<<grid, 256, smem, st>>>(a);
+    }
+}
+
+// LDS-DMA kernel launch: BN = 160 or 128, NS-stage ring in dynamic LDS (> 64 KiB: raised once per instantiation)
+template <int BN, int NS, bool CONV, int EPI>
+void launch_dma_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int smem = NS * (128 + BN) * 128;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<BN, NS, CONV, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        once = true;
+    }
+    gemm_dma_kernel<BN, NS, CONV, EPI><<<grid, 512, smem, st>>>(a);
+}
+
+template <int BN, int NS>
+void launch_dma(const GemmArgs& a, int tiles, hipStream_t st) {
+    dim3 grid(tiles, a.splits);
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
+    if (a.conv) {
+        if (epi == 3) launch_dma_inst<BN, NS, true, 3>(a, grid, st);
+        else if (epi == 1) launch_dma_inst<BN, NS, true, 1>(a, grid, st);
+        else launch_dma_inst<BN, NS, true, 0>(a, grid, st);
+    } else {
+        if (epi == 3) launch_dma_inst<BN, NS, false, 3>(a, grid, st);
+        else if (epi == 1) launch_dma_inst<BN, NS, false, 1>(a, grid, st);
+        else launch_dma_inst<BN, NS, false, 0>(a, grid, st);
     }
 }
 
@@ -500,6 +702,27 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         }
     }
     if (force_tile) small = force_tile == 64;
+    // SPIDER_GEMM_TILE = 160 / 161 (4-stage ring) / 129 (128 x 128 DMA tile): force the LDS-DMA kernel (tuning aid)
+    static const int dbg = env_int("SPIDER_GEMM_DBG");
+    a.dbg = dbg;
+    int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : 0);
+    // Measured on MI355X (scripts/bench_gemm.py with GEMM_CFGS): with >= 2048 rows and >= 16 K tiles the LDS-DMA kernel wins
+    // (UNet convs at 64^2 / 32^2: 33 vs 46 us, 48 vs 70, 32 vs 43, 47 vs 64; ff2 17.6 vs 20.8); below that the register-staged
+    // tiles (more, smaller blocks) stay ahead, and at M = 1536 (LLM prefill) the two tie. Split K to ~256 blocks = 1 per CU.
+    // Only where N fills the 160-wide tiles (<= 8 % padding: the VAE's 128 / 256 / 512 channels would waste 25 %), and for
+    // plain linears only with a long K (at K = 1280 the tower / FF projections measured slower on it).
+    const int n160 = (a.N + 159) / 160;
+    if (!force_tile && !a.geglu && a.M >= 2048 && nk >= (a.conv ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
+        dma_bn = 160;
+        const int tdma = ((a.M + 127) / 128) * n160;
+        splits = 1;
+        if (nk >= 40) {
+            splits = (256 + tdma / 2) / tdma;
+            if (splits > 8) splits = 8;
+            if (splits > nk / 8) splits = nk / 8;
+            if (splits < 1) splits = 1;
+        }
+    }
     if (!a.ws || splits < 1 || a.geglu) splits = 1;
     while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
     const int tiles = small ? t64 : t128;
@@ -509,7 +732,12 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     }
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
-    if (small) launch_tile<64, 64>(a, tiles, st);
+    if (dma_bn && !a.geglu) {
+        const int tdma = ((a.M + 127) / 128) * ((a.N + dma_bn - 1) / dma_bn);
+        if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
+        else if (dma_bn == 160) launch_dma<160, 3>(a, tdma, st);
+        else launch_dma<128, 4>(a, tdma, st);
+    } else if (small) launch_tile<64, 64>(a, tiles, st);
     else launch_tile<128, 128>(a, tiles, st);
     SPIDER_LAUNCH_OK();
     if (a.splits > 1) {
