@@ -546,22 +546,21 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
 
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
     const int a_rd = (wm * 32 + frow) * 128, w_rd = (BM + wn * (BN / 2) + frow) * 128;
-    auto compute = [&](int stage) {
+    bf16x8 af[MT], wf[NT];
+    auto read_frags = [&](int stage, int ks) {
         const char* sb = smem + stage * STAGE;
+        const int coff = ((ks * 4 + fg) ^ fswz) * 16;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fg) ^ fswz) * 16;
-            bf16x8 af[MT], wf[NT];
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_rd + i * 16 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_rd + i * 16 * 128 + coff);
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_rd + j * 16 * 128 + coff);
+    };
+    auto mfmas = [&]() {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_rd + j * 16 * 128 + coff);
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
     // pieces per tile issued by this wave (vmcnt bookkeeping)
@@ -576,11 +575,15 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         __builtin_amdgcn_s_barrier();          // every wave's share of tile kt has landed; stage (kt-1) % NS is free again
         int nxt = stage + NS - 1;
         if (nxt >= NS) nxt -= NS;
-        // the two waves that share a SIMD (w and w + 4) run out of phase: one issues its DMA pieces (~100 cycles of issue
-        // stall each) while the other is in its MFMA cluster; in lockstep both would stall, then both compute
-        if (wave < 4 && p.dbg != 2) issue(kt + NS - 1, nxt);
-        if (p.dbg != 1) compute(stage);
-        if (wave >= 4 && p.dbg != 2) issue(kt + NS - 1, nxt);
+        // The DMA pieces (~100 cycles of issue stall each) are issued while this wave's fragment reads are in flight, and the
+        // two waves that share a SIMD (w and w + 4) do it at different points of the K tile, so one wave's issue stall falls
+        // into the other's MFMA cluster; in lockstep both would stall, then both compute.
+        read_frags(stage, 0);
+        if (wave < 4 && p.dbg != 2) { __builtin_amdgcn_sched_barrier(0); issue(kt + NS - 1, nxt); __builtin_amdgcn_sched_barrier(0); }
+        if (p.dbg != 1) mfmas();
+        read_frags(stage, 1);
+        if (wave >= 4 && p.dbg != 2) { __builtin_amdgcn_sched_barrier(0); issue(kt + NS - 1, nxt); __builtin_amdgcn_sched_barrier(0); }
+        if (p.dbg != 1) mfmas();
         if (++stage == NS) stage = 0;
     }
     wait_vmcnt<0>();                            // the masked tail DMAs must not outlive the workgroup's LDS allocation
@@ -705,14 +708,14 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // SPIDER_GEMM_TILE = 160 / 161 (4-stage ring) / 129 (128 x 128 DMA tile): force the LDS-DMA kernel (tuning aid)
     static const int dbg = env_int("SPIDER_GEMM_DBG");
     a.dbg = dbg;
-    int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : 0);
+    int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : (force_tile == 65 ? 64 : 0));
     // Measured on MI355X (scripts/bench_gemm.py with GEMM_CFGS): with >= 2048 rows and >= 16 K tiles the LDS-DMA kernel wins
-    // (UNet convs at 64^2 / 32^2: 33 vs 46 us, 48 vs 70, 32 vs 43, 47 vs 64; ff2 17.6 vs 20.8); below that the register-staged
+    // (UNet convs at 64^2 / 32^2: 33 vs 46 us, 48 vs 70, 32 vs 43, 47 vs 64; at 16^2 with 8 K splits 30 vs 41, 48 vs 63); below that the register-staged
     // tiles (more, smaller blocks) stay ahead, and at M = 1536 (LLM prefill) the two tie. Split K to ~256 blocks = 1 per CU.
     // Only where N fills the 160-wide tiles (<= 8 % padding: the VAE's 128 / 256 / 512 channels would waste 25 %), and for
     // plain linears only with a long K (at K = 1280 the tower / FF projections measured slower on it).
     const int n160 = (a.N + 159) / 160;
-    if (!force_tile && !a.geglu && a.M >= 2048 && nk >= (a.conv ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
+    if (!force_tile && !a.geglu && a.M >= (a.conv ? 512 : 2048) && nk >= (a.conv && a.M >= 2048 ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
         dma_bn = 160;
         const int tdma = ((a.M + 127) / 128) * n160;
         splits = 1;
@@ -734,7 +737,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
     if (dma_bn && !a.geglu) {
         const int tdma = ((a.M + 127) / 128) * ((a.N + dma_bn - 1) / dma_bn);
-        if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
+        if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
+        else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
         else if (dma_bn == 160) launch_dma<160, 3>(a, tdma, st);
         else launch_dma<128, 4>(a, tdma, st);
     } else if (small) launch_tile<64, 64>(a, tiles, st);
