@@ -153,6 +153,37 @@ def measure_roofline(resp, device):
             "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n}
 
 
+def measure_mfma_roofline(device):
+    """Largest MFMA-bound kernel class of the UNet step: the 3x3 implicit-GEMM conv (ResnetBlock2D conv at the 64x64 latent,
+    320 -> 320 channels, CFG batch 2: M = 8192 output pixels, N = 320, K = 2880; the LDS-DMA kernel with 2 K splits + reduce).
+    Algorithmic flops per call = 2*M*N*K; timed live with HIP events over back-to-back calls on torch's current stream."""
+    from spider_amd import ops
+    x = torch.randn(2, 64, 64, 320, device=device).to(torch.bfloat16)
+    w = (torch.randn(320, 3, 3, 320, device=device) * 0.02).to(torch.bfloat16)
+    for _ in range(5):
+        ops.conv2d(x, w)
+    torch.cuda.synchronize(device)
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    g = torch.cuda.CUDAGraph()      # graph replay: the ~10 us of Python/ctypes launch overhead would otherwise be in the figure
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            ops.conv2d(x, w)
+    g.replay()
+    torch.cuda.synchronize(device)
+    e0.record(stream)
+    g.replay()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 2 * 8192 * 320 * 2880
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,3,CONV> + splitk_reduce (UNet 3x3 conv, 64x64 latent, 320->320, batch 2)",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
+
+
 def cpu_baseline(args):
     """fp32 CPU oracle ("port") on a bounded sample, extrapolated linearly to one response."""
     from oracle.llama import LlamaCfg, LlamaOracle
@@ -288,6 +319,7 @@ def main():
                                            "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
                                                    "not the headline value"}
         roof = measure_roofline(resp, device)
+        extra["roofline_unet_conv"] = measure_mfma_roofline(device)
         c = resp.llm.cfg
         wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
         tok_s = extra["llm_decode_tokens_per_s"] / a.batch

@@ -14,8 +14,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_
 for c in cross64 self64; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d gpurun_out/pmc_${tag}_mfma_$c -- python3 scripts/bench_attn.py $c > /dev/null 2>&1
 done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d gpurun_out/pmc_${tag}_mfma_conv -- python3 scripts/pmc_gemm.py conv64_320 > /dev/null 2>&1
 python3 scripts/summarize_profiles.py $tag
 # gpurun merges at most 64 MiB back: keep the summaries, drop the raw traces (the per-launch kernel trace of the bench alone is ~50 MB)
 mkdir -p gpurun_out/profiles_out && cp profiles/${tag}_* gpurun_out/profiles_out/
 find gpurun_out -name "*kernel_trace.csv" -delete
-rm -rf gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/pmc_${tag}_mfma_cross64 gpurun_out/pmc_${tag}_mfma_self64
+rm -rf gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/pmc_${tag}_mfma_cross64 gpurun_out/pmc_${tag}_mfma_self64 gpurun_out/pmc_${tag}_mfma_conv

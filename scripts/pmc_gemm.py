@@ -9,6 +9,9 @@ if which == "gate_up":
 elif which == "conv64":
     x = torch.randn(2, 64, 64, 640, device=dev).bfloat16(); w = (torch.randn(320, 3, 3, 640, device=dev) * 0.02).bfloat16()
     f = lambda: ops.conv2d(x, w)
+elif which == "conv64_320":   # the roofline_unet_conv shape of bench.py
+    x = torch.randn(2, 64, 64, 320, device=dev).bfloat16(); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).bfloat16()
+    f = lambda: ops.conv2d(x, w)
 elif which == "ff1":
     A = torch.randn(8192, 320, device=dev).bfloat16(); W = (torch.randn(2560, 320, device=dev) * 0.02).bfloat16()
     f = lambda: ops.gemm(A, W)

@@ -71,6 +71,17 @@ for c in ("cross64", "self64"):
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs = 1024 MFMA pipes
         a["mfma_busy_fraction"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8 * 1024)
     mf[c] = a
+f = newest(f"{G}/pmc_{tag}_mfma_conv/**/*counter_collection.csv")
+if f:
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        if "gemm_dma_kernel" in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    a = {k: sum(v) / len(v) for k, v in agg.items()}
+    if a.get("GRBM_GUI_ACTIVE", 0) > 0:
+        a["mfma_busy_fraction"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        a["note"] = "gemm_dma_kernel<160,3,CONV> on the UNet 3x3 conv 320->320 at the 64x64 latent, batch 2 (python scripts/pmc_gemm.py conv64_320)"
+        mf["conv64_320"] = a
 if mf:
     mf["note"] = ("SD-v1.5 UNet attention at 64x64 latent, CFG batch 2, 8 heads, d=40: cross (77 keys) and self (4096 keys); "
                   "python scripts/bench_attn.py <case> under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA")
