@@ -76,21 +76,24 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
 
 // GroupNorm, pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU; output bf16.
 // Rounds once after the affine (as torch's GroupNorm does) and once more after SiLU.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
-                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                                                       bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
-                                                       float eps, int silu, int pix_per_block) {
+__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
+                                const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
+                                float eps, int silu, int pix_per_block, int KP) {
+    // Block = (C/8)*KP threads like pass 1: a thread owns one 8-channel vector for all its pixels, so the per-channel
+    // scale a_c = rstd_g * gamma_c and shift b_c = beta_c - mean_g * a_c live in 16 registers and the inner loop is one fma
+    // (+ SiLU) per element -- no per-element group lookup (an integer division by a runtime C/G and two LDS reads before).
     __shared__ float mean[64], rstd[64];
-    __shared__ float ps[256], pq[256];
+    __shared__ float ps[1024], pq[1024];
     const int b = blockIdx.y;
     const int cpg = C / G;
+    const int nthr = blockDim.x;
     {
-        const int parts = 256 / G;                  // G in {32, 64, ...}: 8 or 4 parts
+        const int parts = nthr / G;                 // >= 2 for every supported shape (nthr >= 128, G <= 64)
         const int g = threadIdx.x % G, part = threadIdx.x / G;
         float gs = 0.f, gq = 0.f;
         if (part < parts) {
-            // nchunk <= 128 and parts >= 4: at most 32 partials per thread, loaded 8 at a time (independent loads)
-            for (int c0 = part; c0 < nchunk; c0 += 8 * parts) {
+            for (int c0 = part; c0 < nchunk; c0 += 8 * parts) {   // 8 independent loads per round
                 float2 t[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -117,32 +120,50 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
     __syncthreads();
     const int cv = C / 8;
-    const int p0 = blockIdx.x * pix_per_block;
-    const int p1 = min(HW, p0 + pix_per_block);
-    const size_t base = (size_t)b * HW * C;
-#pragma unroll 2
-    for (int idx = p0 * cv + threadIdx.x; idx < p1 * cv; idx += 256) {
-        const int v = idx % cv;
-        const u32x4 a = *reinterpret_cast<const u32x4*>(x + base + (size_t)idx * 8);
+    const int v = threadIdx.x % cv, pl = threadIdx.x / cv;
+    float ca[8], cb[8];
+    {
         const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + v * 8);
         const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + v * 8);
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
-        float o[8];
+        const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = v * 8 + j;
-            const int g = c / cpg;
-            const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
+            const int g = (v * 8 + j) / cpg;
             const float ga = (j & 1) ? bf16hi_to_f32(gw[j >> 1]) : bf16lo_to_f32(gw[j >> 1]);
             const float be = (j & 1) ? bf16hi_to_f32(bw[j >> 1]) : bf16lo_to_f32(bw[j >> 1]);
-            float t = (xv - mean[g]) * rstd[g] * ga + be;
-            if (silu) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
-            o[j] = t;
+            ca[j] = rstd[g] * ga;
+            cb[j] = be - mean[g] * ca[j];
         }
-        u32x4 ov;
-        ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
-        ov.z = pack_bf16x2(o[4], o[5]); ov.w = pack_bf16x2(o[6], o[7]);
-        *reinterpret_cast<u32x4*>(y + base + (size_t)idx * 8) = ov;
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const bf16_t* xb = x + (size_t)b * HW * C + v * 8;
+    bf16_t* yb = y + (size_t)b * HW * C + v * 8;
+    for (int px = p0 + pl; px < p1; px += 4 * KP) {
+        u32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pp = px + u * KP;
+            a[u] = pp < p1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)pp * C) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pp = px + u * KP;
+            if (pp >= p1) break;
+            const uint32_t aw[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
+                float t = fmaf(xv, ca[j], cb[j]);
+                if (silu) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
+                o[j] = t;
+            }
+            u32x4 ov;
+            ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
+            ov.z = pack_bf16x2(o[4], o[5]); ov.w = pack_bf16x2(o[6], o[7]);
+            *reinterpret_cast<u32x4*>(yb + (size_t)pp * C) = ov;
+        }
     }
 }
 
@@ -734,11 +755,12 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
     gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
                                                                                        G, nchunk, KP);
     SPIDER_LAUNCH_OK();
-    int ppb = (8 * 256 * 4) / C;  // ~8K elements per thread block iteration set
-    if (ppb < 1) ppb = 1;
+    int ppb = 4 * KP;             // one round of 4 independent 16-byte loads per thread
+    while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;   // keep the grid at <= ~4 blocks per CU
+    SPIDER_CHECK(threads >= 128 || threads >= 2 * G, "groupnorm: too few channels for the block layout");
     dim3 g2((HW + ppb - 1) / ppb, B);
-    gn_apply_kernel<<<g2, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
-                                                         (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, silu, ppb);
+    gn_apply_kernel<<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
+                                                             (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, silu, ppb, KP);
     SPIDER_LAUNCH_OK();
     return 0;
 }
