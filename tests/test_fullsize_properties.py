@@ -4,6 +4,10 @@
   * SD-v1.5 UNet at 64x64: hipGraph replay == eager bit-for-bit, batch-permutation equivariance of the CFG batch
   * flash attention at N = 4096, d = 40: softmax rows are convex combinations (outputs bounded by V's range; constant V
     is reproduced exactly) -- a checksum-style invariant
+  * Qwen2.5-Omni-7B input towers at their true widths (8 of the 32 layers): packing independence -- images / audios encoded
+    together equal the same inputs encoded one by one (segments never see each other), hipGraph replay == eager, a window-
+    attention layer really is local (perturbing one image window leaves the other windows' tokens untouched before the
+    first full-attention layer)
 """
 import pytest
 import torch
@@ -82,3 +86,57 @@ def test_attention_convexity_full_size(dev):
     const = torch.full_like(v, 0.75)
     oc = ops.attention(q, k, const, heads)
     assert torch.equal(oc, const), "softmax rows must sum to one: a constant V is reproduced exactly in bf16"
+
+
+def test_vision_tower_packing_independence_full_width(dev):
+    from spider_amd.qwen_omni import VisionTowerConfig, VisionTowerEngine
+    cfg = VisionTowerConfig.qwen25_omni_7b()
+    cfg.depth, cfg.fullatt = 8, (3, 7)
+    eng = VisionTowerEngine.random_init(cfg, dev, seed=5)
+    g = torch.Generator(device=dev).manual_seed(1)
+    ga, gb = [1, 16, 24], [2, 10, 6]                  # 224 x 336 px image (ragged windows) and a 2-frame 140 x 84 clip
+    pa = torch.randn(16 * 24, cfg.patch_dim, generator=g, device=dev)
+    pb = torch.randn(2 * 10 * 6, cfg.patch_dim, generator=g, device=dev)
+    both = eng(torch.cat([pa, pb]), [ga, gb], use_graph=False)
+    ea, eb = eng(pa, [ga], use_graph=False), eng(pb, [gb], use_graph=False)
+    assert both.shape == (16 * 24 // 4 + 2 * 10 * 6 // 4, cfg.out_hidden) and bool(torch.isfinite(both.float()).all())
+    ref = torch.cat([ea, eb]).float()
+    assert float((both.float() - ref).norm() / ref.norm()) < 1.5e-2    # same arithmetic; only the GEMM tile / split-K choice (fp32 summation order) moves with M
+    assert torch.equal(eng(pa, [ga], use_graph=True), eng(pa, [ga], use_graph=True))
+    assert torch.equal(eng(pa, [ga], use_graph=True), ea)             # graph replay == eager, bit for bit
+    # locality of window attention: with only window layers, patches of the first 8x8-patch window cannot influence other windows
+    cfg2 = VisionTowerConfig.qwen25_omni_7b()
+    cfg2.depth, cfg2.fullatt = 2, ()
+    e2 = VisionTowerEngine.random_init(cfg2, dev, seed=6)
+    base = e2(pa, [ga], use_graph=False)
+    pert = pa.clone()
+    plan = e2.plan([tuple(ga)])
+    first_window_patches = plan["gather"][:64].long()                  # the 64 patches of the first window, original order
+    pert[first_window_patches] += 1.0
+    out = e2(pert, [ga], use_graph=False)
+    changed = (out != base).any(-1)                                    # merged tokens, original order
+    touched = torch.zeros(16 * 24 // 4, dtype=torch.bool, device=dev)
+    touched[(first_window_patches // 4).unique()] = True
+    assert bool(changed[touched].any()) and not bool(changed[~touched].any())
+
+
+def test_audio_tower_packing_independence_full_width(dev):
+    from spider_amd.qwen_omni import AudioTowerConfig, AudioTowerEngine, audio_output_lengths
+    cfg = AudioTowerConfig.qwen25_omni_7b()
+    cfg.layers = 8
+    eng = AudioTowerEngine.random_init(cfg, dev, seed=7)
+    g = torch.Generator(device=dev).manual_seed(2)
+    la, lb = 937, 200                                 # 4 full chunks + a 137-frame tail; exactly one chunk
+    fa = torch.randn(cfg.mel, la, generator=g, device=dev)
+    fb = torch.randn(cfg.mel, lb, generator=g, device=dev)
+    both = eng(torch.cat([fa, fb], 1), [la, lb], use_graph=False)
+    ea, eb = eng(fa, [la], use_graph=False), eng(fb, [lb], use_graph=False)
+    assert both.shape[0] == sum(audio_output_lengths([la, lb])) == 234 + 50
+    ref = torch.cat([ea, eb]).float()
+    assert bool(torch.isfinite(both.float()).all()) and float((both.float() - ref).norm() / ref.norm()) < 1.5e-2
+    assert torch.equal(eng(fa, [la], use_graph=True), ea)
+    # chunks never see each other: changing the last chunk of the first audio leaves the tokens of its first chunk untouched
+    fa2 = fa.clone()
+    fa2[:, 800:] += 0.5
+    e2 = eng(fa2, [la], use_graph=False)
+    assert torch.equal(e2[:50], ea[:50]) and not torch.equal(e2[200:], ea[200:])
