@@ -573,6 +573,18 @@ class QwenOmniThinker:
         self.ids = token_ids or OmniTokenIds()
         self.merge = vision.cfg.merge if vision is not None else 2
 
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", max_len: int = 4096, load_vision: bool = True, load_audio: bool = True):
+        """A Qwen2.5-Omni checkpoint directory (config.json + *.safetensors with `thinker.model.*`, `thinker.visual.*`,
+        `thinker.audio_tower.*`): what `Qwen2_5OmniModel.from_pretrained(args.checkpoint_path)` reads
+        (qwen2.5omni_spider_web.py:376-381), minus the talker / token2wav weights this path never uses."""
+        import json, os
+        from .llm import LlamaEngine
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        return cls(LlamaEngine.from_pretrained(path, device, max_batch=1, max_len=max_len),
+                   VisionTowerEngine.from_pretrained(path, device) if load_vision else None,
+                   AudioTowerEngine.from_pretrained(path, device) if load_audio else None, OmniTokenIds.from_hf_dict(cfg))
+
     def _splice(self, emb: torch.Tensor, input_ids: torch.Tensor, token: int, feats: torch.Tensor, what: str) -> None:
         mask = (input_ids == token).to(emb.device)
         n = int(mask.sum())

@@ -215,3 +215,52 @@ def test_thinker_image_audio_text_prompt_matches_oracle(dev):
         assert float(top2[0] - top2[1]) < 0.08, (gen, ref_tok)
     with pytest.raises(ValueError):   # placeholder count must equal the tower's row count
         thinker.prepare_inputs(ids[:, :-8], None, pixel_values=px, image_grid_thw=torch.tensor(grid))
+
+
+@pytest.mark.gpu
+def test_from_pretrained_reads_the_omni_checkpoint_layout(dev, tmp_path):
+    """config.json with the nested thinker_config (text / vision / audio) + safetensors with the `thinker.*` prefixes, plus
+    talker weights that must be ignored: the three engines load through from_pretrained and reproduce engines built directly."""
+    import json
+    from safetensors.torch import save_file
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    from spider_amd.qwen_omni import AudioTowerConfig, AudioTowerEngine, QwenOmniThinker, VisionTowerConfig, VisionTowerEngine
+    lcfg = LlamaCfg(256, 2, 4, 2, 128, 512, 400, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
+    lw = LlamaOracle.random_weights(lcfg, seed=7, std=0.08)
+    vc, ac = oq.VisionCfg.tiny(), oq.AudioCfg.tiny()
+    vc.out_hidden = ac.out_dim = 256
+    vw = oq.random_weights(oq.vision_param_shapes(vc), seed=8)
+    aw = oq.random_weights(oq.audio_param_shapes(ac), seed=9)
+    sd = {("thinker." + k): v.contiguous() for k, v in lw.items()}
+    sd.update({"thinker.visual." + k: v.contiguous() for k, v in vw.items()})
+    sd.update({"thinker.audio_tower." + k: v.contiguous() for k, v in aw.items()})
+    sd["talker.model.embed_tokens.weight"] = torch.zeros(4, 4)
+    save_file({k: v.to(torch.bfloat16) for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    cfg = {"model_type": "qwen2_5_omni", "thinker_config": {
+        "text_config": {"model_type": "qwen2_5_omni_text", "hidden_size": 256, "num_hidden_layers": 2, "num_attention_heads": 4,
+                        "num_key_value_heads": 2, "head_dim": 128, "intermediate_size": 512, "vocab_size": 400, "rope_theta": 1000000.0,
+                        "rope_scaling": {"mrope_section": [16, 24, 24], "rope_type": "default"}, "rms_norm_eps": 1e-6,
+                        "max_position_embeddings": 512, "tie_word_embeddings": False},
+        "vision_config": {"depth": vc.depth, "hidden_size": vc.hidden, "num_heads": vc.heads, "intermediate_size": vc.inter,
+                          "in_channels": 3, "patch_size": vc.patch, "temporal_patch_size": 2, "spatial_merge_size": 2,
+                          "window_size": vc.window, "out_hidden_size": 256, "fullatt_block_indexes": list(vc.fullatt)},
+        "audio_config": {"num_mel_bins": ac.mel, "encoder_layers": ac.layers, "encoder_attention_heads": ac.heads,
+                         "encoder_ffn_dim": ac.ffn, "d_model": ac.d_model, "max_source_positions": ac.max_pos,
+                         "n_window": ac.n_window, "output_dim": 256},
+        "image_token_index": 390, "video_token_index": 391, "audio_token_index": 392, "vision_start_token_id": 393,
+        "audio_start_token_id": 394, "position_id_per_seconds": 25, "seconds_per_chunk": 2}}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    th = QwenOmniThinker.from_pretrained(str(tmp_path), dev, max_len=128)
+    assert th.ids.image == 390 and th.ids.audio_start == 394 and th.llm.cfg.mrope_section == (16, 24, 24) and th.llm.cfg.qkv_bias
+    assert th.vision.cfg.fullatt == tuple(vc.fullatt) and th.audio.cfg.n_window == ac.n_window
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(24, vc.patch_dim, generator=g).bfloat16().float()
+    feats = torch.randn(ac.mel, 47, generator=g).bfloat16().float()
+    v_ref = VisionTowerEngine(VisionTowerConfig(**vc.__dict__), vw, dev)(px, [[1, 4, 6]])
+    a_ref = AudioTowerEngine(AudioTowerConfig(**ac.__dict__), aw, dev)(feats, [47])
+    assert torch.equal(th.vision(px, [[1, 4, 6]]), v_ref) and torch.equal(th.audio(feats, [47]), a_ref)
+    ids = torch.tensor([[5, 6, 393] + [390] * 6 + [396, 8, 9]])
+    ref = QwenOmniThinker(LlamaEngine(LLMConfig(**lcfg.__dict__), lw, dev, max_batch=1, max_len=128), th.vision, th.audio, th.ids)
+    kw = dict(pixel_values=px, image_grid_thw=torch.tensor([[1, 4, 6]]), max_new_tokens=4)
+    assert torch.equal(th.generate(ids, None, **kw), ref.generate(ids, None, **kw))
