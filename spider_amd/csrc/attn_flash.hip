@@ -178,31 +178,48 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 }
             m_run = m_new;
         } else {
-            const unsigned long long kbits = p.keep_bits ? p.keep_bits[t] : ~0ull;
+            // Branch-free masked tile: an invisible key's score becomes -1e30, so exp2 returns exactly 0 for it and no second
+            // predicate is needed (per-element `ok ? exp2f(..) : 0` compiled to 32 divergent branches per tile -- the whole
+            // consistent-self-attention path and every causal diagonal tile went through them).
+            const int key0 = t * 64 + 4 * h32;                       // key = key0 + kt*32 + (r&3) + 8*(r>>2)
+            const int hi_lim = p.causal ? min(lk_end, caus_max + 1) : lk_end;
             float tmax = -1e30f;
-            unsigned vis = 0u;  // bit (kt*16 + r)
+            if (p.keep_bits) {
+                const unsigned long long kl = p.keep_bits[t] >> (4 * h32);
+                const uint32_t klo = (uint32_t)kl, khi = (uint32_t)(kl >> 32);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h32;
-                    const int key = t * 64 + kk;
-                    bool ok = key < lk_end && key >= kbeg;
-                    if (p.causal) ok = ok && key <= caus_max;
-                    if (p.keep_bits) ok = ok && (((kbits >> kk) & 1ull) || (key >= own_lo && key < own_hi));
-                    vis |= ok ? (1u << (kt * 16 + r)) : 0u;
-                    const float sv = s[kt][r] * p.scale_log2e;
-                    s[kt][r] = sv;
-                    tmax = fmaxf(tmax, ok ? sv : -1e30f);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = kt * 32 + (r & 3) + 8 * (r >> 2);
+                        const int key = key0 + off;
+                        const uint32_t keep = ((off < 32 ? klo : khi) >> (off & 31)) & 1u;
+                        const bool ok = (key >= kbeg) & (key < hi_lim) & ((keep != 0u) | ((key >= own_lo) & (key < own_hi)));
+                        const float sv = ok ? s[kt][r] * p.scale_log2e : -1e30f;
+                        s[kt][r] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2);
+                        const bool ok = (key >= kbeg) & (key < hi_lim);
+                        const float sv = ok ? s[kt][r] * p.scale_log2e : -1e30f;
+                        s[kt][r] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax);
             alpha = exp2f(m_run - m_new);
+            const float m_use = m_new < -1e29f ? 0.f : m_new;     // row with no visible key so far: keep every p at 0
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = ((vis >> (kt * 16 + r)) & 1u) ? exp2f(s[kt][r] - m_new) : 0.f;
+                    const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
                     s[kt][r] = pv;
                     psum += pv;
                 }
