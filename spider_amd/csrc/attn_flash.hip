@@ -100,16 +100,27 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     float m_run = -1e30f, l_run = 0.f;
 
     u32x4 rk[C::NCH], rv[C::NCH];
-    const u32x4 zero = {0u, 0u, 0u, 0u};
+    // K / V rows through buffer descriptors: a chunk outside the tile's keys / the head dim gets an all-ones offset and reads
+    // zeros in hardware -- no per-load branch (with `ok ? load : 0` the loop carried 4 divergent branches per tile).
+    // Ranges are clamped to 4 GiB - 1; attention operands of this path are far below that.
+    auto span = [&](long rs) { const long b_ = ((long)(lk_end - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, span(p.k_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, span(p.v_rs), 0x00020000);
+    uint32_t ld_row[C::NCH], ld_cb[C::NCH], ld_inv[C::NCH];
+#pragma unroll
+    for (int i = 0; i < C::NCH; ++i) {
+        const int c = tid + i * 256;
+        ld_row[i] = (uint32_t)(c / C::CPR);
+        ld_cb[i] = (uint32_t)(c % C::CPR) * 16u;
+        ld_inv[i] = ((c < 64 * C::CPR) && (c % C::CPR) * 8 < p.d) ? 0u : 0xFFFFFFFFu;
+    }
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / C::CPR, ch = c % C::CPR;
-            const int key = t * 64 + row;
-            const bool ok = (c < 64 * C::CPR) && key < lk_end && ch * 8 < p.d;
-            rk[i] = ok ? *reinterpret_cast<const u32x4*>(kb + (long)key * p.k_rs + ch * 8) : zero;
-            rv[i] = ok ? *reinterpret_cast<const u32x4*>(vb + (long)key * p.v_rs + ch * 8) : zero;
+            const int key = t * 64 + (int)ld_row[i];
+            const uint32_t inv = ld_inv[i] | (uint32_t)((lk_end - 1 - key) >> 31);
+            rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, ((uint32_t)key * (uint32_t)p.k_rs * 2u + ld_cb[i]) | inv, 0, 0));
+            rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)key * (uint32_t)p.v_rs * 2u + ld_cb[i]) | inv, 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -324,6 +335,7 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
     SPIDER_CHECK(q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 && o_hs % 4 == 0, "attn: head strides must keep 16-byte alignment");
     SPIDER_CHECK(q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 4 == 0, "attn: batch strides must keep 16-byte alignment");
     SPIDER_CHECK(!keep_bits || blk > 0, "attn: keep_bits needs the image block length");
+    SPIDER_CHECK((long)Lk * k_rs * 2 < (1L << 32) && (long)Lk * v_rs * 2 < (1L << 32), "attn: one (batch, head) K / V view must span < 4 GiB");
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
     a.q_bs = q_bs; a.q_hs = q_hs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_rs = k_rs;
@@ -349,6 +361,7 @@ int spider_attn_varlen_bf16(const void* q, const void* k, const void* v, void* o
     SPIDER_CHECK(total_rows > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && n_tiles > 0 && tiles, "attn_varlen: bad shape");
     SPIDER_CHECK(d > 0 && d % 8 == 0 && d <= 160, "attn_varlen: head_dim must be a multiple of 8 and <= 160");
     SPIDER_CHECK(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0, "attn_varlen: row strides must keep 16-byte alignment");
+    SPIDER_CHECK((long)total_rows * k_rs * 2 < (1L << 32) && (long)total_rows * v_rs * 2 < (1L << 32), "attn_varlen: K / V views must span < 4 GiB");
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
     a.q_hs = a.k_hs = a.v_hs = a.o_hs = d;
