@@ -76,10 +76,11 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
 
 // GroupNorm, pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU; output bf16.
 // Rounds once after the affine (as torch's GroupNorm does) and once more after SiLU.
+template <bool SILU>
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
                                 const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                 bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
-                                float eps, int silu, int pix_per_block, int KP) {
+                                float eps, int pix_per_block, int KP) {
     // Block = (C/8)*KP threads like pass 1: a thread owns one 8-channel vector for all its pixels, so the per-channel
     // scale a_c = rstd_g * gamma_c and shift b_c = beta_c - mean_g * a_c live in 16 registers and the inner loop is one fma
     // (+ SiLU) per element -- no per-element group lookup (an integer division by a runtime C/G and two LDS reads before).
@@ -156,7 +157,7 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
             for (int j = 0; j < 8; ++j) {
                 const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
                 float t = fmaf(xv, ca[j], cb[j]);
-                if (silu) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
+                if (SILU) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
                 o[j] = t;
             }
             u32x4 ov;
@@ -170,10 +171,10 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
 // GroupNorm for small feature maps (HW <= 256): ONE launch, one block per (group, batch); the group's data
 // (HW x cpg values, 4-byte pairs, L2-resident) is read twice by the same block. Replaces the stats + apply pair
 // whose two launches dominate at 16x16 / 8x8 latents.
-template <int MAXP>
+template <int MAXP, bool SILU>
 __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
                                                        const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C,
-                                                       int G, float eps, int silu) {
+                                                       int G, float eps) {
     __shared__ float red[4];
     // MAXP channel pairs per thread: HW * cpg / 2 <= 256 * MAXP (host-checked)
     const int g = blockIdx.x, b = blockIdx.y;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
             const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + cp2);
             float lo = (bf16lo_to_f32(v[u]) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
             float hi = (bf16hi_to_f32(v[u]) - mu) * rs * bf16hi_to_f32(gv) + bf16hi_to_f32(bv);
-            if (silu) {
+            if (SILU) {
                 lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
                 hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
             }
@@ -740,8 +741,10 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
     if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
         // (measured: a 40-pair variant for 20K-element groups is no faster than the stats + apply pair -- 64 blocks cannot
         // pull enough bandwidth)
-        gn_small_kernel<20><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                                        (bf16_t*)y, HW, C, G, eps, silu);
+        if (silu) gn_small_kernel<20, true><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
+                                                                                        (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps);
+        else gn_small_kernel<20, false><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
+                                                                                     (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps);
         SPIDER_LAUNCH_OK();
         return 0;
     }
@@ -759,8 +762,10 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
     while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;   // keep the grid at <= ~4 blocks per CU
     SPIDER_CHECK(threads >= 128 || threads >= 2 * G, "groupnorm: too few channels for the block layout");
     dim3 g2((HW + ppb - 1) / ppb, B);
-    gn_apply_kernel<<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
-                                                             (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, silu, ppb, KP);
+    if (silu) gn_apply_kernel<true><<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
+                                                                       (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    else gn_apply_kernel<false><<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
+                                                                    (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
     SPIDER_LAUNCH_OK();
     return 0;
 }
