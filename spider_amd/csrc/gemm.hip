@@ -596,17 +596,27 @@ template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
     const int n4 = (p.N + 3) / 4;
     const size_t total = (size_t)p.M * n4;
+    const size_t slab = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splits; ++s) {
-            const float* src = p.ws + ((size_t)s * p.M + m) * p.N + n;
-            if (n + 3 < p.N) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-            } else {
-                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[e];
+        const float* src = p.ws + (size_t)m * p.N + n;
+        if (n + 3 < p.N) {
+            // slabs four at a time with INDEPENDENT loads (a one-load-per-iteration loop serialises the round trips); the tail
+            // re-reads the last slab with weight 0 instead of branching
+            for (int s0 = 0; s0 < p.splits; s0 += 4) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(s0 + u, p.splits - 1) * slab);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float w = s0 + u < p.splits ? 1.f : 0.f;
+                    v[0] += w * t[u][0]; v[1] += w * t[u][1]; v[2] += w * t[u][2]; v[3] += w * t[u][3];
+                }
             }
+        } else {
+            for (int s = 0; s < p.splits; ++s)
+                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[(size_t)s * slab + e];
         }
         epilogue_store<EPI>(p, m, n, v);
     }
