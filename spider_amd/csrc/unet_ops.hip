@@ -293,6 +293,14 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
     const u32x4* xv = reinterpret_cast<const u32x4*>(x + (size_t)row * C);
     float h[VPL][8];
     float s = 0.f;
+    // gamma / beta are requested together with the row (they do not depend on the statistics): one memory round trip, not two
+    u32x4 gq[VPL], bq[VPL];
+#pragma unroll
+    for (int it = 0; it < VPL; ++it) {
+        const int i = min(lane + it * 64, nv - 1);
+        gq[it] = *reinterpret_cast<const u32x4*>(gamma + i * 8);
+        bq[it] = *reinterpret_cast<const u32x4*>(beta + i * 8);
+    }
 #pragma unroll
     for (int it = 0; it < VPL; ++it) {
         const int i = lane + it * 64;
@@ -321,9 +329,7 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
     for (int it = 0; it < VPL; ++it) {
         const int i = lane + it * 64;
         if (i < nv) {
-            const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + i * 8);
-            const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + i * 8);
-            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq.x, bq.y, bq.z, bq.w};
+            const uint32_t gw[4] = {gq[it].x, gq[it].y, gq[it].z, gq[it].w}, bw[4] = {bq[it].x, bq[it].y, bq[it].z, bq[it].w};
             u32x4 ov;
             ov.x = pack_bf16x2((h[it][0] - mu) * rs * bf16lo_to_f32(gw[0]) + bf16lo_to_f32(bw[0]), (h[it][1] - mu) * rs * bf16hi_to_f32(gw[0]) + bf16hi_to_f32(bw[0]));
             ov.y = pack_bf16x2((h[it][2] - mu) * rs * bf16lo_to_f32(gw[1]) + bf16lo_to_f32(bw[1]), (h[it][3] - mu) * rs * bf16hi_to_f32(gw[1]) + bf16hi_to_f32(bw[1]));
