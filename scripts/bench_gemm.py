@@ -17,6 +17,16 @@ SHAPES = [  # (tag, M, N, K, conv_cin or 0, hw)
     ("c8 1280>1280", 128, 1280, 11520, 1280, 8), ("c8 2560>1280", 128, 1280, 23040, 2560, 8),
 ]
 
+if os.environ.get("SHAPES") == "sdxl":   # SDXL story step at 768^2, CFG batch 8: 48x48 (C=640) and 24x24 (C=1280) token maps
+    SHAPES = [
+        ("x48 qkv", 18432, 1920, 640, 0, 0), ("x48 out", 18432, 640, 640, 0, 0), ("x48 ff2", 18432, 640, 2560, 0, 0),
+        ("x48 q", 18432, 640, 640, 0, 0),
+        ("x24 qkv", 4608, 3840, 1280, 0, 0), ("x24 out", 4608, 1280, 1280, 0, 0), ("x24 ff2", 4608, 1280, 5120, 0, 0),
+        ("c96 320>320", 73728, 320, 2880, 320, 96), ("c48 640>640", 18432, 640, 5760, 640, 48), ("c48 320>640", 18432, 640, 2880, 320, 48),
+        ("c24 1280>1280", 4608, 1280, 11520, 1280, 24), ("c24 640>1280", 4608, 1280, 5760, 640, 24), ("c48 1280>640", 18432, 640, 11520, 1280, 48),
+        ("c24 2560>1280", 4608, 1280, 23040, 2560, 24),
+    ]
+
 
 def child():
     from spider_amd import ops
@@ -24,7 +34,7 @@ def child():
     out = {}
     for tag, M, N, K, cin, hw in SHAPES:
         if cin:
-            x = torch.randn(2, hw, hw, cin, device=dev).bfloat16()
+            x = torch.randn(M // (hw * hw), hw, hw, cin, device=dev).bfloat16()
             w = (torch.randn(N, 3, 3, cin, device=dev) * 0.02).bfloat16()
             f = lambda: ops.conv2d(x, w)
         else:

@@ -726,14 +726,20 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // plain linears only with a long K (at K = 1280 the tower / FF projections measured slower on it).
     const int n160 = (a.N + 159) / 160;
     if (!force_tile && !a.geglu && a.M >= (a.conv ? 512 : 2048) && nk >= (a.conv && a.M >= 2048 ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
-        dma_bn = 160;
         const int tdma = ((a.M + 127) / 128) * n160;
-        splits = 1;
+        int ds = 1;
         if (nk >= 40) {
-            splits = (256 + tdma / 2) / tdma;
-            if (splits > 8) splits = 8;
-            if (splits > nk / 8) splits = nk / 8;
-            if (splits < 1) splits = 1;
+            ds = (256 + tdma / 2) / tdma;
+            if (ds > 8) ds = 8;
+            if (ds > nk / 8) ds = nk / 8;
+            if (ds < 1) ds = 1;
+        }
+        // one block per CU: a grid just above a multiple of 256 leaves most of the chip idle in its last round (SDXL 24^2 convs:
+        // 288 tiles = 2 rounds at 56 % -> 260 us vs 199 us on the 2-blocks-per-CU kernel; 96^2: 1152 tiles = 90 % -> 190 vs 212)
+        const int blocks = tdma * ds, rounds = (blocks + 255) / 256;
+        if (blocks <= 256 || blocks * 100 >= rounds * 256 * 85) {
+            dma_bn = 160;
+            splits = ds;
         }
     }
     if (!a.ws || splits < 1 || a.geglu) splits = 1;
