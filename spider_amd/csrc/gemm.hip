@@ -702,7 +702,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         if (splits < nk / 32) splits = nk / 32;    // ... and never leave one block with hundreds of K tiles (down_proj)
         if (splits > 8) splits = 8;
         if (splits > nk / 8) splits = nk / 8;
-    } else if (t128 >= 384) {
+    } else if (t128 >= 320) {
         // (re-measured with the per-epilogue instantiations, scripts/bench_gemm_k.py: once the 128^2 kernel's code fits
         // the instruction cache it wins for every K >= 320 at these sizes -- 8192x2560x320: 40.8 vs 45.1 us)
         small = false;
