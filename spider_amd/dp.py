@@ -58,7 +58,10 @@ def gather_padded(local: Dict[str, torch.Tensor], counts_max: int, rank: int, wo
         pad = torch.zeros((counts_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
         pad[:n_local] = t
         b = pad.contiguous().view(torch.uint8).reshape(-1)
-        meta.append((nme, t.dtype, (counts_max,) + tuple(t.shape[1:]), b.numel()))
+        nb = b.numel()
+        if nb % 16:   # every field starts 16-byte aligned in the flat buffer (a wider dtype may follow an odd-sized uint8 field)
+            b = torch.cat([b, torch.zeros(16 - nb % 16, dtype=torch.uint8, device=dev)])
+        meta.append((nme, t.dtype, (counts_max,) + tuple(t.shape[1:]), nb, b.numel()))
         parts.append(b)
     parts.append(torch.tensor([n_local], dtype=torch.int32, device=dev).view(torch.uint8))
     flat = torch.cat(parts)
@@ -70,9 +73,9 @@ def gather_padded(local: Dict[str, torch.Tensor], counts_max: int, rank: int, wo
         if rank != dst:
             return None
     out, off = {}, 0
-    for nme, dt, shp, nb in meta:
+    for nme, dt, shp, nb, padded in meta:
         out[nme] = torch.stack([b[off:off + nb].view(dt).reshape(shp) for b in bufs])
-        off += nb
+        off += padded
     out["count"] = torch.stack([b[off:off + 4].view(torch.int32) for b in bufs]).reshape(-1)
     return out
 

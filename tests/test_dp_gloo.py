@@ -29,10 +29,17 @@ def _worker(rank, world, port, n_items, q):
     per_rank_max = (n_items + world - 1) // world
     toks = torch.stack([torch.arange(6, dtype=torch.int32) + 100 * i for i in mine]) if mine else torch.zeros(0, 6, dtype=torch.int32)
     imgs = torch.stack([torch.full((3, 4, 4), i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 3, 4, 4, dtype=torch.uint8)
-    g = dp.gather_padded({"tokens": toks, "images": imgs}, per_rank_max, rank, world, dst=0)
+    # the any-to-many payload (scripts/bench_any2many.py): + float32 audio and 5-D uint8 video; the 7-byte "flags" field makes
+    # the following int32 field start unaligned unless the flat buffer pads every field
+    aud = torch.stack([torch.full((9,), i + 0.5, dtype=torch.float32) for i in mine]) if mine else torch.zeros(0, 9)
+    vid = torch.stack([torch.full((2, 3, 5, 3), i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 2, 3, 5, 3, dtype=torch.uint8)
+    flg = torch.stack([torch.full((7,), i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros(0, 7, dtype=torch.uint8)
+    g = dp.gather_padded({"tokens": toks, "images": imgs, "audio": aud, "video": vid, "flags": flg}, per_rank_max, rank, world, dst=0)
     if rank == 0:
         assert g["count"].tolist() == [len(dp.shard_indices(n_items, r_, world)) for r_ in range(world)]
         full = dp.unshard(g, n_items, world)
+        assert full["audio"][:, 0].tolist() == [i + 0.5 for i in range(n_items)] and full["video"].shape == (n_items, 2, 3, 5, 3)
+        assert full["video"][:, 1, 2, 4, 2].tolist() == list(range(n_items)) and full["flags"][:, 6].tolist() == list(range(n_items))
         q.put((full["tokens"][:, 0].tolist(), full["images"][:, 0, 0, 0].tolist()))
     else:
         assert g is None
