@@ -184,6 +184,38 @@ def measure_mfma_roofline(device):
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
+def measure_attention_roofline(device):
+    """The UNet's largest attention: self-attention at the 64x64 latent (4096 tokens, 8 heads, d = 40, CFG batch 2).
+    Algorithmic flops = 4 * N^2 * C * B (QK^T + PV, d = 40 as stored -- the kernel pads d to 64 inside its tiles)."""
+    from spider_amd import ops
+    N, heads, d, B = 4096, 8, 40, 2
+    C = heads * d
+    qkv = torch.randn(B, N, 3 * C, device=device).to(torch.bfloat16)
+    f = lambda: ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize(device)
+    n = 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            f()
+    g.replay()
+    torch.cuda.synchronize(device)
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    g.replay()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 4 * N * N * C * B
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "attn_flash_kernel<64> (UNet self-attention, 64x64 latent: 4096 tokens, 8 heads, d=40, batch 2)",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
+
+
 def cpu_baseline(args):
     """fp32 CPU oracle ("port") on a bounded sample, extrapolated linearly to one response."""
     from oracle.llama import LlamaCfg, LlamaOracle
@@ -320,6 +352,8 @@ def main():
                                                    "not the headline value"}
         roof = measure_roofline(resp, device)
         extra["roofline_unet_conv"] = measure_mfma_roofline(device)
+        extra["roofline_unet_attention"] = measure_attention_roofline(device)
+        extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / 2500.0, 4)
         c = resp.llm.cfg
         wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
         tok_s = extra["llm_decode_tokens_per_s"] / a.batch
