@@ -39,6 +39,14 @@ struct AttnArgs {
     int n_tiles;
 };
 
+// value of the partner lane (lane ^ 32) by v_permlane32_swap: a VALU op, where __shfl_xor(x, 32) is a ds_bpermute round trip
+// through the LDS crossbar on the critical path of every tile's softmax (twice)
+__device__ __forceinline__ float partner32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // lanes < 32: {v[l], v[l+32]}; lanes >= 32: {v[l-32], v[l]}
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 template <int DP>
 struct Cfg {
     static constexpr int KS = DP + 8;                                  // K LDS row stride (elements)
@@ -171,22 +179,26 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                                (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off);
         float psum = 0.f, alpha;
         if (full_tile) {
-            float tmax = s[0][0];
+            // four independent chains for the max and for the sum: a single 32-long dependent chain costs its full latency
+            float tm[4] = {s[0][0], s[0][1], s[0][2], s[0][3]};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kt][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2e;
+                for (int r = 0; r < 16; ++r) tm[r & 3] = fmaxf(tm[r & 3], s[kt][r]);
+            float tmax = fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3]));
+            tmax = fmaxf(tmax, partner32(tmax)) * p.scale_log2e;
             const float m_new = fmaxf(m_run, tmax);
             alpha = exp2f(m_run - m_new);
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][r], p.scale_log2e, -m_new));
                     s[kt][r] = pv;
-                    psum += pv;
+                    ps4[r & 3] += pv;
                 }
+            psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
             m_run = m_new;
         } else {
             // Branch-free masked tile: an invisible key's score becomes -1e30, so exp2 returns exactly 0 for it and no second
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                         tmax = fmaxf(tmax, sv);
                     }
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = fmaxf(tmax, partner32(tmax));
             const float m_new = fmaxf(m_run, tmax);
             alpha = exp2f(m_run - m_new);
             const float m_use = m_new < -1e29f ? 0.f : m_new;     // row with no visible key so far: keep every p at 0
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 }
             m_run = m_new;
         }
-        psum += __shfl_xor(psum, 32, 64);
+        psum += partner32(psum);
         l_run = l_run * alpha + psum;
         // rescale O only when some row of the wave actually moved its max (alpha == 1 exactly otherwise)
         if (__any(alpha != 1.f)) {
