@@ -55,7 +55,10 @@ struct Cfg {
     static constexpr int CPR = DP / 8;                                 // chunks per (padded) row
 };
 
-template <int DP>
+// ONES (head_dim < DP, e.g. the UNet's d = 40 / 80 in 64 / 96-wide tiles): the first padded V column is staged as 1.0, so
+// the PV MFMA accumulates the softmax denominator (of the bf16-rounded probabilities it actually multiplies) in an O^T
+// row that would otherwise hold zeros -- 32 adds per lane and K tile leave a loop whose SIMD issue port is the bottleneck.
+template <int DP, bool ONES>
 __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             const uint32_t inv = ld_inv[i] | (uint32_t)((lk_end - 1 - key) >> 31);
             rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, ((uint32_t)key * (uint32_t)p.k_rs * 2u + ld_cb[i]) | inv, 0, 0));
             rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)key * (uint32_t)p.v_rs * 2u + ld_cb[i]) | inv, 0, 0));
+            if (ONES) rv[i].x = (ld_cb[i] == (uint32_t)p.d * 2u && key < lk_end && tid + i * 256 < 64 * C::CPR) ? 0x3F80u : rv[i].x;   // V[key][d] = 1.0
         }
     };
     auto store_tile = [&](int buf) {
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 for (int r = 0; r < 16; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][r], p.scale_log2e, -m_new));
                     s[kt][r] = pv;
-                    ps4[r & 3] += pv;
+                    if (!ONES) ps4[r & 3] += pv;
                 }
-            psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            if (!ONES) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
             m_run = m_new;
         } else {
             // Branch-free masked tile: an invisible key's score becomes -1e30, so exp2 returns exactly 0 for it and no second
@@ -244,12 +248,14 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 for (int r = 0; r < 16; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
                     s[kt][r] = pv;
-                    psum += pv;
+                    if (!ONES) psum += pv;
                 }
             m_run = m_new;
         }
-        psum += partner32(psum);
-        l_run = l_run * alpha + psum;
+        if (!ONES) {
+            psum += partner32(psum);
+            l_run = l_run * alpha + psum;
+        }
         // rescale O only when some row of the wave actually moved its max (alpha == 1 exactly otherwise)
         if (__any(alpha != 1.f)) {
 #pragma unroll
@@ -298,6 +304,15 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     }
 
     // ---- epilogue: lane holds O[qi][db*32 + 8*(r>>2) + 4*h32 + (r&3)] ----
+    if (ONES) {   // the denominator sits in O^T row d: register 4*g of tile db on the lanes with h32 == 0
+        float l = 0.f;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (db * 32 + 8 * g == p.d) l = acc_o[db][4 * g];
+        l_run = __shfl(l, l32, 64);
+    }
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         bf16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
@@ -321,7 +336,8 @@ int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
     const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
-    attn_flash_kernel<DP><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    if (a.d < DP) attn_flash_kernel<DP, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    else attn_flash_kernel<DP, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
     SPIDER_LAUNCH_OK();
     return 0;
 }
