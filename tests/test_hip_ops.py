@@ -423,3 +423,24 @@ def test_conv_small_cout_8(ops, dev):
     y = ops.conv2d_small_cout(x.to(dev), w.to(dev), b.to(dev))
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1)
     close(y, ref, 2e-2, 1e-2, "conv_small_cout(8)", rel_to_std=True)
+
+
+@pytest.mark.parametrize("spike_tile", [0, 3, 17])
+def test_attention_late_max_jump(ops, dev, spike_tile):
+    """Online-softmax rescale exercised on purpose: the running max of one row jumps far above everything seen before at a chosen
+    KV tile (one key row aligned with one query row), and another row gets a modest bump
+    elsewhere. Full-tensor fp64 reference (random data alone rarely moves a max after the first tiles)."""
+    B, N, heads, d = 1, 64 * 20, 2, 40
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(B, N, heads * d, generator=g) * 0.5
+    k = torch.randn(B, N, heads * d, generator=g) * 0.5
+    v = torch.randn(B, N, heads * d, generator=g)
+    row = 5
+    k[0, spike_tile * 64 + 11, :d] = q[0, row, :d] * 40.0          # head 0, query 5: score ~ 40 * |q|^2 / sqrt(d) >> threshold
+    k[0, 64 * 9 + 3, d:] = q[0, row + 1, d:] * 1.5                 # head 1, query 6: a modest bump, below the threshold
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads).float().cpu()
+    qd, kd, vd = [t.double().view(B, N, heads, d).transpose(1, 2) for t in (q, k, v)]
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(d), -1) @ vd).transpose(1, 2).reshape(B, N, heads * d).float()
+    close(out, ref, 2e-2, 1e-2, "attention deferred rescale")
+    assert float((out[0, row, :d] - v[0, spike_tile * 64 + 11, :d].float()).abs().max()) < 0.05   # the spiked key takes all the weight
