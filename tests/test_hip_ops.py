@@ -442,5 +442,5 @@ def test_attention_late_max_jump(ops, dev, spike_tile):
     out = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads).float().cpu()
     qd, kd, vd = [t.double().view(B, N, heads, d).transpose(1, 2) for t in (q, k, v)]
     ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(d), -1) @ vd).transpose(1, 2).reshape(B, N, heads * d).float()
-    close(out, ref, 2e-2, 1e-2, "attention deferred rescale")
+    close(out, ref, 2e-2, 1e-2, "attention late max jump")
     assert float((out[0, row, :d] - v[0, spike_tile * 64 + 11, :d].float()).abs().max()) < 0.05   # the spiked key takes all the weight
