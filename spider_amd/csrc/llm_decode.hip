@@ -647,10 +647,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     const size_t bh = blockIdx.x;  // b * n_q + hq
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
-    for (int s0 = wave; s0 < nsplit; s0 += 32) {       // 8 independent (m,l) + O loads in flight per wave
-        float2 mlv[8], ovv[8];
+    for (int s0 = wave; s0 < nsplit; s0 += 64) {       // 16 independent (m,l) + O loads in flight per wave: 64 splits = ONE round trip
+        float2 mlv[16], ovv[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int s = s0 + 4 * u;
             const bool ok = s < nsplit;
             const size_t pi = bh * nsplit + (ok ? s : 0);
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
             if (!ok) mlv[u] = float2{-INFINITY, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const float ms = mlv[u].x, ls = mlv[u].y;
             const float mn = fmaxf(m, ms);
             const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
