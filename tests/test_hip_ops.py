@@ -139,7 +139,9 @@ def test_attn_decode(ops, dev, B, n_q, n_kv, T, nsplit, beg):
 
 # ------------------------------------------------------------------------------------------ GEMM / conv / attention
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1536, 4608, 3584), (77, 320, 768), (8192, 320, 320), (200, 36, 72),
-                                   (1, 1280, 320), (130, 132, 1032)])
+                                   (1, 1280, 320), (130, 132, 1032),
+                                   (4096, 320, 2560),      # long-K linear with >= 2048 rows: the LDS-DMA kernel, 4 K splits
+                                   (2100, 312, 2568)])     # same path with ragged M / N / K tails (N, K multiples of 8 / 4 only)
 def test_gemm(ops, dev, M, N, K):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     ref = A.float() @ W.float().T
@@ -159,7 +161,9 @@ def test_gemm(ops, dev, M, N, K):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [(2, 16, 16, 64, 128, 3, 1, False), (2, 64, 64, 320, 320, 3, 1, False),
                                                           (1, 16, 12, 128, 64, 3, 2, False), (2, 8, 8, 128, 128, 3, 1, True),
-                                                          (2, 16, 16, 192, 64, 1, 1, False), (1, 9, 7, 64, 68, 3, 1, False)])
+                                                          (2, 16, 16, 192, 64, 1, 1, False), (1, 9, 7, 64, 68, 3, 1, False),
+                                                          (2, 16, 16, 640, 1280, 3, 1, False),    # 16^2 map: LDS-DMA kernel, 8 K splits
+                                                          (2, 64, 64, 320, 320, 3, 2, False)])    # stride 2 on the DMA path (M = 2048)
 def test_conv2d(ops, dev, B, H, W, Cin, Cout, ks, stride, ups):
     x, w, bias = rnd(B, H, W, Cin, seed=1), rnd(Cout, ks, ks, Cin, seed=2, scale=0.05), rnd(Cout, seed=3)
     xin = x.float().permute(0, 3, 1, 2)
