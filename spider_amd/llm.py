@@ -329,11 +329,10 @@ class LlamaEngine:
                 raise ValueError("position_ids with 3 components need a model with mrope_section (Qwen2.5-Omni thinker)")
             if tuple(position_ids.shape) != (3, B, S):
                 raise ValueError(f"position_ids must be [3, {B}, {S}], got {tuple(position_ids.shape)}")
-            if has_pad:
-                raise NotImplementedError("multimodal position_ids together with left padding")
             pos3 = position_ids.to(device=dv, dtype=torch.int32).contiguous()
-            h = self._prefill(h0.view(B * S, -1), pos3.view(3, -1), slot2d.view(-1), None, B, S, step0, mrope=True)
-            next_pos = pos3.amax(dim=(0, 2)) + 1
+            h = self._prefill(h0.view(B * S, -1), pos3.view(3, -1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0, mrope=True)
+            # left-padded rows: the pad slots carry a dummy position (get_rope_index writes 1 there) and are masked by kv_beg
+            next_pos = torch.where(am.bool()[None], pos3, torch.zeros_like(pos3)).amax(dim=(0, 2)) + 1
         else:
             h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
             next_pos = pos2d[:, -1] + 1

@@ -631,9 +631,7 @@ class QwenOmniThinker:
                       "feature_attention_mask", "audio_feature_lengths", "use_audio_in_video", "video_second_per_grid")
         emb, pos = self.prepare_inputs(input_ids, attention_mask, **{k: kw.pop(k) for k in tower_keys if k in kw})
         kw.pop("spk", None); kw.pop("return_audio", None)                          # talker options: no speech on this path
-        if attention_mask is not None and bool((attention_mask == 0).any()):
-            raise NotImplementedError("padded batches: call generate per prompt (the reference demo sends one conversation)")
-        out = self.llm.generate(inputs_embeds=emb, position_ids=pos, max_new_tokens=max_new_tokens, **kw)
+        out = self.llm.generate(inputs_embeds=emb, position_ids=pos, attention_mask=attention_mask, max_new_tokens=max_new_tokens, **kw)
         if isinstance(out, torch.Tensor):
             return torch.cat([input_ids.to(out.device).long(), out], 1)
         out.sequences = torch.cat([input_ids.to(out.sequences.device).long(), out.sequences], 1)

@@ -264,3 +264,34 @@ def test_from_pretrained_reads_the_omni_checkpoint_layout(dev, tmp_path):
     ref = QwenOmniThinker(LlamaEngine(LLMConfig(**lcfg.__dict__), lw, dev, max_batch=1, max_len=128), th.vision, th.audio, th.ids)
     kw = dict(pixel_values=px, image_grid_thw=torch.tensor([[1, 4, 6]]), max_new_tokens=4)
     assert torch.equal(th.generate(ids, None, **kw), ref.generate(ids, None, **kw))
+
+
+@pytest.mark.gpu
+def test_thinker_left_padded_batch_equals_single_prompts(dev):
+    """`padding=True` batches of the processor (qwen2.5omni_spider_web.py:466): a left-padded batch of an image prompt and a
+    shorter text-only prompt generates exactly what each prompt generates on its own (pad slots are masked, their dummy
+    rotary positions never enter a visible key, decode positions continue from each row's own maximum)."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    from spider_amd.qwen_omni import OmniTokenIds, QwenOmniThinker, VisionTowerConfig, VisionTowerEngine
+    H = 256
+    lcfg = LlamaCfg(H, 2, 4, 2, 128, 512, 400, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
+    lw = LlamaOracle.random_weights(lcfg, seed=17, std=0.08)
+    vc = oq.VisionCfg(depth=2, hidden=64, heads=2, inter=88, in_channels=3, patch=4, temporal_patch=2, merge=2, window=16,
+                      out_hidden=H, fullatt=(1,), eps=1e-6)
+    vw = oq.random_weights(oq.vision_param_shapes(vc), seed=18)
+    tok = OmniTokenIds(image=390, video=391, audio=392, vision_start=393, audio_start=394)
+    llm = LlamaEngine(LLMConfig(**lcfg.__dict__), lw, dev, max_batch=2, max_len=128)
+    th = QwenOmniThinker(llm, VisionTowerEngine(VisionTowerConfig(**vc.__dict__), vw, dev), None, tok)
+    px = torch.randn(24, vc.patch_dim, generator=torch.Generator().manual_seed(5)).bfloat16().float()
+    grid = torch.tensor([[1, 4, 6]])
+    a = [5, 6, 393] + [390] * 6 + [396, 8, 9, 10, 11, 12, 13, 14, 15]      # 18 tokens, one image
+    b = [21, 22, 23, 24, 25, 26, 27, 28, 29, 30]                            # 10 tokens, text only
+    pad = len(a) - len(b)
+    ids = torch.tensor([a, [0] * pad + b])
+    am = torch.tensor([[1] * len(a), [0] * pad + [1] * len(b)])
+    both = th.generate(ids, am, max_new_tokens=6, pixel_values=px, image_grid_thw=grid)
+    one_a = th.generate(torch.tensor([a]), torch.ones(1, len(a), dtype=torch.long), max_new_tokens=6, pixel_values=px, image_grid_thw=grid)
+    one_b = th.generate(torch.tensor([b]), torch.ones(1, len(b), dtype=torch.long), max_new_tokens=6)
+    assert torch.equal(both[0], one_a[0])
+    assert torch.equal(both[1, pad:], one_b[0])
