@@ -55,6 +55,11 @@ class UNetCfg:
                        (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (128, 256, 384, 640))
 
     @staticmethod
+    def audioldm_l():   # cvssp/audioldm-l-full unet/config.json: the decoder the reference configures (train_configs/spider_decoder_cfg.py:37)
+        return UNetCfg(8, 8, (256, 512, 768, 1280), (False, True, True, True), (True, True, True, False), (1, 1, 1, 1),
+                     (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (256, 512, 768, 1280))
+
+    @staticmethod
     def tiny_audio():
         return UNetCfg(8, 8, (64, 128, 128), (False, True, True), (True, True, False), (1, 1, 1), (2, 4, 4), 2, 0, 32,
                        False, 0, 0, None, 48, True, (64, 128, 128))

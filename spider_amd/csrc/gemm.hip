@@ -822,8 +822,10 @@ int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* 
     const int ups = (up_h > 0 || up_w > 0) ? 1 : 0;
     if (ups) {
         SPIDER_CHECK(stride == 1, "conv: fused upsample requires stride 1");
-        SPIDER_CHECK(up_h > Hin && up_h <= 2 * Hin && up_w > Win && up_w <= 2 * Win,
-                     "conv: upsampled size must lie in (in, 2*in] per axis");
+        // the kernel reads source row iy >> 1: that is F.interpolate(size=..., mode="nearest") (floor(dst * in / out)) only
+        // for out = 2*in and out = 2*in - 1 (the sizes Upsample2D's `upsample_size` rule produces for odd skip maps)
+        SPIDER_CHECK((up_h == 2 * Hin || up_h == 2 * Hin - 1) && (up_w == 2 * Win || up_w == 2 * Win - 1),
+                     "conv: fused nearest upsample supports output sizes 2*in and 2*in-1 per axis");
     }
     const int Hs = ups ? up_h : Hin, Ws = ups ? up_w : Win;
     const int Hout = (Hs + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wout = (Ws + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;

@@ -94,6 +94,71 @@ def rope_table(cfg: LLMConfig, n_pos: int) -> torch.Tensor:
     return torch.cat([fr.cos(), fr.sin()], dim=-1).contiguous()
 
 
+def read_generation_config(path: str) -> dict:
+    """The defaults HF `generate` takes from the checkpoint when the caller passes none (the reference's
+    `model.generate(**inputs, spk=..., use_audio_in_video=True)`, qwen2.5omni_spider_web.py:468, and
+    `r1_llama3_8B_chat.py:14` rely on them): eos_token_id (int or list), pad_token_id, max_new_tokens / max_length,
+    and Qwen2.5-Omni's thinker_max_new_tokens. generation_config.json wins over config.json, as in transformers."""
+    import json
+    gc: dict = {}
+    for name in ("config.json", "generation_config.json"):
+        f = os.path.join(path, name)
+        if not os.path.exists(f):
+            continue
+        d = json.load(open(f))
+        srcs = [d]
+        if name == "config.json" and "thinker_config" in d:
+            srcs += [d["thinker_config"], d["thinker_config"].get("text_config", {})]
+        for src in srcs:
+            for k in ("eos_token_id", "pad_token_id", "bos_token_id", "max_new_tokens", "max_length",
+                      "thinker_max_new_tokens", "thinker_eos_token_id"):
+                if src.get(k) is not None:
+                    gc[k] = src[k]
+    return gc
+
+
+def _id_list(v) -> Optional[List[int]]:
+    if v is None:
+        return None
+    return [int(v)] if isinstance(v, int) else [int(x) for x in v]
+
+
+def finalize_greedy(tokens: torch.Tensor, eos: Optional[List[int]], pad: Optional[int], stopping_criteria,
+                    prompt: Optional[torch.Tensor], checked: int = 0):
+    """HF greedy-search bookkeeping (`_sample` with do_sample=False, as driven by spider.py:1492-1508), applied to a
+    block of already generated tokens [B, n] (CPU int64):
+      * a row is finished after its first EOS token; every later token of that row is pad_token_id
+        (`next_tokens * unfinished + pad * (1 - unfinished)`);
+      * the loop ends at the first length k where every row is finished, or where a stopping criterion returns True
+        (StoppingCriteriaSub, spider.py:55-73, looks at sequence 0 and ends the whole batch);
+    Returns (tokens with pads applied, k, stopped). `checked` = lengths < checked were already examined (the criteria
+    are re-run only on the new prefixes, so `sync_every` > 1 finds the exact stop step after the fact)."""
+    B, n = tokens.shape
+    tk = tokens.clone()
+    if eos:
+        is_eos = torch.isin(tk, torch.tensor(eos))
+        seen = is_eos.long().cumsum(1)
+        after = (seen - is_eos.long()) > 0          # strictly after the row's first EOS
+        if pad is None:
+            pad = eos[0]                            # HF: "Setting pad_token_id to eos_token_id"
+        tk[after] = pad
+        done_at = torch.where(is_eos.any(1), is_eos.long().argmax(1) + 1, torch.full((B,), n + 1))
+        k_eos = int(done_at.max())                  # all rows finished once the slowest has emitted its EOS
+    else:
+        k_eos = n + 1
+    k_sc = n + 1
+    if stopping_criteria:
+        for k in range(max(1, checked), min(n, k_eos) + 1):
+            seq = tk[:, :k] if prompt is None else torch.cat([prompt, tk[:, :k]], 1)
+            if any(bool(torch.as_tensor(sc(seq, None)).all()) for sc in stopping_criteria):
+                k_sc = k
+                break
+    k = min(k_eos, k_sc)
+    if k <= n:
+        return tk[:, :k], k, True
+    return tk, n, False
+
+
 class GenerateOutput:
     def __init__(self, sequences, hidden_states=None):
         self.sequences = sequences
@@ -118,6 +183,8 @@ class StoppingCriteriaSub:
 
 
 class LlamaEngine:
+    DECODE_ROWS = 8     # sequences per decode graph (lm_head / split-KV workspaces are sized for 8)
+
     def __init__(self, cfg: LLMConfig, weights: dict, device="cuda:0", max_batch: int = 1, max_len: int = 4096):
         self.cfg, self.device = cfg, torch.device(device)
         self.max_batch, self.max_len = max_batch, max_len
@@ -185,7 +252,9 @@ class LlamaEngine:
                     kk = k.replace("thinker.model.", "model.").replace("thinker.lm_head.", "lm_head.")
                     if kk.startswith("model.") or kk.startswith("lm_head."):
                         w[kk] = sf.get_tensor(k)
-        return cls(cfg, w, device, max_batch, max_len)
+        eng = cls(cfg, w, device, max_batch, max_len)
+        eng.generation_config = read_generation_config(path)
+        return eng
 
     def _alloc(self):
         c, dv, B, T = self.cfg, self.device, self.max_batch, self.max_len
@@ -287,8 +356,8 @@ class LlamaEngine:
     # ------------------------------------------------------------------ public generate
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
-                 attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 16,
-                 stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None,
+                 attention_mask: Optional[torch.Tensor] = None, max_new_tokens: Optional[int] = None,
+                 stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None, pad_token_id=None,
                  output_hidden_states: bool = False, return_dict_in_generate: bool = False,
                  num_beams: int = 1, do_sample: bool = False, use_cache: bool = True, output_attentions: bool = False,
                  use_graph: bool = True, sync_every: int = 1, return_logits: bool = False,
@@ -298,11 +367,28 @@ class LlamaEngine:
         conditions only every N tokens (one device->host copy per check instead of per token).
         position_ids [3, B, S]: multimodal (t, h, w) rotary positions of the prompt (Qwen2.5-Omni thinker with image / audio
         embeddings spliced into inputs_embeds; cfg.mrope_section required). Generated tokens continue at
-        max(position_ids) + 1 on all three components, as transformers' rope_deltas bookkeeping does."""
+        max(position_ids) + 1 on all three components, as transformers' rope_deltas bookkeeping does.
+        eos_token_id / pad_token_id / max_new_tokens default to the checkpoint's generation config (HF behaviour):
+        a row is finished at its first EOS and padded with pad_token_id afterwards; the call returns when every row is
+        finished. More than DECODE_ROWS (8) rows are processed in groups of 8 (rows are independent)."""
         if num_beams != 1 or do_sample:
             raise NotImplementedError("the reference path is greedy: num_beams=1, do_sample=False (spider.py:1471-1477)")
         c, dv = self.cfg, self.device
+        gc = getattr(self, "generation_config", None) or {}
+        if eos_token_id is None:
+            eos_token_id = gc.get("eos_token_id")
+        if pad_token_id is None:
+            pad_token_id = gc.get("pad_token_id")
         embeds_only = input_ids is None
+        S_in = inputs_embeds.shape[1] if embeds_only else input_ids.shape[1]
+        if max_new_tokens is None:   # HF: generation_config.max_new_tokens, else max_length (default 20) counts the prompt
+            max_new_tokens = gc.get("max_new_tokens") or max(1, int(gc.get("max_length", 20)) - (0 if embeds_only else S_in))
+        B_all = inputs_embeds.shape[0] if embeds_only else input_ids.shape[0]
+        if B_all > self.DECODE_ROWS:
+            return self._generate_grouped(input_ids, inputs_embeds, attention_mask, position_ids, B_all, dict(
+                max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria, eos_token_id=eos_token_id,
+                pad_token_id=pad_token_id, output_hidden_states=output_hidden_states, use_graph=use_graph,
+                sync_every=sync_every, return_logits=return_logits), return_dict_in_generate)
         if embeds_only:
             h0 = inputs_embeds.to(device=dv, dtype=BF16).contiguous()
             B, S = h0.shape[0], h0.shape[1]
@@ -313,8 +399,6 @@ class LlamaEngine:
         if B > self.max_batch or S + max_new_tokens > self.max_len:
             raise ValueError(f"batch {B} / length {S}+{max_new_tokens} exceed the preallocated KV cache "
                              f"({self.max_batch} x {self.max_len})")
-        if B > 8:
-            raise ValueError("decode path supports up to 8 sequences per engine call (lm_head / attention workspaces)")
         am = (attention_mask.to(dv).to(torch.int32) if attention_mask is not None
               else torch.ones(B, S, dtype=torch.int32, device=dv))
         pos2d = (am.cumsum(-1) - 1).clamp(min=0).to(torch.int32).contiguous()
@@ -358,24 +442,23 @@ class LlamaEngine:
         tokens = torch.empty(B, max_new_tokens, dtype=torch.int32, device=dv)
         tokens[:, 0].copy_(st["next_ids"])
         logits_steps = [st["logits"].clone()] if return_logits else None
-        eos = None if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
-        prompt_cpu = None if embeds_only else input_ids.cpu()
+        eos = _id_list(eos_token_id)
+        prompt_cpu = None if embeds_only else input_ids.cpu().long()
+        need_check = bool(eos) or bool(stopping_criteria)
+        final = None      # (padded tokens [B, k] on the host, k) once a stop condition has been met
 
-        def should_stop(n_done: int) -> bool:
-            if eos is None and not stopping_criteria:
-                return False
-            tk = tokens[:, :n_done].cpu().long()
-            if eos is not None and bool(torch.isin(tk, torch.tensor(eos)).any(-1).all()):
-                return True
-            if stopping_criteria:
-                seq = tk if embeds_only else torch.cat([prompt_cpu, tk], 1)
-                return any(sc(seq, None) for sc in stopping_criteria)
-            return False
+        def check(n_done: int, already: int):
+            if not need_check:
+                return None
+            tk, k, hit = finalize_greedy(tokens[:, :n_done].cpu().long(), eos, pad_token_id, stopping_criteria,
+                                         prompt_cpu, already + 1)
+            return (tk, k) if hit else None
 
         graph = self._graphs[skey][1] if use_graph else None
         n = 1
-        stopped = should_stop(1)
-        if use_graph and graph is None and not stopped and max_new_tokens > 2:
+        checked = 1
+        final = check(1, 0)
+        if use_graph and graph is None and final is None and max_new_tokens > 2:
             # warm the kernels outside capture, then capture one decode step; cursors live on device
             snap = {k: st[k].clone() for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end")}
             s = torch.cuda.Stream(device=dv)
@@ -391,7 +474,7 @@ class LlamaEngine:
             for k, v in snap.items():   # capture does not execute; restore is a no-op safety net
                 st[k].copy_(v)
             self._graphs[skey][1] = graph
-        while n < max_new_tokens and not stopped:
+        while n < max_new_tokens and final is None:
             if graph is not None:
                 graph.replay()
             else:
@@ -403,12 +486,54 @@ class LlamaEngine:
                 logits_steps.append(st["logits"].clone())
             n += 1
             if n % sync_every == 0 or n == max_new_tokens:
-                stopped = should_stop(n)
-        gen = tokens[:, :n].long()
-        if eos is not None:  # trim what ran past the first EOS of sequence 0 when sync_every > 1
-            pass
+                final = check(n, checked)
+                checked = n
+        if final is not None:   # rows padded after their first EOS; steps that ran past the stop (sync_every > 1) dropped
+            gen, n = final[0].to(dv), final[1]
+            if output_hidden_states:
+                del hidden_steps[n:]
+            if return_logits:
+                del logits_steps[n:]
+        elif need_check:        # no stop met within max_new_tokens: finished rows are still padded
+            gen = finalize_greedy(tokens[:, :n].cpu().long(), eos, pad_token_id, None, None)[0].to(dv)
+        else:
+            gen = tokens[:, :n].long()
         seqs = gen if embeds_only else torch.cat([input_ids.long(), gen], 1)
         out = GenerateOutput(seqs, tuple(hidden_steps) if output_hidden_states else None)
         if return_logits:
             out.logits = torch.stack(logits_steps, 1)
         return out if return_dict_in_generate else seqs
+
+    def _generate_grouped(self, input_ids, inputs_embeds, attention_mask, position_ids, B_all: int, kw: dict, as_dict: bool):
+        """More rows than one decode graph holds: groups of DECODE_ROWS, results joined the way one HF call would return
+        them (every row padded to the longest group with pad_token_id; a group that ended early repeats its last state)."""
+        if kw.get("stopping_criteria"):
+            raise NotImplementedError("stopping_criteria look at sequence 0 and end the whole batch (spider.py:55-73); "
+                                      f"use them with at most {self.DECODE_ROWS} rows per call")
+        outs = []
+        R = self.DECODE_ROWS
+        for b0 in range(0, B_all, R):
+            sl = slice(b0, min(B_all, b0 + R))
+            outs.append(self.generate(
+                input_ids=None if input_ids is None else input_ids[sl],
+                inputs_embeds=None if inputs_embeds is None else inputs_embeds[sl],
+                attention_mask=None if attention_mask is None else attention_mask[sl],
+                position_ids=None if position_ids is None else position_ids[:, sl], return_dict_in_generate=True, **kw))
+        eos = _id_list(kw.get("eos_token_id"))
+        pad = kw.get("pad_token_id")
+        pad = pad if pad is not None else (eos[0] if eos else 0)
+        T = max(o.sequences.shape[1] for o in outs)
+        seqs = torch.cat([torch.nn.functional.pad(o.sequences, (0, T - o.sequences.shape[1]), value=pad) for o in outs], 0)
+        out = GenerateOutput(seqs, None)
+        if kw.get("output_hidden_states"):
+            n_steps = max(len(o.hidden_states) for o in outs)
+            hs = []
+            for stp in range(n_steps):
+                per = [o.hidden_states[min(stp, len(o.hidden_states) - 1)] for o in outs]
+                hs.append(tuple(torch.cat([p[l] for p in per], 0) for l in range(len(per[0]))))
+            out.hidden_states = tuple(hs)
+        if kw.get("return_logits"):
+            n_steps = max(o.logits.shape[1] for o in outs)
+            out.logits = torch.cat([torch.cat([o.logits, o.logits[:, -1:].expand(-1, n_steps - o.logits.shape[1], -1)], 1)
+                                    for o in outs], 0)
+        return out if as_dict else seqs

@@ -19,6 +19,8 @@ ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "l
 
 
 def _stream() -> int:
+    """torch's current stream on the CURRENT device: the kernels are launched on that device, so every tensor handed to
+    the library must live there (`_chk` enforces it; engines on another GPU run under `torch.cuda.device(...)`)."""
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -41,6 +43,9 @@ def _p(t: Optional[torch.Tensor]):
 def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
     if not t.is_cuda:
         raise ValueError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise ValueError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                         "(kernels launch on the current device: wrap the call in torch.cuda.device(...))")
     if t.dtype != dtype:
         raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if contiguous and not t.is_contiguous():

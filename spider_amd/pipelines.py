@@ -25,7 +25,7 @@ from . import ops
 from .clap import ClapTextEngine
 from .clip import CLIPTextEngine
 from .registry import registry
-from .schedulers import SCHEDULERS, PNDMScheduler
+from .schedulers import PNDMScheduler, scheduler_from_config
 from .unet import UNetEngine, denoise
 from .unet3d import UNet3DEngine, video_denoise
 from .vae import VAEDecoderEngine
@@ -64,8 +64,7 @@ class StableDiffusionPipeline:
         """diffusers directory layout: unet/, vae/, text_encoder/, tokenizer/, scheduler/scheduler_config.json."""
         from transformers import CLIPTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
-        sched_cls = SCHEDULERS.get(sc.get("_class_name", "PNDMScheduler"), PNDMScheduler)
-        sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
+        sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device),
                    VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, scaling=0.18215),   # custom_sd.py:388
@@ -190,10 +189,7 @@ class AudioLDMPipeline:
         """diffusers layout: unet/, vae/, text_encoder/, tokenizer/, vocoder/, scheduler/scheduler_config.json."""
         from transformers import RobertaTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
-        sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"))
-        if sched_cls is None:
-            raise NotImplementedError(f"scheduler {sc.get('_class_name')!r}")
-        sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
+        sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         return cls(VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),
                    ClapTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
@@ -350,10 +346,7 @@ class TextToVideoSDPipeline(StableDiffusionPipeline):
     def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
         from transformers import CLIPTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
-        sched_cls = SCHEDULERS.get(sc.get("_class_name", "DDIMScheduler"))
-        if sched_cls is None:
-            raise NotImplementedError(f"scheduler {sc.get('_class_name')!r}")
-        sched = sched_cls(**{k: v for k, v in sc.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "steps_offset")})
+        sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device),
                    VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),       # scaling_factor from the config (:382)

@@ -574,14 +574,19 @@ class QwenOmniThinker:
         self.merge = vision.cfg.merge if vision is not None else 2
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", max_len: int = 4096, load_vision: bool = True, load_audio: bool = True):
+    def from_pretrained(cls, path: str, device="cuda:0", max_len: int = 4096, load_vision: bool = True, load_audio: bool = True,
+                        max_batch: int = 4):
         """A Qwen2.5-Omni checkpoint directory (config.json + *.safetensors with `thinker.model.*`, `thinker.visual.*`,
         `thinker.audio_tower.*`): what `Qwen2_5OmniModel.from_pretrained(args.checkpoint_path)` reads
-        (qwen2.5omni_spider_web.py:376-381), minus the talker / token2wav weights this path never uses."""
+        (qwen2.5omni_spider_web.py:376-381), minus the talker / token2wav weights this path never uses.
+        `max_batch` rows of KV cache are preallocated (left-padded processor batches, padding=True); at most 8 rows share a
+        decode graph, more are processed in groups."""
         import json, os
         from .llm import LlamaEngine
         cfg = json.load(open(os.path.join(path, "config.json")))
-        return cls(LlamaEngine.from_pretrained(path, device, max_batch=1, max_len=max_len),
+        if max_batch < 1:
+            raise ValueError("max_batch must be >= 1")
+        return cls(LlamaEngine.from_pretrained(path, device, max_batch=max_batch, max_len=max_len),
                    VisionTowerEngine.from_pretrained(path, device) if load_vision else None,
                    AudioTowerEngine.from_pretrained(path, device) if load_audio else None, OmniTokenIds.from_hf_dict(cfg))
 
@@ -624,9 +629,26 @@ class QwenOmniThinker:
                                 use_audio_in_video, aud_lens, video_second_per_grid)
         return emb, pos
 
+    # Qwen2_5OmniModel.generate's own default for the thinker (thinker_max_new_tokens=1024) and the chat terminators
+    # (<|im_end|>, <|endoftext|>) of the Qwen2.5 vocabulary, used when the checkpoint's config files name none
+    THINKER_MAX_NEW_TOKENS = 1024
+    DEFAULT_EOS = (151645, 151643)
+
     @torch.no_grad()
-    def generate(self, input_ids, attention_mask=None, max_new_tokens: int = 128, **kw):
-        """Returns [B, S + new] token ids like GenerationMixin.generate with input_ids."""
+    def generate(self, input_ids, attention_mask=None, max_new_tokens: Optional[int] = None, thinker_max_new_tokens: Optional[int] = None,
+                 **kw):
+        """Returns [B, S + new] token ids like GenerationMixin.generate with input_ids. Length and EOS default to the
+        checkpoint's generation config as in the reference's bare `model.generate(**inputs, spk=..., use_audio_in_video=True)`
+        (qwen2.5omni_spider_web.py:468): finished rows are pad-filled, the call ends when every row has emitted EOS."""
+        gc = getattr(self.llm, "generation_config", None) or {}
+        if max_new_tokens is None:
+            max_new_tokens = (thinker_max_new_tokens or gc.get("thinker_max_new_tokens") or gc.get("max_new_tokens")
+                              or self.THINKER_MAX_NEW_TOKENS)
+            max_new_tokens = max(1, min(max_new_tokens, self.llm.max_len - input_ids.shape[1]))
+        if kw.get("eos_token_id") is None:
+            kw["eos_token_id"] = gc.get("thinker_eos_token_id") or gc.get("eos_token_id") or (
+                list(self.DEFAULT_EOS) if self.llm.cfg.vocab > max(self.DEFAULT_EOS) else None)
+        kw.setdefault("sync_every", 8)
         tower_keys = ("pixel_values", "image_grid_thw", "pixel_values_videos", "video_grid_thw", "input_features",
                       "feature_attention_mask", "audio_feature_lengths", "use_audio_in_video", "video_second_per_grid")
         emb, pos = self.prepare_inputs(input_ids, attention_mask, **{k: kw.pop(k) for k in tower_keys if k in kw})

@@ -15,18 +15,47 @@ import torch
 from . import ops
 
 
-def _alphas_cumprod(beta_start=0.00085, beta_end=0.012, n=1000) -> torch.Tensor:
-    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+def _alphas_cumprod(beta_start=0.00085, beta_end=0.012, n=1000, beta_schedule="scaled_linear") -> torch.Tensor:
+    if beta_schedule == "scaled_linear":
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    elif beta_schedule == "linear":
+        betas = torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    else:
+        raise NotImplementedError(f"beta_schedule {beta_schedule!r} (scaled_linear and linear are implemented)")
     return torch.cumprod(1.0 - betas, 0)
+
+
+def _check_config(name: str, prediction_type="epsilon", timestep_spacing="leading", clip_sample=False, thresholding=False,
+                  trained_betas=None, skip_prk_steps=True, **ignored):
+    """The fields of scheduler_config.json whose non-default values change the update rule: refuse them instead of
+    silently denoising with the wrong coefficients (the checkpoints on the reference path -- SD-v1.5 PNDM, SDXL /
+    zeroscope / AudioLDM DDIM -- all carry the values accepted here)."""
+    bad = []
+    if prediction_type != "epsilon":
+        bad.append(f"prediction_type={prediction_type!r}")
+    if timestep_spacing != "leading":
+        bad.append(f"timestep_spacing={timestep_spacing!r}")
+    if clip_sample and name == "DDIMScheduler":
+        bad.append("clip_sample=True")
+    if thresholding:
+        bad.append("thresholding=True")
+    if trained_betas is not None:
+        bad.append("trained_betas")
+    if name == "PNDMScheduler" and not skip_prk_steps:
+        bad.append("skip_prk_steps=False")
+    if bad:
+        raise NotImplementedError(f"{name}: unsupported scheduler configuration: " + ", ".join(bad))
 
 
 class PNDMScheduler:
     order = 1
     init_noise_sigma = 1.0
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, **unused):
-        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps)
-        self.final_alpha = self.ac[0]
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 beta_schedule="scaled_linear", set_alpha_to_one=False, **cfg):
+        _check_config("PNDMScheduler", **cfg)
+        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps, beta_schedule)
+        self.final_alpha = torch.tensor(1.0) if set_alpha_to_one else self.ac[0]
         self.n_train, self.offset = num_train_timesteps, steps_offset
 
     def set_timesteps(self, n: int):
@@ -80,9 +109,11 @@ class DDIMScheduler:
     order = 1
     init_noise_sigma = 1.0
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, **unused):
-        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps)
-        self.final_alpha = self.ac[0]
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 beta_schedule="scaled_linear", set_alpha_to_one=False, **cfg):
+        _check_config("DDIMScheduler", **cfg)
+        self.ac = _alphas_cumprod(beta_start, beta_end, num_train_timesteps, beta_schedule)
+        self.final_alpha = torch.tensor(1.0) if set_alpha_to_one else self.ac[0]
         self.n_train, self.offset = num_train_timesteps, steps_offset
 
     def set_timesteps(self, n: int):
@@ -105,3 +136,12 @@ class DDIMScheduler:
 
 
 SCHEDULERS = {"PNDMScheduler": PNDMScheduler, "DDIMScheduler": DDIMScheduler}
+
+
+def scheduler_from_config(sc: dict):
+    """scheduler/scheduler_config.json -> scheduler object. Unknown classes and update-rule options that are not
+    implemented raise (no silent default)."""
+    name = sc.get("_class_name")
+    if name not in SCHEDULERS:
+        raise NotImplementedError(f"scheduler class {name!r} (implemented: {sorted(SCHEDULERS)})")
+    return SCHEDULERS[name](**{k: v for k, v in sc.items() if not k.startswith("_")})

@@ -55,6 +55,11 @@ class UNetConfig:
         return UNetConfig(8, 8, (128, 256, 384, 640), (False, True, True, True), (True, True, True, False), (1, 1, 1, 1),
                           (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (128, 256, 384, 640))
 
+    @staticmethod
+    def audioldm_l():   # cvssp/audioldm-l-full unet/config.json: the decoder the reference configures (train_configs/spider_decoder_cfg.py:37)
+        return UNetConfig(8, 8, (256, 512, 768, 1280), (False, True, True, True), (True, True, True, False), (1, 1, 1, 1),
+                     (8, 8, 8, 8), 2, 0, 32, False, 0, 0, None, 512, True, (256, 512, 768, 1280))
+
     def cross_dim_of(self, down_idx: int) -> int:
         return self.cross_dims[down_idx] if self.cross_dims is not None else self.cross_dim
 

@@ -16,17 +16,21 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 
 
-@pytest.fixture(scope="module")
-def qwen2(dev):
+@pytest.fixture(scope="module", params=["qwen25_7b", "llama3_8b"])
+def qwen2(dev, request):
+    """2 layers of the Qwen2.5-Omni-7B thinker text decoder / of DeepSeek-R1-Distill-Llama-8B at their true widths."""
     from spider_amd.llm import LlamaEngine, LLMConfig
-    cfg = LLMConfig.qwen25_7b()
+    cfg = getattr(LLMConfig, request.param)()
     cfg.layers = 2
-    return LlamaEngine.random_init(cfg, dev, max_batch=2, max_len=512, seed=3, std=0.02)
+    eng = LlamaEngine.random_init(cfg, dev, max_batch=2, max_len=512, seed=3, std=0.02)
+    yield eng
+    del eng
+    torch.cuda.empty_cache()
 
 
 def test_llm_decode_equals_prefill_at_full_width(qwen2, dev):
     eng = qwen2
-    ids = torch.randint(3, 150000, (1, 300), generator=torch.Generator().manual_seed(1))
+    ids = torch.randint(3, eng.cfg.vocab, (1, 300), generator=torch.Generator().manual_seed(1))
     out = eng.generate(input_ids=ids, max_new_tokens=6, return_dict_in_generate=True, return_logits=True)
     gen = out.sequences[0, 300:].cpu()
     again = eng.generate(input_ids=ids, max_new_tokens=6)
@@ -45,7 +49,7 @@ def test_llm_decode_equals_prefill_at_full_width(qwen2, dev):
 
 def test_llm_cache_boundaries(qwen2, dev):
     eng = qwen2
-    ids = torch.randint(3, 150000, (1, 500), generator=torch.Generator().manual_seed(2))
+    ids = torch.randint(3, eng.cfg.vocab, (1, 500), generator=torch.Generator().manual_seed(2))
     out = eng.generate(input_ids=ids, max_new_tokens=12)          # 500 + 12 == max_len: last slot used
     assert out.shape == (1, 512)
     with pytest.raises(ValueError):
@@ -140,3 +144,122 @@ def test_audio_tower_packing_independence_full_width(dev):
     fa2[:, 800:] += 0.5
     e2 = eng(fa2, [la], use_graph=False)
     assert torch.equal(e2[:50], ea[:50]) and not torch.equal(e2[200:], ea[200:])
+
+
+# ------------------------------------------------------------------------------------------ round 2: the remaining true shapes
+def _sdxl_added(B2, hw, dev, g):
+    return dict(text_embeds=torch.randn(B2, 1280, generator=g, device=dev).to(BF),
+                time_ids=torch.tensor([[hw * 8, hw * 8, 0, 0, hw * 8, hw * 8]] * B2, dtype=torch.float32))
+
+
+@pytest.fixture(scope="module")
+def sdxl(dev):
+    from spider_amd.unet import UNetConfig, UNetEngine
+    eng = UNetEngine.random_init(UNetConfig.sdxl(), dev, seed=2)
+    yield eng
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("hw", [64, 96])
+def test_sdxl_unet_graph_equals_eager_and_batch_equivariance(sdxl, dev, hw):
+    """SDXL UNet (2.57 B parameters) at the 512^2 (north_star) and 768^2 (Comic_Generation.py:320) latents."""
+    eng = sdxl
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(2, hw, hw, 4, generator=g, device=dev).to(BF)
+    enc = torch.randn(2, 77, 2048, generator=g, device=dev).to(BF)
+    added = _sdxl_added(2, hw, dev, g)
+    eng.prepare(torch.tensor([981, 500]), enc, added)
+    a = eng.step(x, 1, use_graph=False).clone()
+    b = eng.step(x, 1, use_graph=True).clone()
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    eng.prepare(torch.tensor([981, 500]), enc.flip(0).contiguous(), dict(text_embeds=added["text_embeds"].flip(0).contiguous(),
+                                                                        time_ids=added["time_ids"]))
+    c = eng.step(x.flip(0).contiguous(), 1, use_graph=False)
+    assert torch.equal(c.flip(0), a)
+
+
+@pytest.mark.parametrize("hw", [64, 96])
+def test_sdxl_consistent_self_attention_full_size(sdxl, dev, hw):
+    """The StoryDiffusion write phase at CFG batch 8 (4 panels), all 36 up-block processors on the consistent path
+    (coin forced, cur_step >= 5): deterministic and finite; and with an all-False keep vector (sa32 = sa64 = 0) every
+    query sees only its own image block, so the [2, 4N, C] masked attention must reproduce plain per-image self-attention."""
+    from spider_amd.story import ConsistentSelfAttention, StoryState
+    eng = sdxl
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(8, hw, hw, 4, generator=g, device=dev).to(BF)
+    enc = torch.randn(8, 77, 2048, generator=g, device=dev).to(BF)
+    eng.prepare(torch.tensor([801]), enc, _sdxl_added(8, hw, dev, g))
+    plain = eng.step(x, 0, use_graph=False).clone()
+
+    def run(sa, seed):
+        ug = torch.Generator().manual_seed(seed)
+        st = StoryState(total_count=ConsistentSelfAttention.count_processors(eng), height=hw * 8, width=hw * 8, id_length=4,
+                        sa32=sa, sa64=sa, write=True, cur_step=7, coin=lambda: 1.0, uniforms=lambda n: torch.rand(n, generator=ug))
+        assert st.total_count == 36
+        st.regen_masks(dev)
+        eng.self_attn_hook = ConsistentSelfAttention(st)
+        try:
+            out = eng.step(x, 0, use_graph=False).clone()
+        finally:
+            eng.self_attn_hook = None
+        assert st.cur_step == 8 and st.attn_count == 0          # all 36 processors ran once
+        return out
+
+    own = run(0.0, 0)
+    rel = float((own.float() - plain.float()).norm() / plain.float().norm())
+    assert rel < 1e-2, rel
+    a, b = run(0.5, 3), run(0.5, 3)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert float((a.float() - plain.float()).norm() / plain.float().norm()) > 2 * rel      # the shared keys really change the result
+
+
+def test_unet3d_zeroscope_full_size(dev):
+    """zeroscope UNet3D (1.41 B parameters) at BASELINE configs[4]'s video latent: CFG batch 2 x 16 frames of 40 x 72."""
+    from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
+    eng = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, seed=4)
+    g = torch.Generator(device=dev).manual_seed(0)
+    F_ = 16
+    x = torch.randn(2 * F_, 40, 72, 4, generator=g, device=dev).to(BF)
+    enc = torch.randn(2, 77, 1024, generator=g, device=dev).to(BF)
+    eng.prepare(torch.tensor([951, 401]), enc, frames=F_)
+    a = eng.step(x, 1, use_graph=False).clone()
+    b = eng.step(x, 1, use_graph=True).clone()
+    assert a.shape == (2 * F_, 40, 72, 4) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # swapping the two CFG samples (16 frames each) swaps the outputs: no leakage across samples through the temporal layers
+    xs = x.view(2, F_, 40, 72, 4).flip(0).reshape(2 * F_, 40, 72, 4).contiguous()
+    eng.prepare(torch.tensor([951, 401]), enc.flip(0).contiguous(), frames=F_)
+    c = eng.step(xs, 1, use_graph=False)
+    assert torch.equal(c.view(2, F_, 40, 72, 4).flip(0).reshape(2 * F_, 40, 72, 4), a)
+    # frames of one sample DO see each other: perturbing the last frame changes the first
+    x2 = x.clone()
+    x2[F_ - 1] += 1.0
+    eng.prepare(torch.tensor([951, 401]), enc, frames=F_)
+    d = eng.step(x2, 1, use_graph=False)
+    assert not torch.equal(d[0], a[0]) and torch.equal(d[F_:], a[F_:])
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("preset", ["audioldm", "audioldm_l"])
+def test_audioldm_unet_full_size(dev, preset):
+    """AudioLDM UNet (s-full-v2 and the reference's l-full, train_configs/spider_decoder_cfg.py:37) at the 5 s latent
+    [2, 8, 125, 16]: odd height through three stride-2 levels (125 -> 63 -> 32 -> 16) and the upsample_size rule back up."""
+    from spider_amd.unet import UNetConfig, UNetEngine
+    cfg = getattr(UNetConfig, preset)()
+    eng = UNetEngine.random_init(cfg, dev, seed=5)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(2, 125, 16, 8, generator=g, device=dev).to(BF)
+    cl = torch.nn.functional.normalize(torch.randn(2, 512, generator=g, device=dev), dim=-1).to(BF)
+    eng.prepare(torch.tensor([981, 500]), None, class_labels=cl)
+    a = eng.step(x, 1, use_graph=False).clone()
+    b = eng.step(x, 1, use_graph=True).clone()
+    assert a.shape == (2, 125, 16, 8) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    eng.prepare(torch.tensor([981, 500]), None, class_labels=cl.flip(0).contiguous())
+    c = eng.step(x.flip(0).contiguous(), 1, use_graph=False)
+    assert torch.equal(c.flip(0), a)
+    # the class embedding really conditions the step
+    eng.prepare(torch.tensor([981, 500]), None, class_labels=(cl.float() * -1).to(BF))
+    assert not torch.equal(eng.step(x, 1, use_graph=False), a)
+    del eng
+    torch.cuda.empty_cache()

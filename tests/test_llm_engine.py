@@ -151,3 +151,53 @@ def test_mrope_prefill_and_decode_match_oracle(dev):
         assert float(top2[0] - top2[1]) < 0.08, (gen, ref_tok)
     with pytest.raises(ValueError):
         eng.generate(inputs_embeds=emb.to(dev), position_ids=pos3[:, :, :5], max_new_tokens=2)
+
+
+def test_engine_per_row_eos_with_sync_every(dev):
+    """HF greedy semantics the reference relies on (spider.py:1492-1508): a row is finished at its first EOS and is
+    pad-filled afterwards, the call ends when the slowest row has finished; checking only every 4th token
+    (sync_every=4) must give the same result as checking every token."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig, StoppingCriteriaSub
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, 300, 10000.0, None, 1e-6, True, 256)
+    w = LlamaOracle.random_weights(ocfg, seed=13, std=0.08)
+    eng = LlamaEngine(LLMConfig(**ocfg.__dict__), w, dev, max_batch=2, max_len=96)
+    ids = torch.randint(3, 300, (2, 10), generator=torch.Generator().manual_seed(6))
+    N = 24
+    free = eng.generate(input_ids=ids, max_new_tokens=N)[:, 10:].cpu()
+    assert free.shape == (2, N)
+    e0, e1 = int(free[0, 5]), int(free[1, 13])                  # different stop points per row
+    for eos in ([e0, e1], [e1]):
+        a = eng.generate(input_ids=ids, max_new_tokens=N, eos_token_id=eos, pad_token_id=1, sync_every=1)
+        b = eng.generate(input_ids=ids, max_new_tokens=N, eos_token_id=eos, pad_token_id=1, sync_every=4,
+                         return_dict_in_generate=True, output_hidden_states=True, return_logits=True)
+        assert torch.equal(a, b.sequences)
+        gen = a[:, 10:].cpu()
+        is_eos = torch.isin(free, torch.tensor(eos))
+        first = [int(r.nonzero()[0]) if r.any() else N - 1 for r in is_eos]
+        assert gen.shape[1] == min(N, max(first) + 1)
+        for r in range(2):
+            upto = min(first[r] + 1, gen.shape[1])
+            assert torch.equal(gen[r, :upto], free[r, :upto])
+            assert bool((gen[r, upto:] == 1).all())              # pad after the row's EOS
+        assert len(b.hidden_states) == gen.shape[1] and b.logits.shape[1] == gen.shape[1]
+    # stopping criteria found after the fact (a stop word inside a sync block)
+    sc = StoppingCriteriaSub([[int(free[0, 8]), int(free[0, 9])]])
+    a = eng.generate(input_ids=ids, max_new_tokens=N, stopping_criteria=[sc], sync_every=1)
+    b = eng.generate(input_ids=ids, max_new_tokens=N, stopping_criteria=[sc], sync_every=4)
+    assert torch.equal(a, b) and a.shape[1] <= 10 + 10
+
+
+def test_engine_more_rows_than_one_decode_graph(dev):
+    """11 rows (> DECODE_ROWS): processed in groups, each row identical to its own single-row call."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, 300, 10000.0, None, 1e-6, True, 256)
+    w = LlamaOracle.random_weights(ocfg, seed=14, std=0.08)
+    eng = LlamaEngine(LLMConfig(**ocfg.__dict__), w, dev, max_batch=8, max_len=64)
+    ids = torch.randint(3, 300, (11, 9), generator=torch.Generator().manual_seed(7))
+    allr = eng.generate(input_ids=ids, max_new_tokens=6)
+    assert allr.shape == (11, 15)
+    for r in (0, 7, 8, 10):
+        one = eng.generate(input_ids=ids[r:r + 1], max_new_tokens=6)
+        assert torch.equal(one[0], allr[r])

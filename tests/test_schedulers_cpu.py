@@ -28,3 +28,22 @@ def test_schedulers_match_oracle(monkeypatch):
     assert int(ts[1]) == int(ts[2]) == 951                              # the repeated PLMS warm-up timestep
     ts = _run(S.DDIMScheduler(), DDIMOracle(), 50, monkeypatch)
     assert len(ts) == 50 and int(ts[0]) == 981 and int(ts[-1]) == 1
+
+
+def test_scheduler_config_is_honoured_or_refused():
+    import pytest
+    sd15 = {"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+            "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True,
+            "steps_offset": 1, "trained_betas": None, "clip_sample": False}
+    s = S.scheduler_from_config(sd15)
+    assert isinstance(s, S.PNDMScheduler) and float(s.final_alpha) == float(s.ac[0])
+    s1 = S.scheduler_from_config({**sd15, "_class_name": "DDIMScheduler", "set_alpha_to_one": True})
+    assert float(s1.final_alpha) == 1.0
+    lin = S.scheduler_from_config({**sd15, "beta_schedule": "linear"})
+    assert not torch.allclose(lin.ac, s.ac)
+    for bad in ({"prediction_type": "v_prediction"}, {"timestep_spacing": "trailing"}, {"beta_schedule": "squaredcos_cap_v2"},
+                {"skip_prk_steps": False}, {"_class_name": "EulerDiscreteScheduler"}):
+        with pytest.raises(NotImplementedError):
+            S.scheduler_from_config({**sd15, **bad})
+    with pytest.raises(NotImplementedError):
+        S.scheduler_from_config({**sd15, "_class_name": "DDIMScheduler", "clip_sample": True})

@@ -47,6 +47,69 @@ def test_unet_step_matches_oracle(dev, sdxl_like):
         assert r < 2.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
 
 
+@pytest.mark.parametrize("sdxl_like", [False, True])
+def test_unet_blocks_match_oracle(dev, sdxl_like):
+    """Every block class in isolation (inputs rounded to bf16, taken from the oracle): one bf16 rounding of the block
+    output is 2e-3 .. 4e-3 relative; the bound for a single block is 8e-3 (per-block assertions)."""
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
+    from spider_amd import ops
+    from spider_amd.unet import UNetConfig, UNetEngine
+    BF = torch.bfloat16
+    ocfg = UNetCfg.tiny(sdxl_like)
+    w = random_unet_weights(ocfg, seed=1)
+    orc = UNetOracle(ocfg, w)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    g = torch.Generator().manual_seed(2)
+    B2 = 2
+    x = torch.randn(B2, 4, 16, 24, generator=g).bfloat16().float()
+    enc = torch.randn(B2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    added = None
+    if sdxl_like:
+        added = dict(text_embeds=torch.randn(B2, 64, generator=g).bfloat16().float(),
+                     time_ids=torch.tensor([[128, 192, 0, 0, 128, 192]] * B2, dtype=torch.float32))
+    t = torch.tensor(500)
+    eng.prepare(torch.tensor([500]), enc.to(dev), added)
+    eng.tproj_cur.copy_(eng.tproj_steps[0])
+    temb = orc.time_embed(t, B2, added)
+    nhwc = lambda z: z.permute(0, 2, 3, 1).contiguous().to(dev).to(BF)
+    nchw = lambda z: z.permute(0, 3, 1, 2)
+    errs = {}
+    r0 = "down_blocks.0.resnets.0"
+    errs["tproj"] = _rel(eng.tproj_view[r0], orc._lin(r0 + ".time_emb_proj", torch.nn.functional.silu(temb)))
+    h = orc._conv("conv_in", x)
+    errs["conv_in"] = _rel(nchw(ops.conv2d_small_cin(nhwc(x), eng.w["conv_in.weight"], eng.w["conv_in.bias"])), h)
+    hb = h.bfloat16().float()
+    errs["resnet"] = _rel(nchw(eng._resnet(r0, nhwc(hb))), orc.resnet(r0, hb, temb))
+    a_ref = torch.nn.functional.silu(orc._gn(r0 + ".norm1", hb))
+    errs["gn_silu"] = _rel(nchw(eng._gn(r0 + ".norm1", nhwc(hb), True)), a_ref)
+    ab = a_ref.bfloat16().float()
+    errs["conv3x3"] = _rel(nchw(ops.conv2d(nhwc(ab), eng.w[r0 + ".conv1.weight"], bias=eng.w[r0 + ".conv1.bias"])),
+                           orc._conv(r0 + ".conv1", ab))
+    # a resnet with a channel change (1x1 shortcut conv) and the stride-2 downsampler
+    r1 = "down_blocks.1.resnets.0"
+    errs["resnet_shortcut"] = _rel(nchw(eng._resnet(r1, nhwc(hb))), orc.resnet(r1, hb, temb))
+    dn = "down_blocks.0.downsamplers.0.conv"
+    errs["downsample"] = _rel(nchw(ops.conv2d(nhwc(hb), eng.w[dn + ".weight"], bias=eng.w[dn + ".bias"], stride=2, pad=1)),
+                              orc._conv(dn, hb, stride=2))
+    ti = 1 if not ocfg.down_attn[0] else 0
+    tn = f"down_blocks.{ti}.attentions.0"
+    ci = ocfg.block_out[ti]
+    z = torch.randn(B2, ci, 8, 12, generator=g).bfloat16().float()
+    errs["transformer"] = _rel(nchw(eng._transformer(tn, nhwc(z), ocfg.heads[ti], ocfg.depth[ti])),
+                               orc.transformer(tn, z, enc, ocfg.heads[ti], ocfg.depth[ti]))
+    b = tn + ".transformer_blocks.0"
+    y = torch.randn(B2, 96, ci, generator=g).bfloat16().float()
+    o = eng._self_attn(b, y.to(dev).to(BF), ocfg.heads[ti])
+    errs["self_attn"] = _rel(ops.gemm(o, eng.w[b + ".attn1.to_out.0.weight"], bias=eng.w[b + ".attn1.to_out.0.bias"]),
+                             orc.attention(b + ".attn1", y, y, ocfg.heads[ti]))
+    o = eng._cross_attn(b, y.to(dev).to(BF), ocfg.heads[ti])
+    errs["cross_attn"] = _rel(ops.gemm(o, eng.w[b + ".attn2.to_out.0.weight"], bias=eng.w[b + ".attn2.to_out.0.bias"]),
+                              orc.attention(b + ".attn2", y, enc, ocfg.heads[ti]))
+    print("per-block rel L2:", {k: round(v, 5) for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 8e-3, (k, v)
+
+
 def test_unet_step_vs_bf16_reference_emulation(dev):
     """Separates 'bf16 storage' error from implementation error: the same graph evaluated with torch's CPU bf16 kernels
     (what the reference's modules would compute in bf16) differs from the fp32 oracle as much as our HIP path does, and our
