@@ -12,6 +12,12 @@ A "step" is one such response per GPU (`--batch` prompts per GPU, default 1 = th
 N > 1: one process per GPU (torch.distributed / RCCL), prompts sharded with no data-path collective and ONE gather
 of the padded outputs to rank 0 per step; weak scaling.
 
+`python bench.py --gpus N` with no torchrun environment launches the N ranks itself (fresh child processes, decided before
+any GPU call); under `python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+`--workload any2many` is BASELINE.json configs[4]: `--batch` (default 8) prompts per GPU, each answered with text + one
+512^2 image (SD-v1.5) + 5 s of audio (AudioLDM-L) + a 16-frame 320x576 video (zeroscope) through SpiderDecoder.generate,
+then the ONE gather of the padded outputs.
+
 One JSON line on rank 0, with `roofline` (dominant kernel = the decode weight-streaming GEMV, HBM-bound, timed live
 with HIP events) and `cpu_baseline` (the fp32 CPU oracle timed on this box's host cores on a bounded sample).
 """
@@ -36,7 +42,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--batch", type=int, default=1, help="prompts per GPU per step")
+    p.add_argument("--batch", type=int, default=None, help="prompts per GPU per step (default 1; 8 for --workload any2many)")
+    p.add_argument("--workload", default="text_image", choices=["text_image", "any2many"],
+                   help="text_image = BASELINE configs[1] (headline); any2many = configs[4] (text -> text+image+audio+video)")
+    p.add_argument("--no-extras", action="store_true", help="skip the secondary timings (SDXL story / UNet3D / audio / Llama-8B)")
     p.add_argument("--prompt-len", type=int, default=1536)
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
@@ -44,7 +53,41 @@ def parse():
     p.add_argument("--throughput-batch", type=int, default=8,
                    help="also report (outside the timed region, as an extra field) the rate with this many prompts per GPU; 0 = skip")
     p.add_argument("--llm", default="qwen25_7b", choices=["qwen25_7b", "llama3_8b"])
-    return p.parse_args()
+    a = p.parse_args()
+    if a.batch is None:
+        a.batch = 8 if a.workload == "any2many" else 1
+    return a
+
+
+def launch_ranks(args, script=None, argv=None) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RCCL rendezvous on
+    127.0.0.1) and return the worst exit code. Nothing in THIS process touches the GPU (device_count() does not
+    initialise HIP); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            rc = max(rc, abs(pr.wait()))
+            if rc:          # one rank failed: the others would wait in a collective forever
+                break
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 class Responder:
@@ -109,6 +152,72 @@ class Responder:
         else:
             out = lat
         return gen.to(torch.int32), out
+
+
+class AnyToManyResponder:
+    """BASELINE configs[4]: text -> {text + image + audio + video}. The LLM answers the rank's `batch` prompts in one batched
+    generate; every response then goes through the real Decoders-Controller (SpiderDecoder.generate: routing + decode_image /
+    decode_audio / decode_video, spider_decoder.py:100-166,309-348), one response per call like the reference (only sample 0
+    is read, :311). Random-init weights of the true shapes: SD-v1.5, AudioLDM-L (train_configs/spider_decoder_cfg.py:37),
+    zeroscope_v2_576w."""
+
+    def __init__(self, args, device, rank=0):
+        from spider_amd.clap import ClapTextConfig, ClapTextEngine
+        from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+        from spider_amd.llm import LlamaEngine, LLMConfig
+        from spider_amd.pipelines import AudioLDMPipeline, StableDiffusionPipeline, TextToVideoSDPipeline
+        from spider_amd.schedulers import DDIMScheduler
+        from spider_amd.spider_decoder import SpiderDecoder
+        from spider_amd.synthetic import FakeRobertaTokenizer, FakeTokenizer
+        from spider_amd.unet import UNetConfig, UNetEngine
+        from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
+        from spider_amd.vae import VAEConfig, VAEDecoderEngine
+        from spider_amd.vocoder import HifiGanConfig, HifiGanEngine
+        self.args, self.dev = args, device
+        dev = device
+        cfg = getattr(LLMConfig, args.llm)()
+        self.llm = LlamaEngine.random_init(cfg, dev, max_batch=min(args.batch, 8), max_len=args.prompt_len + args.new_tokens + 8, seed=0)
+        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2),
+                                     CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 3), FakeTokenizer(40000))
+        ad = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), dev, 4), ClapTextEngine.random_init(ClapTextConfig(), dev, 5),
+                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6),
+                              DDIMScheduler(beta_start=0.0015, beta_end=0.0195), HifiGanEngine.random_init(HifiGanConfig.audioldm(), dev, 7))
+        vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9),
+                                   CLIPTextEngine.random_init(CLIPTextConfig(49408, 1024, 23, 16, 4096, 77, 1e-5, "gelu"), dev, 10),
+                                   FakeTokenizer(40000))
+        self.decoder = SpiderDecoder(pipelines={"IMAGE": sd, "AUDIO": ad, "VIDEO": vd}, device=str(dev))
+        g = torch.Generator(device=dev).manual_seed(2047 + rank)
+        self.prompt = torch.randint(3, cfg.vocab, (args.batch, args.prompt_len), generator=g, device=dev)
+        self.stage = {}
+
+    def includes(self):
+        return ["llm_prefill", "llm_decode", "routing", "clip_text_encoder", "sd15_unet_loop", "vae_decode", "clap_text_encoder",
+                "audioldm_l_unet_loop", "mel_vae_decode", "hifigan_vocoder", "zeroscope_unet3d_loop", "vae_decode_16_frames"]
+
+    def respond(self, batch=None):
+        import numpy as np
+        from spider_amd import routing
+        a, dev = self.args, self.dev
+        B = batch or a.batch
+        t0 = time.perf_counter()
+        toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)[:, a.prompt_len:]
+        host = toks.cpu()
+        t1 = time.perf_counter()
+        imgs, auds, vids = [], [], []
+        for b in range(B):
+            head = " ".join(str(int(t)) for t in host[b, :6])
+            # random-init weights emit no tags: the synthetic response carries exactly one caption per modality
+            text = f"Sure. <IMAGE>scene {head}</IMAGE> <AUDIO>sound {head}</AUDIO> <VIDEO>clip {head}</VIDEO>"
+            answers, preds, ptext = routing.new_outputs()
+            answers, preds, ptext = self.decoder.generate({"llm_text_all": [text]}, answers, preds, ptext)
+            assert len(preds["IMAGE"]) == 1 and len(preds["AUDIO"]) == 1 and len(preds["VIDEO"]) == 1
+            imgs.append(torch.from_numpy(np.asarray(preds["IMAGE"][0], dtype=np.uint8)))                         # [512, 512, 3]
+            auds.append(torch.from_numpy(np.asarray(preds["AUDIO"][0], dtype=np.float32).reshape(-1)))           # [80000]
+            vids.append(torch.from_numpy(np.stack([np.asarray(f, dtype=np.uint8) for f in preds["VIDEO"][0]])))  # [16, 320, 576, 3]
+        torch.cuda.synchronize(dev)
+        self.stage = dict(llm_ms=round((t1 - t0) * 1e3, 1), decoders_ms=round((time.perf_counter() - t1) * 1e3, 1))
+        return {"tokens": toks.to(torch.int32), "image": torch.stack(imgs).to(dev), "audio": torch.stack(auds).to(dev),
+                "video": torch.stack(vids).to(dev)}
 
 
 def measure_roofline(resp, device):
@@ -272,30 +381,185 @@ def cpu_baseline(args):
             "unet_step_ms": round(t_unet * 1e3, 1), "decode_tokens_per_s": round(1.0 / (L * t_dec_layer + t_head1), 4)}
 
 
+def measure_story_attention_roofline(device):
+    """Consistent self-attention of the StoryDiffusion write phase at 768^2 (Comic_Generation.py:94-118): the [8, N, C] ->
+    [2, 4N, C] view at the 48x48 up-block level: 9216 tokens, 10 heads, d = 64, column-structured keep mask (sa64 = 0.5).
+    Algorithmic flops = 4 * (4N)^2 * C * 2 groups -- dense, as the reference computes it."""
+    from spider_amd import ops
+    from spider_amd.story import pack_keep_bits
+    N, img, heads, C = 2304, 4, 10, 640
+    L = img * N
+    qkv = torch.randn(2, L, 3 * C, device=device).to(torch.bfloat16)
+    keep = torch.rand(L, generator=torch.Generator().manual_seed(0)) < 0.5
+    bits = pack_keep_bits(keep).to(device)
+    f = lambda: ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, keep_bits=bits, blk=N, q_off=0)
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize(device)
+    n = 5
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(n):
+        f()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 4 * L * L * C * 2
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "attn_flash_kernel<64> keep-bits mask (SDXL consistent self-attention, 768^2: 9216 tokens, 10 heads, d=64, 2 CFG groups)",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n,
+            "note": "dense flop count; the kernel skips key tiles whose 64 columns are all masked for the query tile's image"}
+
+
+def _ev_ms(fn, n, device):
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record(stream)
+    for i in range(n):
+        fn(i)
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def other_decoders(device):
+    """Secondary, driver-visible numbers for the other BASELINE configs (outside the timed region; random-init weights of the
+    true shapes): SDXL story step (configs[2]), UNet3D step + AudioLDM-L clip (configs[3]/[4]), Llama-8B decode (configs[0]/[2])."""
+    import random as _random
+    from spider_amd import ops
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.unet import UNetConfig, UNetEngine, unet_flops
+    out = {}
+    g = torch.Generator(device=device).manual_seed(7)
+    # ---- SDXL story step: 768^2, CFG batch 8 (4 panels), FreeU, all 36 up-block processors on the consistent path
+    from spider_amd.story import ConsistentSelfAttention, StoryState
+    sdxl = UNetEngine.random_init(UNetConfig.sdxl(), device, seed=11)
+    sdxl.freeu = (0.6, 0.4, 1.1, 1.2)
+    hw = 96
+    x = torch.randn(8, hw, hw, 4, generator=g, device=device).to(torch.bfloat16)
+    enc = torch.randn(8, 77, 2048, generator=g, device=device).to(torch.bfloat16)
+    added = dict(text_embeds=torch.randn(8, 1280, generator=g, device=device).to(torch.bfloat16),
+                 time_ids=torch.tensor([[768, 768, 0, 0, 768, 768]] * 8, dtype=torch.float32))
+    ts = DDIMScheduler().set_timesteps(50)
+    sdxl.prepare(ts, enc, added)
+    rnd = _random.Random(2047)
+    st = StoryState(total_count=ConsistentSelfAttention.count_processors(sdxl), height=768, width=768, id_length=4, sa32=0.5, sa64=0.5,
+                    write=True, cur_step=5, coin=rnd.random)
+    st.regen_masks(device)
+    sdxl.self_attn_hook = ConsistentSelfAttention(st)
+    sdxl.step(x, 5)
+    n = 6
+    ms = _ev_ms(lambda i: sdxl.step(x, 6 + i), n, device)
+    sdxl.self_attn_hook = None
+    fl = unet_flops(UNetConfig.sdxl(), hw, hw)
+    plain_up = 6 * 4 * 2304 ** 2 * 640 + 30 * 4 * 576 ** 2 * 1280            # the 36 up-block self-attentions, per sample
+    cons = 2 * (6 * 4 * 9216 ** 2 * 640 + 30 * 4 * 2304 ** 2 * 1280)         # the same layers on the consistent path, per step
+    p_cons = 0.7                                                             # Bernoulli(0.7) for steps 5..19 (Comic_Generation.py:94-118)
+    step_flops = 8 * fl["total"] + p_cons * (cons - 8 * plain_up)
+    out["sdxl_story_step_ms"] = round(ms, 2)
+    out["sdxl_story_step"] = {"latent": "8x96x96x4 (4 panels, CFG), 768^2", "consistent_self_attention": "36 up-block processors, coin 0.7 (steps 5..19)",
+                              "freeu": True, "expected_flops_per_step_tf": round(step_flops / 1e12, 2),
+                              "tflops_per_s": round(step_flops / (ms * 1e-3) / 1e12, 1), "mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / 2500.0, 4),
+                              "flops_per_sample_plain_gf": {k: round(v / 1e9, 1) for k, v in fl.items()}}
+    out["roofline_story_attention"] = measure_story_attention_roofline(device)
+    del sdxl
+    torch.cuda.empty_cache()
+    # ---- zeroscope UNet3D step: CFG batch 2 x 16 frames at 40x72
+    from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
+    u3 = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), device, seed=12)
+    enc = torch.randn(2, 77, 1024, generator=g, device=device).to(torch.bfloat16)
+    ts = DDIMScheduler().set_timesteps(40)
+    u3.prepare(ts, enc, frames=16)
+    x2 = ops.latent_to_nhwc(torch.randn(16, 4, 40, 72, generator=g, device=device), reps=2)
+    u3.step(x2, 0)
+    out["unet3d_step_ms"] = round(_ev_ms(lambda i: u3.step(x2, i), 5, device), 2)
+    del u3
+    torch.cuda.empty_cache()
+    # ---- AudioLDM-L clip: 5 s, 40 DDIM steps, CFG, mel VAE, HiFi-GAN (train_configs/spider_decoder_cfg.py:37)
+    from spider_amd.clap import ClapTextConfig, ClapTextEngine
+    from spider_amd.pipelines import AudioLDMPipeline
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    from spider_amd.vocoder import HifiGanConfig, HifiGanEngine
+    pipe = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), device, 1), ClapTextEngine.random_init(ClapTextConfig(), device, 2),
+                            None, UNetEngine.random_init(UNetConfig.audioldm_l(), device, 3), DDIMScheduler(beta_start=0.0015, beta_end=0.0195),
+                            HifiGanEngine.random_init(HifiGanConfig.audioldm(), device, 4))
+    ids = torch.randint(3, 50000, (1, 12)); ids[0, 0] = 0; ids[0, -1] = 2
+    emb = pipe.text_encoder.text_embeds(torch.cat([ids, ids]), normalize=True)
+    call = lambda: pipe(prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], audio_length_in_s=5.0, num_inference_steps=40,
+                        guidance_scale=2.5, generator=torch.Generator(device=device).manual_seed(0))
+    call()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    call()
+    torch.cuda.synchronize(device)
+    out["audio_clip_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    x = torch.randn(2, 125, 16, 8, generator=g, device=device).to(torch.bfloat16)
+    pipe.unet.step(x, 0)
+    out["audio_unet_step_ms"] = round(_ev_ms(lambda i: pipe.unet.step(x, i), 10, device), 3)
+    out["audio_clip"] = "AudioLDM-L shapes, 5.0 s, 40 DDIM steps, CFG, mel VAE + HiFi-GAN; CLAP text (2 prompts) outside"
+    del pipe
+    torch.cuda.empty_cache()
+    return out
+
+
+def llama8b_numbers(device):
+    """BASELINE configs[0]/[2]: DeepSeek-R1-Distill-Llama-8B shapes, 256-token prompt + 256 greedy tokens."""
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    cfg = LLMConfig.llama3_8b()
+    eng = LlamaEngine.random_init(cfg, device, max_batch=1, max_len=600, seed=0)
+    ids = torch.randint(3, cfg.vocab, (1, 256), generator=torch.Generator(device=device).manual_seed(1), device=device)
+    eng.generate(input_ids=ids, max_new_tokens=8, sync_every=8)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    eng.generate(input_ids=ids, max_new_tokens=2, use_graph=False)
+    torch.cuda.synchronize(device)
+    tp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.generate(input_ids=ids, max_new_tokens=256, sync_every=256)
+    torch.cuda.synchronize(device)
+    tg = time.perf_counter() - t0
+    tok_s = 254 / max(tg - tp, 1e-6)
+    wbytes = 2 * (cfg.layers * (cfg.hidden * (cfg.n_q + 2 * cfg.n_kv) * cfg.head_dim + cfg.n_q * cfg.head_dim * cfg.hidden + 3 * cfg.hidden * cfg.inter)
+                  + cfg.vocab * cfg.hidden)
+    kv = 2 * cfg.layers * cfg.n_kv * cfg.head_dim * 2 * (256 + 128)
+    del eng
+    torch.cuda.empty_cache()
+    return {"prefill_256_ms": round(tp * 1e3, 1), "decode_tokens_per_s": round(tok_s, 1),
+            "decode_hbm_frac": round((wbytes + kv) * tok_s / 1e9 / HBM_PEAK_GBS, 4), "weight_bytes_per_token": wbytes}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # self-launch, decided before any GPU call
+        raise SystemExit(launch_ranks(args))
     from spider_amd import dp
     rank, world, local = dp.init_from_env()
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
-    resp = Responder(args, device)
+    a2m = args.workload == "any2many"
+    resp = AnyToManyResponder(args, device, rank) if a2m else Responder(args, device)
 
     def one_step():
+        if a2m:
+            return dp.gather_padded(resp.respond(), args.batch, rank, world, dst=0)
         toks, out = resp.respond()
-        g = dp.gather_padded({"tokens": toks, "out": out}, args.batch, rank, world, dst=0)
-        return g
+        return dp.gather_padded({"tokens": toks, "out": out}, args.batch, rank, world, dst=0)
 
+    g = None
     for _ in range(args.warmup):
-        one_step()
+        g = one_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        g = one_step()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -305,76 +569,112 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # secondary timings on rank 0 (outside the timed region)
-    extra = {}
     if rank == 0:
-        from spider_amd import ops
-        from spider_amd.unet import unet_flops, UNetConfig
         a = args
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # UNet step ms (BASELINE.json's second metric): graph replay of one CFG-batch-2 evaluation
-        x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2)
-        ts = resp.sched.set_timesteps(a.denoise_steps)
-        resp.unet.prepare(ts, resp.enc_synth[:2].contiguous())
-        resp.unet.step(x2, 0)
-        torch.cuda.synchronize(device)
-        e0.record()
-        for i in range(10):
-            resp.unet.step(x2, i)
-        e1.record(); e1.synchronize()
-        unet_ms = e0.elapsed_time(e1) / 10
-        fl = unet_flops(UNetConfig.sd15(), 64, 64)
-        extra["unet_step_ms"] = round(unet_ms, 3)
-        extra["unet_tflops_per_s"] = round(2 * fl["total"] / (unet_ms * 1e-3) / 1e12, 1)
-        extra["unet_flops_per_sample"] = {k: round(v / 1e9, 2) for k, v in fl.items()}
-        # LLM phases
-        t1 = time.perf_counter()
-        resp.llm.generate(input_ids=resp.prompt[:a.batch].contiguous(), max_new_tokens=2, use_graph=False)
-        torch.cuda.synchronize(device)
-        t_prefill = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        resp.llm.generate(input_ids=resp.prompt[:a.batch].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
-        torch.cuda.synchronize(device)
-        t_gen = time.perf_counter() - t1
-        extra["llm_prefill_ms"] = round(t_prefill * 1e3, 1)
-        extra["llm_decode_tokens_per_s"] = round(a.batch * (a.new_tokens - 2) / max(t_gen - t_prefill, 1e-6), 1)
-        if a.throughput_batch and a.throughput_batch != a.batch:
-            tb = min(a.throughput_batch, 8)
-            resp.respond(tb)
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            resp.respond(tb)
-            torch.cuda.synchronize(device)
-            dtb = time.perf_counter() - t1
-            extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
-                                           "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
-                                                   "not the headline value"}
-        roof = measure_roofline(resp, device)
-        extra["roofline_unet_conv"] = measure_mfma_roofline(device)
-        extra["roofline_unet_attention"] = measure_attention_roofline(device)
-        extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / 2500.0, 4)
-        c = resp.llm.cfg
-        wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
-        tok_s = extra["llm_decode_tokens_per_s"] / a.batch
-        extra["llm_decode_hbm_frac"] = round((wbytes + 2 * c.layers * c.n_kv * c.head_dim * 2 * (a.prompt_len + a.new_tokens // 2)) * tok_s / 1e9 / HBM_PEAK_GBS, 4)
-        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # reported at N=1 only
         total = world * args.batch * args.steps
-        line = {
-            "metric": "multimodal responses/sec (text->text+image)", "value": round(total / dt, 4), "unit": "responses/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SpiderFree text->text+1x512^2 image: {args.llm} text-decoder shapes, prompt {a.prompt_len} + "
-                                   f"{a.new_tokens} greedy tokens, routing, SD-v1.5 UNet 64x64 latent, PNDM {a.denoise_steps} steps "
-                                   f"({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5",
-                       "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": resp.includes(),
-                       "weights": "random-init of the true shapes"},
-            "roofline": roof, "cpu_baseline": cpu, **extra,
-        }
-        print(json.dumps(line), flush=True)
+        base = {"value": round(total / dt, 4), "unit": "responses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic"}
+        if g is not None:
+            base["gathered"] = {k: list(v.shape) for k, v in g.items()}
+            base["gather_bytes_per_rank"] = int(sum(v[0].numel() * v[0].element_size() for v in g.values()))
+        if a2m:
+            line = {"metric": "multimodal responses/sec (text->text+image+audio+video)", **base,
+                    "config": {"workload": f"any-to-many (BASELINE configs[4]): {a.llm} text-decoder shapes, prompt {a.prompt_len} + {a.new_tokens} "
+                                           "greedy tokens, routing of IMAGE+AUDIO+VIDEO tags through SpiderDecoder.generate: SD-v1.5 512^2 "
+                                           "(41 UNet calls), AudioLDM-L 5 s (40 steps + mel VAE + HiFi-GAN), zeroscope 16x320x576 (40 steps + VAE); "
+                                           "one gather of the padded outputs to rank 0 per step",
+                               "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": resp.includes(),
+                               "weights": "random-init of the true shapes"},
+                    "rank0_stage_ms_last_step": resp.stage, "roofline": None, "cpu_baseline": None}
+            print(json.dumps(line), flush=True)
+        else:
+            extra = text_image_extras(args, resp, device)
+            roof = measure_roofline(resp, device)
+            if not args.no_extras and world == 1:
+                del resp
+                torch.cuda.empty_cache()
+                extra.update(other_decoders(device))
+                extra["llama3_8b"] = llama8b_numbers(device)
+            cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # reported at N=1 only
+            line = {"metric": "multimodal responses/sec (text->text+image)", **base,
+                    "config": {"workload": f"SpiderFree text->text+1x512^2 image: {args.llm} text-decoder shapes, prompt {a.prompt_len} + "
+                                           f"{a.new_tokens} greedy tokens, routing, SD-v1.5 UNet 64x64 latent, PNDM {a.denoise_steps} steps "
+                                           f"({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5",
+                               "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": extra.pop("_includes"),
+                               "weights": "random-init of the true shapes"},
+                    "roofline": roof, "cpu_baseline": cpu, **extra}
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def text_image_extras(args, resp, device):
+    """Secondary timings of the headline workload on rank 0 (outside the timed region)."""
+    from spider_amd import ops
+    from spider_amd.unet import unet_flops, UNetConfig
+    a = args
+    extra = {"_includes": resp.includes()}
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # UNet step ms (BASELINE.json's second metric): graph replay of one CFG-batch-2 evaluation
+    x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2)
+    ts = resp.sched.set_timesteps(a.denoise_steps)
+    resp.unet.prepare(ts, resp.enc_synth[:2].contiguous())
+    resp.unet.step(x2, 0)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for i in range(10):
+        resp.unet.step(x2, i)
+    e1.record(); e1.synchronize()
+    unet_ms = e0.elapsed_time(e1) / 10
+    fl = unet_flops(UNetConfig.sd15(), 64, 64)
+    extra["unet_step_ms"] = round(unet_ms, 3)
+    extra["unet_tflops_per_s"] = round(2 * fl["total"] / (unet_ms * 1e-3) / 1e12, 1)
+    extra["unet_flops_per_sample"] = {k: round(v / 1e9, 2) for k, v in fl.items()}
+    c = resp.llm.cfg
+    wbytes = 2 * (c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden)
+    kvb = 2 * c.layers * c.n_kv * c.head_dim * 2 * (a.prompt_len + a.new_tokens // 2)
+
+    def llm_phase(B):
+        ids = resp.prompt[:B].contiguous()
+        resp.llm.generate(input_ids=ids, max_new_tokens=4, sync_every=4)          # graph for this batch captured outside the timing
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        resp.llm.generate(input_ids=ids, max_new_tokens=2, use_graph=False)
+        torch.cuda.synchronize(device)
+        t_prefill = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        resp.llm.generate(input_ids=ids, max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
+        torch.cuda.synchronize(device)
+        t_gen = time.perf_counter() - t1
+        tok_s = B * (a.new_tokens - 2) / max(t_gen - t_prefill, 1e-6)
+        # bytes that must cross HBM per decoded token-step: the weights once per step (shared by the B rows) + every row's KV
+        frac = (wbytes + B * kvb) * (tok_s / B) / 1e9 / HBM_PEAK_GBS
+        return t_prefill, tok_s, frac
+
+    tp, tok_s, frac = llm_phase(a.batch)
+    extra["llm_prefill_ms"] = round(tp * 1e3, 1)
+    extra["llm_decode_tokens_per_s"] = round(tok_s, 1)
+    extra["llm_decode_hbm_frac"] = round(frac, 4)
+    if a.throughput_batch and a.throughput_batch != a.batch:
+        tb = min(a.throughput_batch, 8)
+        _, tok8, frac8 = llm_phase(tb)
+        extra["llm_decode_batched"] = {"rows": tb, "tokens_per_s": round(tok8, 1), "hbm_frac": round(frac8, 4)}
+        resp.respond(tb)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        resp.respond(tb)
+        torch.cuda.synchronize(device)
+        dtb = time.perf_counter() - t1
+        extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
+                                       "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
+                                               "not the headline value"}
+    extra["roofline_unet_conv"] = measure_mfma_roofline(device)
+    extra["roofline_unet_attention"] = measure_attention_roofline(device)
+    extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / 2500.0, 4)
+    return extra
 
 
 if __name__ == "__main__":

@@ -69,3 +69,33 @@ def test_single_process_gather_and_length_ordering():
     assert g["x"].shape == (1, 4, 3) and g["count"].tolist() == [2]
     assert dp.order_by_length([5, 50, 20]) == [1, 2, 0]
     assert dp.shard_indices(10, 3, 8) == [3] and dp.shard_indices(3, 5, 8) == []
+
+
+def test_bench_self_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` outside torchrun starts N rank processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (here: a stand-in rank script that rendezvouses over gloo and all-reduces its rank), and refuses when fewer devices are
+    visible than ranks requested."""
+    import argparse
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "dist.init_process_group('gloo', rank=r, world_size=w)\n"
+        "t = torch.tensor([r + 1]); dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], f'rank{r}.txt'), 'w').write(str(int(t)))\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if (len(sys.argv) > 2 and r == 1) else 0)\n")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    rc = bench.launch_ranks(argparse.Namespace(gpus=2), script=str(script), argv=[str(tmp_path)])
+    assert rc == 0
+    assert (tmp_path / "rank0.txt").read_text() == "3" and (tmp_path / "rank1.txt").read_text() == "3"
+    assert bench.launch_ranks(argparse.Namespace(gpus=2), script=str(script), argv=[str(tmp_path), "fail"]) == 3   # a failing rank is reported
+    with pytest.raises(SystemExit, match="only 2 GPU"):
+        bench.launch_ranks(argparse.Namespace(gpus=4), script=str(script), argv=[str(tmp_path)])
