@@ -207,11 +207,13 @@ def test_sdxl_consistent_self_attention_full_size(sdxl, dev, hw):
         return out
 
     own = run(0.0, 0)
+    # same arithmetic through a different tiling (masked [2, 4N] tiles vs plain [8, N] tiles): bf16 rounding differences only,
+    # amplified by the ~100 layers downstream (two bf16 evaluations of this UNet differ by ~1.5e-2, see test_unet_engine.py)
     rel = float((own.float() - plain.float()).norm() / plain.float().norm())
-    assert rel < 1e-2, rel
+    assert rel < 3e-2, rel
     a, b = run(0.5, 3), run(0.5, 3)
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
-    assert float((a.float() - plain.float()).norm() / plain.float().norm()) > 2 * rel      # the shared keys really change the result
+    assert float((a.float() - plain.float()).norm() / plain.float().norm()) > 3 * rel      # the shared keys really change the result
 
 
 def test_unet3d_zeroscope_full_size(dev):
