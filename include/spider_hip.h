@@ -92,6 +92,15 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
                      float out_scale, void* ws, long ws_bytes, void* stream);
 
+/* C = LayerNorm(A; gamma, beta, eps) . W^T + bias (+res) in ONE launch (act 0), or its GEGLU form (act 4, as above).
+ * Replaces BasicTransformerBlock.norm1 / norm2 / norm3 + the projection that consumes it (attn1 to_q/k/v, attn2 to_q,
+ * ff.net.0.proj; diffusers-0.25 attention.py, reached from custom_sd.py:634-639). The normalisation is folded:
+ *   Wf = W * diag(gamma) (bf16 [N,K]), colsum[n] = sum_k Wf[n,k] (fp32), colbias[n] = sum_k beta[k] W[n,k] + bias[n] (fp32)
+ * are prepared once per layer by the caller; the kernel takes the row statistics of A while it stages the rows and applies
+ * C = rstd * (A.Wf^T - mean * colsum) + colbias in the epilogue. Rows of A are K wide (lda = K). */
+int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
+                        int M, int N, int K, int ldc, int act, float eps, void* stream);
+
 /* conv2d NHWC as implicit GEMM (ResnetBlock2D / Downsample2D / Upsample2D convs reached from
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,

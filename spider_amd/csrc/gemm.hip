@@ -50,6 +50,12 @@ struct GemmArgs {
     // without ups lim_h/lim_w = Hin/Win. cin64: a 64-wide K tile never straddles two taps (uniform tap per tile).
     int conv, Hin, Win, Cin, Hout, Wout, kh, kw, stride, pad_h, pad_w, dil, ups, lim_h, lim_w, cin64;
     int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
+    // LayerNorm folded into the GEMM (LN instantiations): C = rstd[m] * (A.W'^T - mean[m] * colsum[n]) + colbias[n], with
+    // W' = W * diag(gamma) (folded by the caller), colsum[n] = sum_k W'[n,k], colbias[n] = sum_k beta[k] W[n,k] + bias[n];
+    // the row statistics of A (K = the whole normalised row) are accumulated by the block itself while it stages A.
+    const float* ln_colsum;
+    const float* ln_bias;
+    float ln_eps;
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -166,8 +172,22 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
 }
 
 // ---- epilogue shared by the GEMM kernels: lane holds C[mb + i*16 + (lane&15)][nb + j*16 + (lane>>4)*4 + 0..3] ----
-template <int MT, int NT, int EPI>
-__device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT], int mb, int nb, int split, int lane) {
+// LayerNorm fold: row statistics {mean, rstd} of the block's rows live in LDS (ln_stat[row - m_blk]); see GemmArgs
+__device__ __forceinline__ void ln_fix(const GemmArgs& p, const float2* ln_stat, int row_in_blk, int n, float v[4]) {
+    const float2 ms = ln_stat[row_in_blk];
+    if (n + 3 < p.N) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+        const f32x4 cb = *reinterpret_cast<const f32x4*>(p.ln_bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ms.y * (v[e] - ms.x * cs[e]) + cb[e];
+    } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] = ms.y * (v[e] - ms.x * p.ln_colsum[n + e]) + p.ln_bias[n + e];
+    }
+}
+
+template <int MT, int NT, int EPI, bool LN = false>
+__device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT], int mb, int nb, int split, int lane,
+                                          const float2* ln_stat = nullptr, int m_blk = 0) {
     if (EPI <= 1 && p.splits == 1) {
         const EpiRsrc er = make_epi_rsrc(p);
 #pragma unroll
@@ -179,6 +199,7 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
             for (int j = 0; j < NT; ++j) {
                 const int n = nb + j * 16 + (lane >> 4) * 4;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (LN) ln_fix(p, ln_stat, m - m_blk, n, v);
                 epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
             }
         }
@@ -217,7 +238,7 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
     }
 }
 
-template <int BM, int BN, bool CONV, int EPI>
+template <int BM, int BN, bool CONV, int EPI, bool LN = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool GEGLU = EPI == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,8 +346,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
     };
     const int st_chunk = chunk ^ ((lrow >> 1) & 7);   // rows lrow + 32*i share bits 1..3 with lrow
+    float ln_s[AC], ln_q[AC];     // LN: this thread's share (8 of every 64 k) of sum x and sum x^2 of rows lrow + 32*i
+#pragma unroll
+    for (int i = 0; i < AC; ++i) ln_s[i] = ln_q[i] = 0.f;
     auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
         bf16_t* base = lds + buf * TILE_ELEMS;
+        if (LN) {   // every K tile passes through here exactly once (masked tiles are zeros)
+#pragma unroll
+            for (int i = 0; i < AC; ++i) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float lo = bf16lo_to_f32(ra[i][d]), hi = bf16hi_to_f32(ra[i][d]);
+                    ln_s[i] += lo + hi;
+                    ln_q[i] = fmaf(lo, lo, fmaf(hi, hi, ln_q[i]));
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < AC; ++i)
             *reinterpret_cast<u32x4*>(base + (lrow + 32 * i) * LDS_STRIDE + st_chunk * 8) = ra[i];
@@ -384,6 +419,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    const float2* ln_stat = reinterpret_cast<const float2*>(smem);
+    if (LN) {   // finish the row statistics: the 8 lanes tid & 7 of a row hold its partial sums
+        __syncthreads();                       // the K loop's last fragment reads are done: the tile memory is free
+        float2* st = reinterpret_cast<float2*>(smem);
+        const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < AC; ++i) {
+            float s_ = ln_s[i], q_ = ln_q[i];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q_ += __shfl_xor(q_, o, 64); }
+            if (chunk == 0) {
+                const float mean = s_ * inv_k;
+                const float var = fmaxf(q_ * inv_k - mean * mean, 0.f);
+                st[lrow + 32 * i] = float2{mean, rsqrtf(var + p.ln_eps)};
+            }
+        }
+        __syncthreads();
+    }
+
     // ---- GEGLU epilogue: value tile j and gate tile j + NT/2 of the same lane ----
     if (GEGLU) {
 #pragma unroll
@@ -398,7 +452,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                     for (int e = 0; e < 4; ++e) {
                         const int ne = n + e < p.N ? n + e : p.N - 1;
                         float v = acc[i][j][e], g = acc[i][j + NT / 2][e];
-                        if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
+                        if (LN) {
+                            const float2 ms = ln_stat[m - m0];
+                            v = ms.y * (v - ms.x * p.ln_colsum[ne]) + p.ln_bias[ne];
+                            g = ms.y * (g - ms.x * p.ln_colsum[p.N + ne]) + p.ln_bias[p.N + ne];
+                        } else if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
                         v = bf16_to_f32(f32_to_bf16(v));
                         g = bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16_to_f32(f32_to_bf16(g)))));
                         r[e] = v * g;
@@ -417,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         return;
     }
 
-    write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), split, lane);
+    write_out<MT, NT, EPI, LN>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), split, lane, ln_stat, m0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -629,6 +687,11 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = a.geglu ? 2 : (!fast_ok ? 3 : (a.act ? 1 : 0));
+    if (a.ln_colsum) {     // LayerNorm-folded linears (checked by the caller: bf16 out, N % 4 == 0, no activation, no split-K)
+        if (epi == 2) gemm_kernel<BM, BN, false, 2, true><<<grid, 256, smem, st>>>(a);
+        else gemm_kernel<BM, BN, false, 0, true><<<grid, 256, smem, st>>>(a);
+        return;
+    }
     if (a.conv) {
         if (epi == 3) gemm_kernel<BM, BN, true, 3><<<grid, 256, smem, st>>>(a);
         else if (epi == 1) gemm_kernel<BM, BN, true, 1><<<grid, 256, smem, st>>>(a);
@@ -742,10 +805,11 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
             splits = ds;
         }
     }
+    if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)
     if (!a.ws || splits < 1 || a.geglu) splits = 1;
     while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
     const int tiles = small ? t64 : t128;
-    if (force_splits && a.ws && !a.geglu) {
+    if (force_splits && a.ws && !a.geglu && !a.ln_colsum) {
         splits = force_splits < nk ? force_splits : nk;
         while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
     }
@@ -801,6 +865,35 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     a.w_bytes = (uint32_t)((size_t)N * K * 2);
     set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
+}
+
+// C = LayerNorm(A; gamma, beta, eps) . W^T + bias (+ res), or its GEGLU form (act = 4), with the normalisation folded into the
+// GEMM: Wf = W * diag(gamma) (bf16, [N, K]), colsum[n] = sum_k Wf[n,k] (fp32), colbias[n] = sum_k beta[k] W[n,k] + bias[n]
+// (fp32) are prepared once per layer by the caller; the kernel computes the row statistics of A on the fly and applies
+// C = rstd * (A.Wf^T - mean * colsum) + colbias in its epilogue. Replaces BasicTransformerBlock.norm1/2/3 + the projection
+// that consumes it (diffusers-0.25 attention.py; call site custom_sd.py:634-639). lda must equal K (whole rows are normalised).
+int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
+                        int M, int N, int K, int ldc, int act, float eps, void* stream) {
+    SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm_ln: empty problem");
+    SPIDER_CHECK(K % 8 == 0, "gemm_ln: K must be a multiple of 8 (16-byte rows)");
+    SPIDER_CHECK(act == 0 || act == 4, "gemm_ln: only the plain and the GEGLU epilogue are built");
+    SPIDER_CHECK(colsum && colbias && C, "gemm_ln: colsum, colbias and C are required");
+    SPIDER_CHECK(act != 4 || (!res && N % 2 == 0), "gemm_ln: GEGLU epilogue needs even N and no residual");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)Wf; a.C = (bf16_t*)C; a.C32 = nullptr;
+    a.bias = nullptr; a.res = (const bf16_t*)res; a.rowbias = nullptr; a.rows_per_group = 0;
+    a.M = M; a.K = K; a.lda = K; a.ldc = ldc;
+    a.geglu = act == 4;
+    a.N = a.geglu ? N / 2 : N;
+    SPIDER_CHECK(a.N % 4 == 0 && ldc % 4 == 0 && ldc >= a.N, "gemm_ln: output width and ldc must be multiples of 4, ldc >= width");
+    a.act = 0; a.act_param = 0.f; a.out_scale = 1.f; a.conv = 0; a.ws = nullptr;
+    a.ln_colsum = colsum; a.ln_bias = colbias; a.ln_eps = eps;
+    SPIDER_CHECK((size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 2 < ((size_t)1 << 31),
+                 "gemm_ln: operands must be < 2 GiB");
+    a.a_bytes = (uint32_t)((size_t)M * K * 2);
+    a.w_bytes = (uint32_t)((size_t)N * K * 2);
+    set_epilogue_ranges(a);
+    return launch(a, 0, stream);
 }
 
 // NHWC conv as implicit GEMM, general form. x [B, Hin, Win, Cin] bf16; w [Cout, kh, kw, Cin] bf16 (OHWI);

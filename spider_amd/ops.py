@@ -179,6 +179,38 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     return out
 
 
+def fold_layernorm(W, gamma, beta, bias=None):
+    """One-time parameter folding for gemm_ln (done when an engine loads its weights, like the OIHW -> OHWI repack):
+    LayerNorm(x) @ W^T + bias == rstd * (x @ Wf^T - mean * colsum) + colbias with
+    Wf = W * gamma (bf16), colsum = Wf.sum(1) (fp32, of the ROUNDED Wf so that the mean term cancels exactly),
+    colbias = W @ beta + bias (fp32). Returns (Wf, colsum, colbias)."""
+    W32 = W.float()
+    Wf = (W32 * gamma.float()[None, :]).to(BF16).contiguous()
+    colsum = Wf.float().sum(1).contiguous()
+    colbias = (W32 @ beta.float())
+    if bias is not None:
+        colbias = colbias + bias.float()
+    return Wf, colsum, colbias.contiguous()
+
+
+def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
+    """LayerNorm(A) @ W^T + bias (+ res) in one launch; (Wf, colsum, colbias) = fold_layernorm(W, gamma, beta, bias).
+    act: None or "geglu". A [..., K] bf16 contiguous rows."""
+    _chk(A, BF16, "A"); _chk(Wf, BF16, "Wf"); _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
+    N, K = Wf.shape
+    assert A.shape[-1] == K and colsum.numel() == N and colbias.numel() == N, "gemm_ln: shape mismatch"
+    assert act in (None, "geglu"), "gemm_ln: only the plain and GEGLU epilogues exist"
+    M = A.numel() // K
+    n_out = N // 2 if act == "geglu" else N
+    if out is None:
+        out = torch.empty(*A.shape[:-1], n_out, dtype=BF16, device=A.device)
+    if res is not None:
+        _chk(res, BF16, "res")
+    _lib.call("spider_gemm_ln_bf16", _p(A), _p(Wf), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out, ACT[act], float(eps),
+              _stream())
+    return out
+
+
 def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None):
     """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]."""
     _chk(x, BF16, "x"); _chk(w, BF16, "w")

@@ -15,6 +15,7 @@ MI355X-first choices (vs. the reference's per-op PyTorch calls):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -129,6 +130,21 @@ class UNetEngine:
             if self.w[n + ".attn2.to_k.weight"].shape[1] == self.w[n + ".attn2.to_q.weight"].shape[1]:
                 # encoder_hidden_states=None (AudioLDM): attn2 attends to its own input, one fused [3C,C] projection
                 self.w[n + ".attn2.qkv"] = torch.cat([self.w[n + ".attn2.to_q.weight"], self.w[n + ".attn2.kv"]], 0).contiguous()
+        # LayerNorm folded into the projection that consumes it (ops.fold_layernorm / spider_gemm_ln_bf16): norm1 -> attn1 q/k/v,
+        # norm2 -> attn2 to_q (or q/k/v when attn2 is a second self-attention), norm3 -> the GEGLU projection. One-time
+        # parameter folding at load; the un-folded weights stay for the paths that need the normalised tokens themselves
+        # (StoryDiffusion's id bank stores them, story.py).
+        self.ln: Dict[str, tuple] = {}
+        self.fuse_ln = os.environ.get("SPIDER_LN_FUSE", "1") != "0"
+        for b in [k[:-len(".norm1.weight")] for k in list(self.w) if k.endswith(".norm1.weight") and ".transformer_blocks." in k]:
+            W = self.w
+            if b + ".attn1.qkv" not in W:
+                continue
+            self.ln[b + ".attn1"] = ops.fold_layernorm(W[b + ".attn1.qkv"], W[b + ".norm1.weight"], W[b + ".norm1.bias"])
+            w2 = W[b + ".attn2.qkv"] if b + ".attn2.qkv" in W else W[b + ".attn2.to_q.weight"]
+            self.ln[b + ".attn2"] = ops.fold_layernorm(w2, W[b + ".norm2.weight"], W[b + ".norm2.bias"])
+            self.ln[b + ".ff"] = ops.fold_layernorm(W[b + ".ff.net.0.proj.weight"], W[b + ".norm3.weight"], W[b + ".norm3.bias"],
+                                                    W[b + ".ff.net.0.proj.bias"])
         # resnet table: order of time_emb_proj consumers
         self.resnets = [k[:-len(".time_emb_proj.weight")] for k in self.w if k.endswith(".time_emb_proj.weight")]
         self.tproj_w = torch.cat([self.w[r + ".time_emb_proj.weight"] for r in self.resnets], 0).contiguous()
@@ -256,14 +272,25 @@ class UNetEngine:
         qkv = ops.gemm(y, self.w[b + ".attn1.qkv"])
         return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
 
-    def _cross_attn(self, b, y, heads):
+    def _proj2(self, b, y, ln_input: bool):
+        """attn2's projection of the block input: y is the norm2 output (ln_input=False) or the un-normalised residual stream
+        (ln_input=True: norm2 folded into the GEMM)."""
+        if ln_input:
+            Wf, cs, cb = self.ln[b + ".attn2"]
+            C = y.shape[-1]
+            if not self.self_cross and Wf.shape[0] != C:   # folded from a fused [q | k | v] weight, text K/V in use: q rows only
+                Wf, cs, cb = Wf[:C], cs[:C], cb[:C]
+            return ops.gemm_ln(y, Wf, cs, cb)
+        return ops.gemm(y, self.w[b + (".attn2.qkv" if self.self_cross else ".attn2.to_q.weight")])
+
+    def _cross_attn(self, b, y, heads, ln_input: bool = False):
         """attn2 of a BasicTransformerBlock: K/V of the text tokens were projected in prepare(); with
         encoder_hidden_states=None (AudioLDM) it is a second self-attention."""
         C = y.shape[-1]
         if self.self_cross:
-            qkv = ops.gemm(y, self.w[b + ".attn2.qkv"])
+            qkv = self._proj2(b, y, ln_input)
             return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
-        q = ops.gemm(y, self.w[b + ".attn2.to_q.weight"])
+        q = self._proj2(b, y, ln_input)
         kv = self.kv[b]
         return ops.attention(q, kv[..., :C], kv[..., C:], heads)
 
@@ -275,17 +302,26 @@ class UNetEngine:
         h = ops.gemm(a.view(B, H * W_, C), pw, bias=w[n + ".proj_in.bias"])
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
-            y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
+            fuse = self.fuse_ln
             if self.self_attn_hook is not None and self.self_attn_hook.wants(b + ".attn1"):
+                y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
                 o = self.self_attn_hook(self, b + ".attn1", y, heads)
+            elif fuse:     # norm1 + q/k/v projection: one launch
+                qkv = ops.gemm_ln(h, *self.ln[b + ".attn1"])
+                o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
             else:
-                o = self._self_attn(b, y, heads)
+                o = self._self_attn(b, ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"]), heads)
             h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
-            y = ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"])
-            o = self._cross_attn(b, y, heads)
+            if fuse:
+                o = self._cross_attn(b, h, heads, ln_input=True)
+            else:
+                o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
             h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
-            y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
-            g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
+            if fuse:       # norm3 + GEGLU projection: one launch
+                g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
+            else:
+                y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
+                g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
             h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
         out = ops.gemm(h, w[n + ".proj_out.weight"].view(C, C), bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
         return out.view(B, H, W_, C)

@@ -448,3 +448,30 @@ def test_attention_late_max_jump(ops, dev, spike_tile):
     ref = (torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(d), -1) @ vd).transpose(1, 2).reshape(B, N, heads * d).float()
     close(out, ref, 2e-2, 1e-2, "attention late max jump")
     assert float((out[0, row, :d] - v[0, spike_tile * 64 + 11, :d].float()).abs().max()) < 0.05   # the spiked key takes all the weight
+
+
+@pytest.mark.parametrize("M,N,K,mean", [(8192, 960, 320, 0.0), (2048, 640, 640, 3.0), (520, 1280, 1280, -8.0), (77, 72, 64, 0.5),
+                                        (300, 3840, 1280, 0.0), (8192, 320, 320, 1.0)])
+def test_gemm_layernorm_folded(ops, dev, M, N, K, mean):
+    """LayerNorm folded into the consuming GEMM (spider_gemm_ln_bf16) against torch fp32 LayerNorm -> linear, plain / + residual /
+    GEGLU; rows with a large common offset (|mean| >> std) exercise the mean-cancellation term."""
+    x = (rnd(M, K, seed=1).float() + mean).to(BF)
+    W, b = rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3, scale=0.2)
+    ga, be = (1 + 0.2 * rnd(K, seed=4).float()).to(BF), rnd(K, seed=5, scale=0.2)
+    res = rnd(M, N, seed=6)
+    y = F.layer_norm(x.float(), (K,), ga.float(), be.float(), 1e-5)
+    ref = y @ W.float().T + b.float()
+    Wf, cs, cb = ops.fold_layernorm(W.to(dev), ga.to(dev), be.to(dev), b.to(dev))
+    close(ops.gemm_ln(x.to(dev), Wf, cs, cb, eps=1e-5), ref, 1.5e-2, 1e-2, "gemm_ln", rel_to_std=True)
+    close(ops.gemm_ln(x.to(dev), Wf, cs, cb, res=res.to(dev), eps=1e-5), ref + res.float(), 1.5e-2, 1e-2, "gemm_ln + res", rel_to_std=True)
+    # the two-launch form it replaces (LayerNorm rounds its output to bf16 first): agreement to bf16 rounding
+    two = ops.gemm(ops.layernorm(x.to(dev), ga.to(dev), be.to(dev), 1e-5), W.to(dev), bias=b.to(dev))
+    close(ops.gemm_ln(x.to(dev), Wf, cs, cb, eps=1e-5), two.float(), 2.5e-2, 1.5e-2, "gemm_ln vs layernorm + gemm", rel_to_std=True)
+    if N % 8 == 0:
+        inner = N // 2
+        # value * gelu(gate): where the value is ~0 and the gate is several sigma, the product inherits the value's absolute
+        # error (the fold rounds W * gamma to bf16 once more, ~1e-3 of the pre-activation scale) times the gate -- a handful of
+        # elements per million sit there, so the elementwise bound is wider and the aggregate error is bounded separately
+        got, rg = ops.gemm_ln(x.to(dev), Wf, cs, cb, act="geglu", eps=1e-5), ref[:, :inner] * F.gelu(ref[:, inner:])
+        close(got, rg, 5e-2, 2e-2, "gemm_ln geglu", rel_to_std=True)
+        assert float((got.float().cpu() - rg).norm() / rg.norm()) < 4e-3
