@@ -80,6 +80,25 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
                                   int* counters, int B, int n_q, int n_kv, int d, int T_max, float scale, int nsplit,
                                   void* stream);
 
+/* Batched-decode forms on a FRAGMENT-MAJOR weight copy (5..16 sequences share one weight stream; also valid for 1..4).
+ * Wfm = the weight W [N, K] repacked once at load time so that every wave instruction of the kernel reads 1 KiB of contiguous
+ * memory: [ceil(N/16) row groups][K/64 k blocks][2 sub-steps][64 lanes][8 bf16], lane 16 g + r of a piece holding
+ * W[16 rg + r][64 kb + 32 sx + 8 g + 0..7] (the A fragment of mfma_f32_16x16x32_bf16); rows beyond N are zero. K % 64 == 0.
+ * fold_rmsnorm = 0: x [B, K] is used as is. fold_rmsnorm = 1: RMSNorm folded into the projection -- x is the un-normalised
+ * residual stream, Wfm was repacked from W * diag(norm_w) (bf16), and the kernel takes sum x^2 per sequence from the x fragments
+ * it streams anyway and scales its accumulators by rsqrt(mean + eps): LlamaRMSNorm + nn.Linear in one launch
+ * (modeling_llama3.py:77-82 + :186-199). Replaces the same nn.Linear calls as spider_gemv_bf16 /
+ * spider_gemv_swiglu_bf16 / spider_lm_head_argmax_bf16 (modeling_llama3.py:186-199,240-313,870-871) at batch sizes where the
+ * row-major gather (16 rows x 64 B per instruction) cannot reach the HBM stream rate. */
+int spider_gemv_fm_bf16(const void* Wfm, const void* x, void* out, const void* bias, const void* res, int B, int N, int K,
+                        int fold_rmsnorm, float eps, void* stream);
+/* Wfm_gate_up: the repacked [gate rows (I) | up rows (I)] matrix, I % 16 == 0; out[b, i] = silu(g) * u */
+int spider_gemv_swiglu_fm_bf16(const void* Wfm_gate_up, const void* x, void* out, int B, int I, int K, int fold_rmsnorm, float eps,
+                               void* stream);
+/* logits (optional) [B, V] bf16; ws_val / ws_idx >= B * spider_lm_head_nparts(V) entries; ties -> lowest token id */
+int spider_lm_head_argmax_fm_bf16(const void* Wfm, const void* x, int* out_ids, void* logits, void* ws_val, void* ws_idx, int B,
+                                  int V, int K, int fold_rmsnorm, float eps, void* stream);
+
 /* ======================= MFMA GEMM / conv / attention ======================= */
 
 /* C = act(A[M,K] . W[N,K]^T + bias[N] + rowbias[row/rows_per_group, N]) (+res) * out_scale.

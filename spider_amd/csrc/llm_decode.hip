@@ -1020,6 +1020,165 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(const bf16_t* __re
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Skinny MFMA GEMM on a FRAGMENT-MAJOR weight copy (batched decode, 5..16 sequences; also the batched lm_head).
+// Layout of Wfm (built once per weight at load time, spider_amd.ops.repack_fm16): for every group of 16 weight rows and every
+// 64-wide k block, two 1 KiB pieces (k sub-steps sx = 0, 1); piece = [lane 0..63][8 bf16] with lane = 16 g + r holding
+// W[16 rg + r][64 kb + 32 sx + 8 g + 0..7] -- exactly the A fragment of mfma_f32_16x16x32_bf16. One wave instruction
+// therefore reads 1 KiB of CONTIGUOUS memory; the row-major form above gathers 16 rows x 64 B per instruction and was
+// measured at 2.0 - 4.0 TB/s at 8 sequences where this form streams at 3.2 (N = 3584, one block per CU) - 5.9 TB/s.
+// The <= 16 activation rows are the B operand (natural k order, rows >= B read as zeros through the buffer range);
+// each of the NW waves takes 1/NW of K and keeps 2 k blocks in flight; partial tiles are summed through LDS.
+// MODE 0: out = x.W^T (+bias) (+res);  1: W = [gate rows | up rows], out = silu(g) * u;
+// MODE 2: lm_head -- logits rounded to bf16, running arg-max per sequence over the block's row groups (ties -> lowest id),
+//         one (value, index) partial per block and sequence, optional bf16 logits.
+// ----------------------------------------------------------------------------------------------
+// NORM: x is the UN-normalised residual stream and Wfm was built from W * diag(norm_w): the kernel accumulates sum x^2 of
+// every sequence from the x fragments it streams anyway and applies rsqrt(mean + eps) to the accumulators (RMSNorm folded
+// into the projection: no rmsnorm launch, no normalised copy of x).
+template <int MODE, int NW, bool NORM>
+__global__ __launch_bounds__(NW * 64) void skinny_fm_kernel(const bf16_t* __restrict__ Wfm, const bf16_t* __restrict__ x,
+                                                            bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
+                                                            const bf16_t* __restrict__ res, float* __restrict__ pval,
+                                                            int* __restrict__ pidx, int B, int N, int K, int NG,
+                                                            uint32_t w_bytes, uint32_t x_bytes, float eps) {
+    constexpr bool GATEUP = MODE == 1;
+    constexpr int TN = GATEUP ? 2 : 1;
+    constexpr int D = 2;
+    __shared__ float part[NW][TN][64][4];
+    __shared__ float ssq[NW][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wfm), 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, x_bytes, 0x00020000);
+    const uint32_t xbase = (uint32_t)r16 * (uint32_t)K * 2u + 16u * g;      // rows >= B lie beyond x_bytes: read as zeros
+    const int nkb = K / 64;
+    const int kb0 = (wave * nkb) / NW, kb1 = ((wave + 1) * nkb) / NW;
+    const uint32_t grp_bytes = (uint32_t)nkb * 2048u;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+
+    for (int rg = blockIdx.x; rg < NG; rg += gridDim.x) {
+        uint32_t wbase[TN];
+        wbase[0] = (uint32_t)rg * grp_bytes + 16u * lane;
+        if (GATEUP) wbase[1] = (uint32_t)(NG + rg) * grp_bytes + 16u * lane;
+        f32x4 acc[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float sq = 0.f;     // NORM: this lane's share of sum_k x[r16, k]^2 over the wave's K range
+        u32x4 wq[D][TN][2], xq[D][2];
+        auto issue = [&](int kb, int s) {
+            const uint32_t inv = (uint32_t)((kb1 - 1 - kb) >> 31);          // all ones past this wave's K range: zeros
+            const uint32_t kw = (uint32_t)kb * 2048u, kx = (uint32_t)kb * 128u;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                wq[s][t][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (wbase[t] + kw) | inv, 0, 2));
+                wq[s][t][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (wbase[t] + kw + 1024u) | inv, 0, 2));
+            }
+            xq[s][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xbase + kx) | inv, 0, 0));
+            xq[s][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xbase + kx + 64u) | inv, 0, 0));
+        };
+#pragma unroll
+        for (int s = 0; s < D; ++s) issue(kb0 + s, s);
+        for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, xq[s][sx]);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[s][t][sx]), xf, acc[t], 0, 0, 0);
+                    if (NORM) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const float lo = bf16lo_to_f32(xq[s][sx][d]), hi = bf16hi_to_f32(xq[s][sx][d]);
+                            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+                        }
+                    }
+                }
+                issue(kb + D + s, s);
+                __builtin_amdgcn_sched_barrier(0);      // keep "consume slot s, refill slot s" in this order
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[wave][t][lane][j] = acc[t][j];
+        if (NORM) {
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (lane < 16) ssq[wave][lane] = sq;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane holds D[n = 16 rg + 4 g + j][m = r16]
+            float v[TN][4];
+            float rs = 1.f;
+            if (NORM) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += ssq[w][r16];
+                rs = rsqrtf(tot / (float)K + eps);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) a += part[w][t][lane][j];
+                    v[t][j] = a * rs;
+                }
+            const int m = r16;
+            if (MODE == 2) {
+                float lb = -INFINITY;
+                int li = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = 16 * rg + 4 * g + j;
+                    const bf16_t q = f32_to_bf16(v[0][j]);
+                    const float lv = bf16_to_f32(q);
+                    if (nn < N && m < B) {
+                        if (out) out[(size_t)m * N + nn] = q;
+                        if (lv > lb) { lb = lv; li = nn; }        // j ascending: the first maximum has the lowest index
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {        // the 4 lane groups of a sequence
+                    const float ov = __shfl_xor(lb, off, 64);
+                    const int oi = __shfl_xor(li, off, 64);
+                    if (ov > lb || (ov == lb && oi < li)) { lb = ov; li = oi; }
+                }
+                if (lb > best || (lb == best && li < besti)) { best = lb; besti = li; }
+            } else if (m < B) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = 16 * rg + 4 * g + j;
+                    if (nn < N) {
+                        float o;
+                        if (GATEUP) {
+                            const float gg = bf16_to_f32(f32_to_bf16(v[0][j])), uu = bf16_to_f32(f32_to_bf16(v[TN - 1][j]));
+                            o = bf16_to_f32(f32_to_bf16(silu_f(gg))) * uu;
+                        } else {
+                            o = v[0][j];
+                            if (bias) o += bf16_to_f32(bias[nn]);
+                            if (res) o = bf16_to_f32(f32_to_bf16(o)) + bf16_to_f32(res[(size_t)m * N + nn]);
+                        }
+                        out[(size_t)m * N + nn] = f32_to_bf16(o);
+                    }
+                }
+            }
+        }
+        if (MODE == 2) __syncthreads();     // `part` is rewritten by the next row group
+    }
+    if (MODE == 2 && wave == 0 && lane < 16 && lane < B) {
+        pval[(size_t)lane * gridDim.x + blockIdx.x] = best;
+        pidx[(size_t)lane * gridDim.x + blockIdx.x] = besti;
+    }
+}
+
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
     gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
         (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
@@ -1156,6 +1315,56 @@ int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w,
         case 7: LMHEAD_LAUNCH(7); break;
         default: LMHEAD_LAUNCH(8); break;
     }
+    SPIDER_LAUNCH_OK();
+    argmax_final_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const float*)ws_val, (const int*)ws_idx, out_ids, nparts);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// Fragment-major forms (see skinny_fm_kernel): Wfm is the repacked copy of W [N, K] (K % 64 == 0; rows padded to a multiple
+// of 16 with zeros; the gate/up form packs [gate | up] with I % 16 == 0). 1 <= B <= 16. fold_rmsnorm = 0: x is used as is;
+// 1: x is the un-normalised residual stream, Wfm was repacked from W * diag(norm_w), and the kernel applies
+// rsqrt(mean(x^2) + eps) per sequence in its epilogue (RMSNorm folded into the projection).
+int spider_gemv_fm_bf16(const void* Wfm, const void* x, void* out, const void* bias, const void* res, int B, int N, int K,
+                        int fold_rmsnorm, float eps, void* stream) {
+    SPIDER_CHECK(B >= 1 && B <= 16 && N > 0 && K > 0 && K % 64 == 0, "gemv_fm: 1 <= B <= 16, K a positive multiple of 64");
+    const int NG = (N + 15) / 16;
+    const size_t wb = (size_t)NG * 16 * K * 2, xb = (size_t)B * K * 2;
+    SPIDER_CHECK(wb < ((size_t)1 << 32), "gemv_fm: weight copy must be < 4 GiB");
+#define FM_ARGS(OUT_, BIAS_, RES_, PV_, PI_, N_) (const bf16_t*)Wfm, (const bf16_t*)x, (bf16_t*)(OUT_), (const bf16_t*)(BIAS_), (const bf16_t*)(RES_), \
+        (float*)(PV_), (int*)(PI_), B, N_, K, NG, (uint32_t)wb, (uint32_t)xb, eps
+    if (fold_rmsnorm) skinny_fm_kernel<0, 8, true><<<NG, 512, 0, (hipStream_t)stream>>>(FM_ARGS(out, bias, res, nullptr, nullptr, N));
+    else skinny_fm_kernel<0, 8, false><<<NG, 512, 0, (hipStream_t)stream>>>(FM_ARGS(out, bias, res, nullptr, nullptr, N));
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int spider_gemv_swiglu_fm_bf16(const void* Wfm, const void* x, void* out, int B, int I, int K, int fold_rmsnorm, float eps,
+                               void* stream) {
+    SPIDER_CHECK(B >= 1 && B <= 16 && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0,
+                 "gemv_swiglu_fm: 1 <= B <= 16, I a multiple of 16, K a positive multiple of 64");
+    const int NG = I / 16;
+    const size_t wb = (size_t)2 * I * K * 2, xb = (size_t)B * K * 2;
+    SPIDER_CHECK(wb < ((size_t)1 << 32), "gemv_swiglu_fm: weight copy must be < 4 GiB");
+    if (fold_rmsnorm) skinny_fm_kernel<1, 8, true><<<NG, 512, 0, (hipStream_t)stream>>>(FM_ARGS(out, nullptr, nullptr, nullptr, nullptr, I));
+    else skinny_fm_kernel<1, 8, false><<<NG, 512, 0, (hipStream_t)stream>>>(FM_ARGS(out, nullptr, nullptr, nullptr, nullptr, I));
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// Batched lm_head + greedy argmax on the fragment-major copy: x [B, K] is the NORMALISED last hidden state (1 <= B <= 16),
+// logits (optional) [B, V] bf16. ws_val / ws_idx: >= B * spider_lm_head_nparts(V) entries.
+int spider_lm_head_argmax_fm_bf16(const void* Wfm, const void* x, int* out_ids, void* logits, void* ws_val, void* ws_idx, int B,
+                                  int V, int K, int fold_rmsnorm, float eps, void* stream) {
+    SPIDER_CHECK(B >= 1 && B <= 16 && V > 0 && K > 0 && K % 64 == 0, "lm_head_argmax_fm: 1 <= B <= 16, K a positive multiple of 64");
+    const int NG = (V + 15) / 16;
+    const size_t wb = (size_t)NG * 16 * K * 2, xb = (size_t)B * K * 2;
+    SPIDER_CHECK(wb < ((size_t)1 << 32), "lm_head_argmax_fm: weight copy must be < 4 GiB");
+    int nparts = spider_lm_head_nparts(V);
+    if (nparts > NG) nparts = NG;
+    if (fold_rmsnorm) skinny_fm_kernel<2, 8, true><<<nparts, 512, 0, (hipStream_t)stream>>>(FM_ARGS(logits, nullptr, nullptr, ws_val, ws_idx, V));
+    else skinny_fm_kernel<2, 8, false><<<nparts, 512, 0, (hipStream_t)stream>>>(FM_ARGS(logits, nullptr, nullptr, ws_val, ws_idx, V));
+#undef FM_ARGS
     SPIDER_LAUNCH_OK();
     argmax_final_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const float*)ws_val, (const int*)ws_idx, out_ids, nparts);
     SPIDER_LAUNCH_OK();

@@ -34,6 +34,9 @@ SIGNATURES = {
     "spider_gemv_swiglu_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "spider_lm_head_nparts": (_i, [_i]),
     "spider_lm_head_argmax_bf16": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "spider_gemv_fm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "spider_gemv_swiglu_fm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "spider_lm_head_argmax_fm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "spider_rope_kv_append_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_rope_kv_append_mrope_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_attn_decode_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),

@@ -184,6 +184,7 @@ class StoppingCriteriaSub:
 
 class LlamaEngine:
     DECODE_ROWS = 8     # sequences per decode graph (lm_head / split-KV workspaces are sized for 8)
+    FM_MIN_BATCH = 5    # from this many sequences on the decode GEMVs run as skinny MFMA GEMMs on fragment-major weight copies
 
     def __init__(self, cfg: LLMConfig, weights: dict, device="cuda:0", max_batch: int = 1, max_len: int = 4096):
         self.cfg, self.device = cfg, torch.device(device)
@@ -206,6 +207,18 @@ class LlamaEngine:
                 w_down=g(p + "mlp.down_proj.weight"),
                 ln1=g(p + "input_layernorm.weight"), ln2=g(p + "post_attention_layernorm.weight"))
             self.layers.append(lw)
+        # Batched decode (5..8 sequences per graph) streams a second, fragment-major copy of every decode weight (ops.repack_fm16:
+        # 1 KiB contiguous per wave instruction of the skinny MFMA kernels). Memory is laid out for 288 GB of HBM: the copy
+        # costs one more model size (15 GB for the 7B / 8B decoders) and buys 1.4 - 1.6x on the batched weight streams.
+        self.fm_batch = max_batch >= self.FM_MIN_BATCH and cfg.hidden % 64 == 0 and cfg.inter % 64 == 0 \
+            and (cfg.n_q * cfg.head_dim) % 64 == 0 and os.environ.get("SPIDER_DECODE_FM", "1") != "0"
+        if self.fm_batch:
+            for lw in self.layers:     # the projections behind a LlamaRMSNorm carry its weight (fold_rmsnorm form of the kernels)
+                lw["w_qkv_fm"] = ops.repack_fm16(lw["w_qkv"], lw["ln1"])
+                lw["w_gu_fm"] = ops.repack_fm16(lw["w_gu"], lw["ln2"])
+                lw["w_o_fm"] = ops.repack_fm16(lw["w_o"])
+                lw["w_down_fm"] = ops.repack_fm16(lw["w_down"])
+            self.lm_head_fm = ops.repack_fm16(self.lm_head, self.norm)
         self._alloc()
 
     # ------------------------------------------------------------------ construction helpers
@@ -298,10 +311,13 @@ class LlamaEngine:
         hs = st.get("hidden_buf")
         if hs is not None:
             hs[0].copy_(h)
+        fm = self.fm_batch and B >= self.FM_MIN_BATCH
         fuse_norm = B < 5      # >= 5 sequences use the skinny MFMA GEMM, which takes pre-normalised activations
         for l, lw in enumerate(self.layers):
             if fuse_norm:
                 ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])
+            elif fm:
+                ops.gemv_fm(lw["w_qkv_fm"], h, lw["w_qkv"].shape[0], bias=lw["b_qkv"], out=st["qkv"], norm_eps=c.eps)
             else:
                 ops.gemv(lw["w_qkv"], ops.rmsnorm(h, lw["ln1"], c.eps, out=st["xn"]), bias=lw["b_qkv"], out=st["qkv"])
             if c.head_dim == 128:   # RoPE + KV append + split-KV attention + combine: one launch
@@ -312,16 +328,25 @@ class LlamaEngine:
                                    B, 1, c.n_q, c.n_kv, c.head_dim)
                 ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
                                 nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
-            h1 = ops.gemv(lw["w_o"], st["attn"], res=h, out=st["h1"])
-            if fuse_norm:
-                ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
+            if fm:
+                h1 = ops.gemv_fm(lw["w_o_fm"], st["attn"], c.hidden, res=h, out=st["h1"])
+                ops.gemv_swiglu_fm(lw["w_gu_fm"], h1, out=st["act"], norm_eps=c.eps)
+                h = ops.gemv_fm(lw["w_down_fm"], st["act"], c.hidden, res=h1, out=st["h2"][l & 1])
             else:
-                ops.gemv_swiglu(lw["w_gu"], ops.rmsnorm(h1, lw["ln2"], c.eps, out=st["xn"]), out=st["act"])
-            h = ops.gemv(lw["w_down"], st["act"], res=h1, out=st["h2"][l & 1])
+                h1 = ops.gemv(lw["w_o"], st["attn"], res=h, out=st["h1"])
+                if fuse_norm:
+                    ops.gemv_swiglu(lw["w_gu"], h1, norm_w=lw["ln2"], eps=c.eps, out=st["act"])
+                else:
+                    ops.gemv_swiglu(lw["w_gu"], ops.rmsnorm(h1, lw["ln2"], c.eps, out=st["xn"]), out=st["act"])
+                h = ops.gemv(lw["w_down"], st["act"], res=h1, out=st["h2"][l & 1])
             if hs is not None:
                 hs[l + 1].copy_(h)
-        ops.lm_head_argmax(self.lm_head, h, norm_w=self.norm, eps=c.eps, out_ids=st["next_ids"], ws=st["lm_ws"],
-                           logits=st.get("logits"))
+        if fm:
+            ops.lm_head_argmax_fm(self.lm_head_fm, h, c.vocab, out_ids=st["next_ids"], ws=st["lm_ws"], logits=st.get("logits"),
+                                  norm_eps=c.eps)
+        else:
+            ops.lm_head_argmax(self.lm_head, h, norm_w=self.norm, eps=c.eps, out_ids=st["next_ids"], ws=st["lm_ws"],
+                               logits=st.get("logits"))
         if hs is not None:  # HF reports the normed state as the last hidden state (modeling_llama3.py:619-623)
             ops.rmsnorm(h, self.norm, c.eps, out=hs[c.layers])
         # advance the device-side cursors (index math only)

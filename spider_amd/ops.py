@@ -95,6 +95,68 @@ def gemv_swiglu(W_gate_up, x, norm_w=None, eps=0.0, out=None):
     return out
 
 
+def repack_fm16(W: torch.Tensor, norm_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W [N, K] bf16 (K % 64 == 0); with norm_w [K] the copy holds bf16(W * norm_w) for the kernels' fold_rmsnorm form.
+    W -> fragment-major copy [ceil(N/16), K/64, 2, 64, 8] for the *_fm kernels: piece (rg, kb, sx)
+    holds, at lane 16 g + r, W[16 rg + r, 64 kb + 32 sx + 8 g : + 8]. Pure data movement, done once when an engine loads its
+    weights (like the OIHW -> OHWI conv repack); rows are zero-padded to a multiple of 16."""
+    _chk(W, BF16, "W")
+    N, K = W.shape
+    assert K % 64 == 0, "repack_fm16: K must be a multiple of 64"
+    if norm_w is not None:
+        W = (W.float() * norm_w.float()[None, :]).to(BF16)
+    NG = (N + 15) // 16
+    if NG * 16 != N:
+        W = torch.cat([W, torch.zeros(NG * 16 - N, K, dtype=BF16, device=W.device)], 0)
+    # [rg, r, kb, sx, g, e] -> [rg, kb, sx, g, r, e]
+    return W.view(NG, 16, K // 64, 2, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(NG, K // 64, 2, 64, 8)
+
+
+def gemv_fm(Wfm, x, N, bias=None, res=None, out=None, norm_eps=None):
+    """out[b, n] = sum_k x[b, k] W[n, k] (+bias) (+res) on the fragment-major copy Wfm = repack_fm16(W); 1 <= B <= 16.
+    norm_eps: RMSNorm folded in -- Wfm = repack_fm16(W, norm_w), x un-normalised."""
+    _chk(Wfm, BF16, "Wfm"); _chk(x, BF16, "x")
+    K = Wfm.shape[1] * 64
+    B = x.numel() // K
+    assert x.shape[-1] == K and Wfm.shape[0] == (N + 15) // 16
+    if out is None:
+        out = torch.empty(B, N, dtype=BF16, device=x.device)
+    _lib.call("spider_gemv_fm_bf16", _p(Wfm), _p(x), _p(out), _p(bias), _p(res), B, N, K, int(norm_eps is not None),
+              float(norm_eps or 0.0), _stream())
+    return out
+
+
+def gemv_swiglu_fm(Wfm_gate_up, x, out=None, norm_eps=None):
+    """out = silu(x @ Wg^T) * (x @ Wu^T) on repack_fm16(cat([Wg, Wu])); I % 16 == 0."""
+    _chk(Wfm_gate_up, BF16, "Wfm_gate_up"); _chk(x, BF16, "x")
+    K = Wfm_gate_up.shape[1] * 64
+    I = Wfm_gate_up.shape[0] * 16 // 2
+    B = x.numel() // K
+    assert x.shape[-1] == K and I % 16 == 0
+    if out is None:
+        out = torch.empty(B, I, dtype=BF16, device=x.device)
+    _lib.call("spider_gemv_swiglu_fm_bf16", _p(Wfm_gate_up), _p(x), _p(out), B, I, K, int(norm_eps is not None), float(norm_eps or 0.0),
+              _stream())
+    return out
+
+
+def lm_head_argmax_fm(Wfm, x, V, out_ids=None, logits=None, ws=None, norm_eps=None):
+    """Greedy argmax of x @ W^T on the fragment-major lm_head copy; 1 <= B <= 16. x normalised, or (norm_eps given, Wfm =
+    repack_fm16(W, norm_w)) the un-normalised last hidden state."""
+    _chk(Wfm, BF16, "Wfm"); _chk(x, BF16, "x")
+    K = Wfm.shape[1] * 64
+    B = x.numel() // K
+    npart = lm_head_nparts(V)
+    if ws is None:
+        ws = (torch.empty(B * npart, dtype=torch.float32, device=x.device), torch.empty(B * npart, dtype=torch.int32, device=x.device))
+    assert ws[0].numel() >= B * npart and ws[1].numel() >= B * npart
+    if out_ids is None:
+        out_ids = torch.empty(B, dtype=torch.int32, device=x.device)
+    _lib.call("spider_lm_head_argmax_fm_bf16", _p(Wfm), _p(x), _p(out_ids), _p(logits), _p(ws[0]), _p(ws[1]), B, V, K,
+              int(norm_eps is not None), float(norm_eps or 0.0), _stream())
+    return out_ids
+
+
 def lm_head_nparts(V: int) -> int:
     return _lib.load().spider_lm_head_nparts(V)
 

@@ -476,3 +476,72 @@ def test_gemm_layernorm_folded(ops, dev, M, N, K, mean):
         close(got, rg, 5e-2, 2e-2, "gemm_ln geglu", rel_to_std=True)
         assert float((got.float().cpu() - rg).norm() / rg.norm()) < 6e-3    # three bf16 roundings (value, gelu(gate), product)
 
+
+
+@pytest.mark.parametrize("B,N,K", [(8, 4608, 3584), (5, 3584, 18944), (16, 130, 1024), (1, 7, 64), (8, 18944, 3584), (3, 1000, 256)])
+def test_skinny_gemm_fragment_major(ops, dev, B, N, K):
+    """Batched-decode GEMV on the fragment-major weight copy (repack_fm16): plain / + bias + residual / gate-up SwiGLU, against
+    fp32 torch and against the row-major kernels (same products, different summation order)."""
+    W, x = rnd(N, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    bias, res = rnd(N, seed=3), rnd(B, N, seed=4)
+    ref = x.float() @ W.float().T
+    Wd = W.to(dev)
+    Wfm = ops.repack_fm16(Wd)
+    assert Wfm.shape == ((N + 15) // 16, K // 64, 2, 64, 8)
+    # the layout contract of include/spider_hip.h: piece (rg, kb, sx), lane 16 g + r -> W[16 rg + r, 64 kb + 32 sx + 8 g : + 8]
+    rg, kb, sx, g, r = (N - 1) // 16, K // 64 - 1, 1, 3, (N - 1) % 16
+    assert torch.equal(Wfm[rg, kb, sx, 16 * g + r].cpu(), W[16 * rg + r, 64 * kb + 32 * sx + 8 * g: 64 * kb + 32 * sx + 8 * g + 8])
+    close(ops.gemv_fm(Wfm, x.to(dev), N), ref, 1e-2, 1e-2, "gemv_fm", rel_to_std=True)
+    close(ops.gemv_fm(Wfm, x.to(dev), N, bias=bias.to(dev), res=res.to(dev)), ref + bias.float() + res.float(), 1.5e-2, 1e-2,
+          "gemv_fm + bias + res", rel_to_std=True)
+    if B <= 8:
+        close(ops.gemv_fm(Wfm, x.to(dev), N), ops.gemv(Wd, x.to(dev)).float(), 1e-2, 1e-2, "gemv_fm vs row-major", rel_to_std=True)
+    if N % 32 == 0:
+        I = N // 2
+        gg, uu = ref[:, :I], ref[:, I:]
+        close(ops.gemv_swiglu_fm(Wfm, x.to(dev)), F.silu(gg) * uu, 1.5e-2, 2e-2, "gemv_swiglu_fm", rel_to_std=True)
+
+
+@pytest.mark.parametrize("B,V,K", [(8, 152064, 3584), (5, 1000, 256), (16, 97, 64), (1, 33000, 128)])
+def test_lm_head_argmax_fragment_major(ops, dev, B, V, K):
+    W, x = rnd(V, K, seed=1, scale=0.05), rnd(B, K, seed=2)
+    Wd, xd = W.to(dev), x.to(dev)
+    Wfm = ops.repack_fm16(Wd)
+    logits = torch.empty(B, V, dtype=BF, device=dev)
+    ids = ops.lm_head_argmax_fm(Wfm, xd, V, logits=logits)
+    ref = (x.float() @ W.float().T)
+    close(logits, ref, 1e-2, 1e-2, "lm_head logits", rel_to_std=True)
+    # the arg-max is taken over the bf16-rounded logits with ties -> lowest id: recompute it from the kernel's own logits
+    lg = logits.float().cpu()
+    assert ids.cpu().tolist() == lg.argmax(-1).tolist() or all(
+        float(lg[b, int(ids[b])]) == float(lg[b].max()) and int(ids[b]) == int((lg[b] == lg[b].max()).nonzero()[0]) for b in range(B))
+    # forced ties: identical rows of W give identical logits, the lowest token id must win
+    W2 = W.clone(); W2[V - 1] = W2[3]; W2[V // 2] = W2[3]
+    big = x.float() @ W2[3].float()
+    xs = torch.where(big[:, None] > 0, x.float(), -x.float()).to(BF)       # make row 3's logit positive for every sequence
+    W2[3] = W2[3] * 8; W2[V - 1] = W2[3]; W2[V // 2] = W2[3]
+    ids2 = ops.lm_head_argmax_fm(ops.repack_fm16(W2.to(dev)), xs.to(dev), V)
+    lg2 = (xs.float() @ W2.float().T)
+    for b in range(B):
+        if int(lg2[b].argmax()) in (3, V // 2, V - 1):
+            assert int(ids2[b]) == min(3, V // 2), (b, int(ids2[b]))
+
+
+@pytest.mark.parametrize("B,N,K", [(8, 4608, 3584), (6, 130, 1024)])
+def test_skinny_fragment_major_folded_rmsnorm(ops, dev, B, N, K):
+    """RMSNorm folded into the fragment-major projection (weights carry norm_w, the kernel applies rsqrt(mean x^2 + eps)):
+    against fp32 RMSNorm -> linear, for the plain, gate/up and lm_head forms."""
+    W, x, nw = rnd(N, K, seed=1, scale=0.05), rnd(B, K, seed=2, scale=3.0), (1 + 0.2 * rnd(K, seed=5).float()).to(BF)
+    bias = rnd(N, seed=3)
+    xn = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6) * nw.float()
+    ref = xn @ W.float().T
+    Wfm = ops.repack_fm16(W.to(dev), nw.to(dev))
+    close(ops.gemv_fm(Wfm, x.to(dev), N, bias=bias.to(dev), norm_eps=1e-6), ref + bias.float(), 1.5e-2, 1e-2, "gemv_fm folded norm", rel_to_std=True)
+    if N % 32 == 0:
+        I = N // 2
+        close(ops.gemv_swiglu_fm(Wfm, x.to(dev), norm_eps=1e-6), F.silu(ref[:, :I]) * ref[:, I:], 1.5e-2, 2e-2, "gemv_swiglu_fm folded norm",
+              rel_to_std=True)
+    logits = torch.empty(B, N, dtype=BF, device=dev)
+    ids = ops.lm_head_argmax_fm(Wfm, x.to(dev), N, logits=logits, norm_eps=1e-6)
+    close(logits, ref, 1.5e-2, 1e-2, "lm_head_fm folded norm", rel_to_std=True)
+    assert ids.cpu().tolist() == logits.float().cpu().argmax(-1).tolist()
