@@ -700,8 +700,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 // ticket issues an agent-scope acquire, reduces all partials and writes the output (placement-independent
 // release/acquire hand-off; the counter is reset by the reducer, so graph replays need no memset).
 // ----------------------------------------------------------------------------------------------
-template <int D, int G>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(
+template <int D, int G, int NWV, int UR>
+__global__ __launch_bounds__(NWV * 64) void attn_decode_fused_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ pos, const float* __restrict__ cs, bf16_t* __restrict__ kc,
     bf16_t* __restrict__ vc, const int* __restrict__ kv_beg, const int* __restrict__ kv_end, float* __restrict__ part_o,
     float* __restrict__ part_ml, int* __restrict__ cnt, bf16_t* __restrict__ out, int n_kv, int T_max, float scale,
@@ -724,16 +724,17 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     // cache rows of this lane group, requested first: nothing below depends on them until the score loop
     const bf16_t* kbase = kc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
     const bf16_t* vbase = vc + ((size_t)b * n_kv + hk) * (size_t)T_max * D;
-    auto load_rows = [&](int tb_, u32x4 (&kr)[4], u32x4 (&vr)[4]) {
+    constexpr int RSTEP = 4 * NWV;                        // cache rows covered by one instruction of every wave of the block
+    auto load_rows = [&](int tb_, u32x4 (&kr)[UR], u32x4 (&vr)[UR]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = min(tb_ + 16 * u, t1 - 1);      // clamped rows are loaded but not used
+        for (int u = 0; u < UR; ++u) {
+            const int t = min(tb_ + RSTEP * u, t1 - 1);   // clamped rows are loaded but not used
             kr[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
             vr[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
         }
     };
     const int tb0 = t0 + wave * 4 + sub;
-    u32x4 kq[4], vq[4];
+    u32x4 kq[UR], vq[UR];
     if (tb0 < t1) load_rows(tb0, kq, vq);
 
     const bf16_t* row = qkv + (size_t)b * (n_q + 2 * n_kv) * D;
@@ -795,15 +796,15 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         }
     };
 
-    // 4 cache rows per lane group in flight (K and V). The first (at T ~ 1.5k and 32 splits: the only) chunk was requested at
-    // the top of the kernel, before the q loads and RoPE; later chunks are requested one iteration ahead.
-    for (int tb = tb0; tb < t1; tb += 64) {
-        u32x4 kn[4], vn[4];
-        const bool more = tb + 64 < t1;
-        if (more) load_rows(tb + 64, kn, vn);
+    // UR cache rows per lane group in flight (K and V): NWV * 4 * UR rows per block and chunk (8 waves x 8: 256 rows, i.e. the
+    // whole split of a 2k-token context in ONE round trip). The first chunk was requested at the top of the kernel, before the q
+    // loads and RoPE; later chunks are requested one iteration ahead.
+    constexpr int CHUNK = RSTEP * UR;
+    for (int tb = tb0; tb < t1; tb += CHUNK) {
+        const bool more = tb + CHUNK < t1;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (tb + 16 * u < t1) {                       // uniform within the 16-lane row group
+        for (int u = 0; u < UR; ++u) {
+            if (tb + RSTEP * u < t1) {                    // uniform within the 16-lane row group
                 const uint32_t kw[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, vw[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
                 float kf[8], vf[8];
 #pragma unroll
@@ -813,10 +814,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
                 }
                 update(kf, vf);
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { kq[u] = kn[u]; vq[u] = vn[u]; }
+            if (more) {                                   // refill this slot for the next chunk (ring: no second register set)
+                const int t = min(tb + CHUNK + RSTEP * u, t1 - 1);
+                kq[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)t * D + dl);
+                vq[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)t * D + dl);
+            }
         }
     }
     // the current token: last split, wave 0, row sub-group 0 (16 lanes) -- from registers, and appended to the cache
@@ -836,8 +838,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     }
 
     // merge the 4 row sub-groups of the wave, then the 4 waves via LDS
-    __shared__ float sm_m[4][G], sm_l[4][G];
-    __shared__ float sm_o[4][G][D];
+    __shared__ float sm_m[NWV][G], sm_l[NWV][G];
+    __shared__ float sm_o[NWV][G][D];
     __shared__ int sm_last;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -863,14 +865,14 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+    for (int idx = threadIdx.x; idx < G * D; idx += NWV * 64) {
         const int g = idx / D, dd = idx % D;
         float mm = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm_m[w][g]);
+        for (int w = 0; w < NWV; ++w) mm = fmaxf(mm, sm_m[w][g]);
         float ll = 0.f, oo = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NWV; ++w) {
             const float a = (sm_m[w][g] == -INFINITY) ? 0.f : __expf(sm_m[w][g] - mm);
             ll += sm_l[w][g] * a;
             oo += sm_o[w][g][dd] * a;
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     __syncthreads();
     if (!sm_last) return;
     // reducer: wave w owns heads w, w+4 (no LDS, no barriers); each lane 2 head-dim elements, loop over the splits
-    for (int g = wave; g < G; g += 4) {
+    for (int g = wave; g < G; g += NWV) {
         const size_t bh = (size_t)b * n_q + hk * G + g;
         float mr = -INFINITY, lr = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll 4
@@ -1430,10 +1432,15 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
     return 0;
 }
 
+#define ATTN_FUSED_ARGS                                                                                         \
+    (const bf16_t*)qkv, pos, cos_sin, (bf16_t*)k_cache, (bf16_t*)v_cache, kv_beg, kv_end, (float*)ws_o, (float*)ws_ml, counters, \
+        (bf16_t*)out, n_kv, T_max, scale, nsplit, inline_combine
+// wide: 8 waves x 8 rows per lane group = 256 cache rows in flight per block (splits of >= ~100 rows); narrow: 4 x 4 = 64
 #define ATTN_FUSED_LAUNCH(G_)                                                                                   \
-    attn_decode_fused_kernel<128, G_><<<grid, 256, 0, (hipStream_t)stream>>>(                                   \
-        (const bf16_t*)qkv, pos, cos_sin, (bf16_t*)k_cache, (bf16_t*)v_cache, kv_beg, kv_end, (float*)ws_o,      \
-        (float*)ws_ml, counters, (bf16_t*)out, n_kv, T_max, scale, nsplit, inline_combine)
+    do {                                                                                                        \
+        if (wide) attn_decode_fused_kernel<128, G_, 8, 8><<<grid, 512, 0, (hipStream_t)stream>>>(ATTN_FUSED_ARGS); \
+        else attn_decode_fused_kernel<128, G_, 4, 4><<<grid, 256, 0, (hipStream_t)stream>>>(ATTN_FUSED_ARGS);   \
+    } while (0)
 
 // Fused decode attention (RoPE + KV append of the current token + split-KV attention + combine), one launch.
 // kv_end[b] INCLUDES the current token (its slot is kv_end[b]-1). counters: int[B*n_kv], zero before first use.
@@ -1448,6 +1455,8 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
     dim3 grid(nsplit, n_kv, B);
     // combine inline (ticket + last-arriver reduce) or by the separate combine kernel (SPIDER_ATTN_INLINE=0/1)
     static const int inline_combine = [] { const char* e = getenv("SPIDER_ATTN_INLINE"); return e ? atoi(e) : 0; }();
+    static const int wide_env = [] { const char* e = getenv("SPIDER_ATTN_WIDE"); return e ? atoi(e) : -1; }();
+    const bool wide = wide_env >= 0 ? wide_env != 0 : (T_max / nsplit >= 96);
     switch (G) {
         case 1: ATTN_FUSED_LAUNCH(1); break;
         case 2: ATTN_FUSED_LAUNCH(2); break;
