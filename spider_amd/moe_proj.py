@@ -19,6 +19,89 @@ BF16 = torch.bfloat16
 HIDDEN, EXPERTS, LAYERS, HEADS = 512, 3, 4, 4      # hard-coded in the reference (layers.py:156-157,163,172-174)
 
 
+def split_cross_attention(w: Dict[str, torch.Tensor], prefix: str) -> None:
+    """decoder cross-attention of an nn.Transformer state dict under `prefix`: q from the target stream, fused k|v from the memory"""
+    E = HIDDEN
+    for l in range(LAYERS):
+        p = f"{prefix}decoder.layers.{l}.multihead_attn."
+        W, b = w[p + "in_proj_weight"], w[p + "in_proj_bias"]
+        w[p + "q_w"], w[p + "q_b"] = W[:E].contiguous(), b[:E].contiguous()
+        w[p + "kv_w"], w[p + "kv_b"] = W[E:].contiguous(), b[E:].contiguous()
+
+
+def nn_transformer(w: Dict[str, torch.Tensor], t: str, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+    """torch.nn.Transformer(batch_first=True, norm_first=True, d_model=512, 4 + 4 layers, nhead=4, ReLU FFN 2048, dropout 0)
+    as the reference instantiates it (layers.py:67-69,172-174), on the HIP kernels; `t` = state-dict prefix, src [B, S, 512]
+    (encoder input), tgt [B, T, 512] (decoder input); no masks (the reference passes none)."""
+    E = HIDDEN
+    ln = lambda n, x: ops.layernorm(x, w[n + ".weight"], w[n + ".bias"], 1e-5)
+
+    def self_attn(p, y):
+        qkv = ops.gemm(y, w[p + "in_proj_weight"], bias=w[p + "in_proj_bias"])
+        return ops.attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], HEADS)
+
+    x = src
+    for l in range(LAYERS):
+        p = f"{t}encoder.layers.{l}."
+        a = self_attn(p + "self_attn.", ln(p + "norm1", x))
+        x = ops.gemm(a, w[p + "self_attn.out_proj.weight"], bias=w[p + "self_attn.out_proj.bias"], res=x)
+        h = ops.gemm(ln(p + "norm2", x), w[p + "linear1.weight"], bias=w[p + "linear1.bias"], act="relu")
+        x = ops.gemm(h, w[p + "linear2.weight"], bias=w[p + "linear2.bias"], res=x)
+    mem = ln(t + "encoder.norm", x)
+    x = tgt
+    for l in range(LAYERS):
+        p = f"{t}decoder.layers.{l}."
+        a = self_attn(p + "self_attn.", ln(p + "norm1", x))
+        x = ops.gemm(a, w[p + "self_attn.out_proj.weight"], bias=w[p + "self_attn.out_proj.bias"], res=x)
+        q = ops.gemm(ln(p + "norm2", x), w[p + "multihead_attn.q_w"], bias=w[p + "multihead_attn.q_b"])
+        kv = ops.gemm(mem, w[p + "multihead_attn.kv_w"], bias=w[p + "multihead_attn.kv_b"])
+        a = ops.attention(q, kv[..., :E], kv[..., E:], HEADS)
+        x = ops.gemm(a, w[p + "multihead_attn.out_proj.weight"], bias=w[p + "multihead_attn.out_proj.bias"], res=x)
+        h = ops.gemm(ln(p + "norm3", x), w[p + "linear1.weight"], bias=w[p + "linear1.bias"], act="relu")
+        x = ops.gemm(h, w[p + "linear2.weight"], bias=w[p + "linear2.bias"], res=x)
+    return ln(t + "decoder.norm", x)
+
+
+class TextFcLayer:
+    """Per-modality alignment projector of trained Spider when no MoE mode is configured (`output_alignment_MoE_mode is None`,
+    spider.py:200-209): spider/models/layers.py:26-144. Same constructor arguments and `forward(x, modality=None)` contract;
+    `weights` = the reference module's state dict.
+      mode 'linear':       outputs = model(x)                                                  (layers.py:64-65)
+      mode 'transformer':  outputs = model(tfm(fc(x), query_embs.repeat(B, 1, 1)))             (layers.py:66-75,113-124)
+      mode 'qformer' needs the pretrained BERT Q-Former and is not on this path (NotImplementedError, like unknown modes)."""
+
+    def __init__(self, in_dim: int, out_dim: int, num_input_tokens: int = 1, num_output_tokens: int = 1, mode: str = "linear",
+                 device="cuda:0", freeze_qformer=False, weights: Dict[str, torch.Tensor] = None):
+        if mode not in ("linear", "transformer"):
+            raise NotImplementedError(mode)
+        if weights is None:
+            raise ValueError("TextFcLayer needs the reference module's state dict (weights=...)")
+        self.num_input_tokens, self.num_output_tokens, self.mode, self.out_dim = num_input_tokens, num_output_tokens, mode, out_dim
+        self.device = torch.device(device)
+        self.w = {k: v.to(device=self.device, dtype=BF16).contiguous() for k, v in weights.items()}
+        if mode == "transformer":
+            split_cross_attention(self.w, "tfm.")
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, modality=None) -> torch.Tensor:
+        w = self.w
+        x = x.to(device=self.device, dtype=BF16).contiguous()
+        if self.mode == "linear":
+            outputs = ops.gemm(x, w["model.weight"], bias=w["model.bias"])
+        else:
+            h = ops.gemm(x, w["fc.weight"], bias=w["fc.bias"])
+            tgt = w["query_embs"].expand(x.shape[0], -1, -1).contiguous()
+            outputs = ops.gemm(nn_transformer(w, "tfm.", h, tgt), w["model.weight"], bias=w["model.bias"])
+        assert outputs.shape[1] == 1 or (outputs.shape[1] * outputs.shape[2] == self.num_output_tokens * self.out_dim), \
+            (tuple(outputs.shape), self.num_output_tokens)          # layers.py:141-143
+        return outputs
+
+    __call__ = forward
+
+
 class TextFcLayerMoE:
     def __init__(self, in_dim: int, output_alignment_modules: Dict[str, dict], mode: str = "moe_transformer",
                  reconstruct_loss: bool = False, device="cuda:0", weights: Dict[str, torch.Tensor] = None):
@@ -31,14 +114,8 @@ class TextFcLayerMoE:
         self.in_dim, self.output_alignment_modules, self.mode = in_dim, output_alignment_modules, mode
         self.device = torch.device(device)
         self.w = {k: v.to(device=self.device, dtype=BF16).contiguous() for k, v in weights.items()}
-        # decoder cross-attention: q from the target stream, fused k|v from the encoder memory
-        E = HIDDEN
         for e in range(EXPERTS):
-            for l in range(LAYERS):
-                p = f"expert_tfm_layers.{e}.decoder.layers.{l}.multihead_attn."
-                W, b = self.w[p + "in_proj_weight"], self.w[p + "in_proj_bias"]
-                self.w[p + "q_w"], self.w[p + "q_b"] = W[:E].contiguous(), b[:E].contiguous()
-                self.w[p + "kv_w"], self.w[p + "kv_b"] = W[E:].contiguous(), b[E:].contiguous()
+            split_cross_attention(self.w, f"expert_tfm_layers.{e}.")
         # the router's 3 output rows padded to the 4-column granularity of the GEMM epilogue
         for m in output_alignment_modules:
             fw, fb = self.w[f"routers.{m}.fc2.weight"], self.w[f"routers.{m}.fc2.bias"]
@@ -49,36 +126,8 @@ class TextFcLayerMoE:
     def eval(self):
         return self
 
-    # ------------------------------------------------------------------ nn.Transformer pieces
-    def _self_attn(self, p, y):
-        E = HIDDEN
-        qkv = ops.gemm(y, self.w[p + "in_proj_weight"], bias=self.w[p + "in_proj_bias"])
-        return ops.attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], HEADS)
-
     def _transformer(self, t: str, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
-        w = self.w
-        E = HIDDEN
-        ln = lambda n, x: ops.layernorm(x, w[n + ".weight"], w[n + ".bias"], 1e-5)
-        x = src
-        for l in range(LAYERS):
-            p = f"{t}encoder.layers.{l}."
-            a = self._self_attn(p + "self_attn.", ln(p + "norm1", x))
-            x = ops.gemm(a, w[p + "self_attn.out_proj.weight"], bias=w[p + "self_attn.out_proj.bias"], res=x)
-            h = ops.gemm(ln(p + "norm2", x), w[p + "linear1.weight"], bias=w[p + "linear1.bias"], act="relu")
-            x = ops.gemm(h, w[p + "linear2.weight"], bias=w[p + "linear2.bias"], res=x)
-        mem = ln(t + "encoder.norm", x)
-        x = tgt
-        for l in range(LAYERS):
-            p = f"{t}decoder.layers.{l}."
-            a = self._self_attn(p + "self_attn.", ln(p + "norm1", x))
-            x = ops.gemm(a, w[p + "self_attn.out_proj.weight"], bias=w[p + "self_attn.out_proj.bias"], res=x)
-            q = ops.gemm(ln(p + "norm2", x), w[p + "multihead_attn.q_w"], bias=w[p + "multihead_attn.q_b"])
-            kv = ops.gemm(mem, w[p + "multihead_attn.kv_w"], bias=w[p + "multihead_attn.kv_b"])
-            a = ops.attention(q, kv[..., :E], kv[..., E:], HEADS)
-            x = ops.gemm(a, w[p + "multihead_attn.out_proj.weight"], bias=w[p + "multihead_attn.out_proj.bias"], res=x)
-            h = ops.gemm(ln(p + "norm3", x), w[p + "linear1.weight"], bias=w[p + "linear1.bias"], act="relu")
-            x = ops.gemm(h, w[p + "linear2.weight"], bias=w[p + "linear2.bias"], res=x)
-        return ln(t + "decoder.norm", x)
+        return nn_transformer(self.w, t, src, tgt)
 
     # ------------------------------------------------------------------ forward (layers.py:249-268,331)
     @torch.no_grad()

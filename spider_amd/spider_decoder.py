@@ -148,3 +148,66 @@ class SpiderDecoderInfer:
 
     clean_prompt_array = staticmethod(routing.clean_prompt_array)
     extract_story_elements = staticmethod(routing.extract_story_elements)
+
+
+class SpiderStoryFreeInfer:
+    """SpiderStory-free (BASELINE configs[2]): LLM generate -> `extract_story_elements` -> `story_generation`, the
+    `spider_story_free_llama3` branch of demo/inference_api.py:92-149 (`SpiderInference.__call__`).
+
+        infer = SpiderStoryFreeInfer(cfg, llm=LlamaEngine..., tokenizer=..., story_pipe=init_story_generation(...))
+        answers, predictions, predictions_text = infer({"Question": ["a day of a fox"]})
+
+    Kept from the reference: user_input = Question[0] + ". " + cfg.model.system_prompt; the chat template of the tokenizer with
+    add_generation_prompt=True; max_new_tokens = cfg.model.max_context_len (:130); the decoded response goes to BOTH
+    `answers` and predictions_text["IMAGESTORY"] (:132-133); the story is generated only when all three elements parse
+    (:144-149), otherwise the reference's error line is printed. cfg.model may be a dict or an mmengine Config node;
+    llm / tokenizer / story_pipe may be injected (tests, bench) or are loaded from cfg.model.model_path."""
+
+    def __init__(self, cfg, llm=None, tokenizer=None, story_pipe=None, device="cuda:0", story_kwargs: Optional[dict] = None):
+        model_cfg = dict(cfg["model"] if isinstance(cfg, dict) else cfg.model)
+        self.model_config = model_cfg
+        self.model_name = model_cfg.get("name", "spider_story_free_llama3")
+        self.system_prompt = model_cfg.get("system_prompt", "")
+        self.max_new_tokens = int(model_cfg.get("max_context_len", 1024))
+        self.device = device
+        if llm is None:
+            from .llm import LlamaEngine
+            llm = LlamaEngine.from_pretrained(model_cfg["model_path"], device, max_batch=1, max_len=self.max_new_tokens + 2048)
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(model_cfg["model_path"])
+        self.model, self.tokenizer = llm, tokenizer
+        self.story_diffusion = story_pipe
+        self.story_kwargs = dict(story_kwargs or {})
+
+    @torch.no_grad()
+    def __call__(self, samples):
+        answers, predictions, predictions_text = routing.new_outputs()
+        user_input = samples["Question"][0] + ". " + self.system_prompt
+        messages = [{"role": "user", "content": user_input}]
+        prompt = self.tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        inputs = self.tokenizer(prompt, return_tensors="pt")
+        ids = inputs["input_ids"] if isinstance(inputs, dict) else inputs.input_ids
+        am = inputs.get("attention_mask") if isinstance(inputs, dict) else getattr(inputs, "attention_mask", None)
+        budget = self.model.max_len - ids.shape[1]
+        outputs = self.model.generate(input_ids=ids, attention_mask=am, max_new_tokens=max(1, min(self.max_new_tokens, budget)),
+                                      sync_every=16)
+        response = self.tokenizer.decode(outputs[0], skip_special_tokens=True)
+        predictions_text["IMAGESTORY"].append(response)
+        answers.append(response)
+        if len(predictions_text["IMAGESTORY"]) > 0:
+            output_texts = predictions_text["IMAGESTORY"][0]
+            general_prompt, prompt_array, style_name = routing.extract_story_elements(output_texts)
+            if (self.story_diffusion is not None) and general_prompt and prompt_array and isinstance(prompt_array, list) \
+                    and len(prompt_array) > 0 and style_name:
+                from .story import story_generation
+                preds = story_generation(self.story_diffusion, general_prompt=general_prompt, prompt_array=prompt_array,
+                                         style_name=style_name, **self.story_kwargs)
+                predictions["IMAGESTORY"].append(preds)
+                predictions_text["IMAGESTORY_prompts"].append(prompt_array)
+            else:
+                print("Error: One or more required inputs for story_generation are empty!")
+        return answers, predictions, predictions_text
+
+    clean_prompt_array = staticmethod(routing.clean_prompt_array)
+    extract_story_elements = staticmethod(routing.extract_story_elements)

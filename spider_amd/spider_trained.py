@@ -30,10 +30,12 @@ class TrainedSpider:
                  output_alignment_MoE_mode: Optional[str] = "moe_transformer", using_lora: bool = False):
         """llm: spider_amd.llm.LlamaEngine; tokenizer: the LLM tokenizer with the signal tokens added;
         alignment_projs: one TextFcLayerMoE per entry of output_alignment_modules[M]['alignment_layer'] (shared by all
-        modalities, as in the reference's MoE mode); modality_tokens: tokenizer_modules['new_modality_tokens']
+        modalities, as in the reference's MoE mode), or -- output_alignment_MoE_mode=None -- {modality: [TextFcLayer, ...]}; modality_tokens: tokenizer_modules['new_modality_tokens']
         (spider.py:142); pipelines: {'IMAGE'|'VIDEO'|'AUDIO': pipeline object}."""
-        if output_alignment_MoE_mode is None:
-            raise NotImplementedError("per-modality TextFcLayer projections (output_alignment_MoE_mode=None) are not on this path")
+        if output_alignment_MoE_mode is None and not isinstance(alignment_projs, dict):
+            raise ValueError("output_alignment_MoE_mode=None: alignment_projs must be {modality: [TextFcLayer per alignment layer]} "
+                             "(spider.py:200-209)")
+        self.output_alignment_MoE_mode = output_alignment_MoE_mode
         self.llama_model, self.llama_tokenizer = llm, tokenizer
         self.alignment_projs = alignment_projs
         self.output_alignment_modules = output_alignment_modules
@@ -116,7 +118,12 @@ class TrainedSpider:
     # ------------------------------------------------------------------ decoders (spider.py:346-520)
     def _project(self, hidden_list, input_list, modality):
         proj = None
-        for layer_idx, fc_layer in enumerate(self.alignment_projs):
+        if self.output_alignment_MoE_mode is None:      # per-modality TextFcLayer stacks (spider.py:347-351,464-468,502-506)
+            assert modality in self.alignment_projs, f"{modality} alignment projections do not exist !"
+            projs = self.alignment_projs[modality]
+        else:
+            projs = self.alignment_projs
+        for layer_idx, fc_layer in enumerate(projs):
             h = ops.add(hidden_list[layer_idx].to(BF16).contiguous(), input_list[layer_idx].to(BF16).contiguous())
             p = fc_layer(h, modality=modality)
             proj = p if proj is None else ops.add(proj, p)

@@ -125,6 +125,69 @@ def test_story_unet_write_then_read_matches_oracle(dev):
         assert rel < 2.5e-2, (i, rel)
 
 
+def _tiny_story_pipe(dev):
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.story import StableDiffusionXLPipeline
+    from spider_amd.unet import UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    from helpers import FakeTokenizer
+    ocfg, w, cfg = _mk(9)
+    c1 = CLIPCfg(400, 32, 2, 2, 64, 77)
+    w1 = random_weights(clip_param_shapes(c1), seed=1)
+    w2 = random_weights(clip_param_shapes(c1), seed=2)
+    w2["text_projection.weight"] = torch.randn(64, 32) * 0.1
+    vc = VAECfg(4, 3, (64, 64, 64, 128), 1, 32)
+    pipe = StableDiffusionXLPipeline(UNetEngine(cfg, w, dev), VAEDecoderEngine(VAEConfig(**vc.__dict__), random_weights(vae_param_shapes(vc), seed=3), dev),
+                                     CLIPTextEngine(CLIPTextConfig(**c1.__dict__), w1, dev), CLIPTextEngine(CLIPTextConfig(**c1.__dict__), w2, dev),
+                                     FakeTokenizer(), FakeTokenizer(), DDIMScheduler())
+    pipe.enable_freeu(0.6, 0.4, 1.1, 1.2)
+    return pipe
+
+
+def test_spider_story_free_infer_end_to_end(dev):
+    """BASELINE configs[2] wiring (demo/inference_api.py:92-149): Question + ". " + system_prompt -> chat template -> native LLM
+    generate -> decode -> extract_story_elements -> story_generation, containers filled as the reference fills them. The tiny
+    random-weight LLM emits noise, so the tokenizer stand-in decodes it to a scripted response; what is checked is the contract."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    from spider_amd.spider_decoder import SpiderStoryFreeInfer
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, 300, 10000.0, None, 1e-6, True, 256)
+    llm = LlamaEngine(LLMConfig(**ocfg.__dict__), LlamaOracle.random_weights(ocfg, seed=3, std=0.08), dev, max_batch=1, max_len=96)
+    seen = {}
+
+    class Tok:
+        def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+            seen["messages"], seen["agp"] = messages, add_generation_prompt
+            return "<|user|>" + messages[0]["content"] + "<|assistant|>"
+
+        def __call__(self, prompt, return_tensors="pt"):
+            seen["prompt"] = prompt
+            ids = torch.tensor([[3 + (ord(c) % 250) for c in prompt[:40]]])
+            return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+
+        def decode(self, ids, skip_special_tokens=True):
+            seen["n_out"] = int(ids.shape[0])
+            return ("<think>plan</think> <GENERALPROMPT> 'a red fox' </GENERALPROMPT> <PROMPTARRAY> ['wakes up', 'hunts', 'plays', "
+                    "'sleeps', 'dreams'] </PROMPTARRAY> <STYLENAME> 'Comic book' </STYLENAME>")
+
+    cfg = dict(model=dict(type="spider_free", name="spider_story_free_llama3", model_path="unused", system_prompt="SYS", max_context_len=12))
+    infer = SpiderStoryFreeInfer(cfg, llm=llm, tokenizer=Tok(), story_pipe=_tiny_story_pipe(dev),
+                                 story_kwargs=dict(height=64, width=64, num_steps=6, output_type="np"))
+    answers, predictions, predictions_text = infer({"Question": ["a day of a fox"]})
+    assert seen["messages"] == [{"role": "user", "content": "a day of a fox. SYS"}] and seen["agp"] is True
+    assert seen["n_out"] == 40 + 12                                        # prompt + max_context_len new tokens, as HF returns them
+    assert answers == predictions_text["IMAGESTORY"] and "<PROMPTARRAY>" in answers[0]
+    assert predictions_text["IMAGESTORY_prompts"] == [["wakes up", "hunts", "plays", "sleeps", "dreams"]]
+    assert len(predictions["IMAGESTORY"]) == 1 and len(predictions["IMAGESTORY"][0]) == 5      # 4 id panels + 1 real panel
+    assert predictions["IMAGESTORY"][0][0].shape == (64, 64, 3) and predictions["IMAGE"] == []
+    # a response without the three tags: no story, the reference's error path
+    infer.tokenizer.decode = lambda ids, skip_special_tokens=True: "no tags here"
+    a2, p2, t2 = infer({"Question": ["x"]})
+    assert a2 == ["no tags here"] and p2["IMAGESTORY"] == [] and t2["IMAGESTORY_prompts"] == []
+
+
 def test_story_generation_api(dev):
     """story_generation end to end on tiny engines: 4 id images + 1 real image, deterministic for a fixed seed."""
     from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes

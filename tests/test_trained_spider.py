@@ -115,3 +115,37 @@ def test_trained_spider_decode_flow(dev):
     assert a2 == ["[OUTPUT] a random reply without signal tags"] and p2["IMAGE"] == [] and t2["IMAGE"] == []
     with pytest.raises(NotImplementedError):
         ts.generate({"TaskPrompt": ["[IMAGE]"], "Question": ["<IMAGE><IMAGE-Placeholder></IMAGE> what is this"]}, *routing.new_outputs())
+
+
+@pytest.mark.parametrize("mode", ["transformer", "linear"])
+def test_text_fc_layer_matches_torch_modules(dev, mode):
+    """Per-modality `TextFcLayer` (spider/models/layers.py:26-144; used when no MoE mode is configured, spider.py:200-209) on the
+    HIP kernels against the very torch modules the reference instantiates: nn.Linear + nn.Transformer(batch_first, norm_first,
+    d_model 512, 4 + 4 layers, FFN 2048, 4 heads, dropout 0) + learned query embeddings, fp32 on the CPU, seeded weights."""
+    import torch.nn as nn
+    from spider_amd.moe_proj import TextFcLayer
+    torch.manual_seed(7)
+    in_dim, out_dim, n_out = 256, 192, 9
+    if mode == "linear":
+        model = nn.Linear(in_dim, out_dim)
+        sd = {"model." + k: v for k, v in model.state_dict().items()}
+        x = torch.randn(1, 1, in_dim)
+        ref = model(x)
+        layer = TextFcLayer(in_dim, out_dim, 1, 1, mode="linear", device=dev, weights=sd)
+    else:
+        fc, model = nn.Linear(in_dim, 512), nn.Linear(512, out_dim)
+        tfm = nn.Transformer(batch_first=True, norm_first=True, d_model=512, num_encoder_layers=4, num_decoder_layers=4,
+                             dim_feedforward=2048, dropout=0.0, nhead=4).eval()
+        q = torch.randn(1, n_out, 512)
+        sd = {**{"fc." + k: v for k, v in fc.state_dict().items()}, **{"model." + k: v for k, v in model.state_dict().items()},
+              **{"tfm." + k: v for k, v in tfm.state_dict().items()}, "query_embs": q}
+        x = torch.randn(1, 3, in_dim)
+        with torch.no_grad():
+            ref = model(tfm(fc(x), q.repeat(1, 1, 1)))
+        layer = TextFcLayer(in_dim, out_dim, 3, n_out, mode="transformer", device=dev, weights=sd)
+    got = layer(x.to(dev), modality="IMAGE").float().cpu()
+    assert got.shape == ref.shape
+    rel = float((got - ref.detach()).norm() / ref.detach().norm())
+    assert rel < 2e-2, rel                       # bf16 weights / activations against the fp32 modules (8 pre-LN layers)
+    with pytest.raises(NotImplementedError):
+        TextFcLayer(in_dim, out_dim, mode="qformer", device=dev, weights=sd)
