@@ -410,7 +410,8 @@ def measure_story_attention_roofline(device):
     return {"bound": "mfma", "kernel": "attn_flash_kernel<64> keep-bits mask (SDXL consistent self-attention, 768^2: 9216 tokens, 10 heads, d=64, 2 CFG groups)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n,
-            "note": "dense flop count; the kernel skips key tiles whose 64 columns are all masked for the query tile's image"}
+            "note": "dense flop count, as the reference computes it (masked keys are scored and zeroed, no tile is skipped: a 64-key "
+                    "tile with every key masked has probability 2^-64 under the Bernoulli(0.5) keep vector)"}
 
 
 def _ev_ms(fn, n, device):

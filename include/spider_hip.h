@@ -120,6 +120,18 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
 int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
                         int M, int N, int K, int ldc, int act, float eps, void* stream);
 
+/* Fused cross-attention sub-block of BasicTransformerBlock (diffusers-0.25 attention.py, reached from custom_sd.py:634-639):
+ *   out = x + to_out( softmax( to_q(LayerNorm(x)) K^T / sqrt(d) ) V )      for 8 heads and <= 80 text keys, ONE launch.
+ * The prompt's K / V are constant over the denoising loop and are folded into the projections once per prompt:
+ *   Mq[b] [8*80, C] = scale * K_h[b] . Wq_h . diag(gamma)   (key l of head h at row 80 h + l; rows of keys >= n_keys are zero)
+ *   Mo[b] [C, 8*80] = Wo_h . V_h[b]^T
+ *   colsum[b, r] = sum_c Mq[b][r, c],  colbias[b, r] = scale * K_h[b][l] . (Wq_h . beta)      (LayerNorm fold, fp32)
+ * mq_fm / mo_fm are the fragment-major copies of Mq [B2 * 640, C] and Mo [B2 * C, 640] (layout of spider_gemv_fm_bf16's Wfm).
+ * x, out [B2 * n_tok, C] bf16 (sample-major rows); C % 64 == 0, C <= 1280; n_tok % 16 == 0. */
+int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
+                            const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
+                            void* stream);
+
 /* conv2d NHWC as implicit GEMM (ResnetBlock2D / Downsample2D / Upsample2D convs reached from
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,

@@ -77,6 +77,10 @@ class UNetCfg:
                        2048, 32, True, 256, 2816, 10)
 
     @staticmethod
+    def tiny8():     # SD-v1.5-like with 8 attention heads per level (the head count of every SD-v1.5 transformer block)
+        return UNetCfg(4, 4, (64, 128, 128), (True, True, False), (False, True, True), (1, 1, 1), (8, 8, 8), 2, 64, 32, False, 0, 0, None)
+
+    @staticmethod
     def tiny(sdxl_like=False):
         if sdxl_like:
             return UNetCfg(4, 4, (64, 128, 128), (False, True, True), (True, True, False), (1, 2, 2), (1, 2, 2), 2, 64,

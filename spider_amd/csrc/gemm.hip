@@ -171,6 +171,35 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
 }
 
+// 8 consecutive columns per lane (16-byte bias / residual loads and stores): see the tile-pair exchange in write_out
+template <bool ACT>
+__device__ __forceinline__ void epilogue_fast8(const GemmArgs& p, const EpiRsrc& r, int m, int n, uint32_t rb_row_byte, float v[8]) {
+    const uint32_t inv = (uint32_t)(((p.M - 1 - m) | (p.N - 8 - n)) >> 31);       // all ones outside the problem (N % 8 == 0)
+    const uint32_t off = (((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n) * 2u) | inv;
+    const uint32_t noff = ((uint32_t)n * 2u) | inv;
+    auto add8 = [&](const u32x4 q) {
+        v[0] += bf16lo_to_f32(q.x); v[1] += bf16hi_to_f32(q.x); v[2] += bf16lo_to_f32(q.y); v[3] += bf16hi_to_f32(q.y);
+        v[4] += bf16lo_to_f32(q.z); v[5] += bf16hi_to_f32(q.z); v[6] += bf16lo_to_f32(q.w); v[7] += bf16hi_to_f32(q.w);
+    };
+    if (p.bias) add8(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.bias, noff, 0, 0)));
+    if (p.rowbias) add8(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rowbias, (rb_row_byte + (uint32_t)n * 2u) | inv, 0, 0)));
+    if (ACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(p, v[e]);
+    }
+    if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
+        const u32x4 rq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res, off, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+        add8(rq);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    u32x4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
+}
+
 // ---- epilogue shared by the GEMM kernels: lane holds C[mb + i*16 + (lane&15)][nb + j*16 + (lane>>4)*4 + 0..3] ----
 // LayerNorm fold: row statistics {mean, rstd} of the block's rows live in LDS (ln_stat[row - m_blk]); see GemmArgs
 __device__ __forceinline__ void ln_fix(const GemmArgs& p, const float2* ln_stat, int row_in_blk, int n, float v[4]) {
@@ -190,11 +219,44 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
                                           const float2* ln_stat = nullptr, int m_blk = 0) {
     if (EPI <= 1 && p.splits == 1) {
         const EpiRsrc er = make_epi_rsrc(p);
+        // Wide form (N, ldc multiples of 8): the 4 lane groups g = lane >> 4 of a row hold 4 columns each of tile j and of tile
+        // j + 1. One v_permlane16_swap per accumulator register exchanges [tile j, odd g] <-> [tile j + 1, even g]: afterwards
+        // a lane of an even group owns columns 4g .. 4g+7 of tile j and a lane of an odd group columns 4(g-1) .. 4(g-1)+7 of tile
+        // j + 1 -- 8 consecutive columns, so bias / residual / output move as 16-byte accesses, 64 contiguous bytes per row and
+        // wave instruction instead of 32 (the 8-byte form is store-issue and partial-line bound on the UNet's M x 320 outputs).
+        const bool wide = NT >= 2 && ((p.N | p.ldc) & 7) == 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = mb + i * 16 + (lane & 15);
             uint32_t rb_row = 0;
             if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
+            if (wide) {
+                const int g = lane >> 4;
+#pragma unroll
+                for (int j = 0; j + 1 < NT; j += 2) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][j][e]), __float_as_uint(acc[i][j + 1][e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    const int n = nb + (j + (g & 1)) * 16 + 4 * (g & 2);
+                    if (LN) {   // ln_fix works on 4 columns: two halves
+                        ln_fix(p, ln_stat, m - m_blk, n, v);
+                        ln_fix(p, ln_stat, m - m_blk, n + 4, v + 4);
+                    }
+                    epilogue_fast8<EPI == 1>(p, er, m, n, rb_row, v);
+                }
+                if (NT & 1) {
+                    const int j = NT - 1;
+                    const int n = nb + j * 16 + (lane >> 4) * 4;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (LN) ln_fix(p, ln_stat, m - m_blk, n, v);
+                    epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = nb + j * 16 + (lane >> 4) * 4;

@@ -273,6 +273,23 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
     return out
 
 
+XATTN_LP = 80     # keys per head in the folded cross-attention operands (77 text tokens padded to a multiple of 16)
+
+
+def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps=1e-5, out=None):
+    """x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) with the prompt's K / V folded into mq_fm / mo_fm (see
+    include/spider_hip.h, spider_xattn_fused_bf16, and UNetEngine.prepare). x [B2, n_tok, C] or [B2 * n_tok, C] bf16."""
+    _chk(x, BF16, "x"); _chk(mq_fm, BF16, "mq_fm"); _chk(mo_fm, BF16, "mo_fm")
+    _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias"); _chk(bias_o, BF16, "bias_o")
+    C = x.shape[-1]
+    n_tok = x.numel() // (C * B2)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("spider_xattn_fused_bf16", _p(x), _p(mq_fm), _p(mo_fm), _p(colsum), _p(colbias), _p(bias_o), _p(out), B2, n_tok, C,
+              heads, n_keys, float(eps), _stream())
+    return out
+
+
 def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None):
     """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]."""
     _chk(x, BF16, "x"); _chk(w, BF16, "w")

@@ -145,6 +145,26 @@ class UNetEngine:
             self.ln[b + ".attn2"] = ops.fold_layernorm(w2, W[b + ".norm2.weight"], W[b + ".norm2.bias"])
             self.ln[b + ".ff"] = ops.fold_layernorm(W[b + ".ff.net.0.proj.weight"], W[b + ".norm3.weight"], W[b + ".norm3.bias"],
                                                     W[b + ".ff.net.0.proj.bias"])
+        # Fused cross-attention sub-block (ops.xattn_fused): weight-only halves of the per-prompt fold (prepare() finishes it
+        # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
+        self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
+        self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
+        self.xw: Dict[str, dict] = {}
+        for b in list(self.ln):
+            if not b.endswith(".attn2"):
+                continue
+            l = b[:-len(".attn2")]
+            W = self.w
+            Wq = W[l + ".attn2.to_q.weight"]
+            C = Wq.shape[0]
+            if C % 64 != 0 or C > 1280 or self._heads_of(l) != 8 or ".temp_attentions." in l or l.startswith("transformer_in"):
+                continue
+            g2, b2 = W[l + ".norm2.weight"].float(), W[l + ".norm2.bias"].float()
+            wqb4 = torch.zeros(4, C, dtype=BF16, device=dv)
+            wqb4[0] = (Wq.float() @ b2).to(BF16)
+            self.xw[l] = dict(wqt_g=(Wq.float() * g2[None, :]).t().contiguous().to(BF16), wqb4=wqb4)
+        self._ones4 = {}
+        self.xf: Dict[str, dict] = {}
         # resnet table: order of time_emb_proj consumers
         self.resnets = [k[:-len(".time_emb_proj.weight")] for k in self.w if k.endswith(".time_emb_proj.weight")]
         self.tproj_w = torch.cat([self.w[r + ".time_emb_proj.weight"] for r in self.resnets], 0).contiguous()
@@ -161,6 +181,16 @@ class UNetEngine:
         self._graph = None
         self._graph_key = None
         self.kv: Dict[str, torch.Tensor] = {}
+
+    def _heads_of(self, layer: str) -> int:
+        """attention heads of the transformer block `layer` (diffusers: attention_head_dim per block of the config)"""
+        cfg = self.cfg
+        parts = layer.split(".")
+        if parts[0] == "down_blocks":
+            return cfg.heads[int(parts[1])]
+        if parts[0] == "up_blocks":
+            return list(reversed(cfg.heads))[int(parts[1])]
+        return cfg.heads[-1]
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -246,11 +276,51 @@ class UNetEngine:
             self._rows = rows
             self.kv = {} if self.self_cross else {
                 l: torch.empty(B2, enc.shape[1], self.w[l + ".attn2.kv"].shape[0], dtype=BF16, device=dv) for l in self.cross_layers}
+            self.xf = {}
+            if not self.self_cross and self.fuse_xattn and frames == 1 and enc.shape[1] <= ops.XATTN_LP:
+                HL = 8 * ops.XATTN_LP
+                for l in self.cross_layers:
+                    if l in self.xw:
+                        C = self.xw[l]["wqt_g"].shape[0]
+                        self.xf[l] = dict(kexp=torch.zeros(B2, 8, ops.XATTN_LP, 8, C // 8, dtype=BF16, device=dv),
+                                          vexp=torch.zeros(B2, 8, ops.XATTN_LP, 8, C // 8, dtype=BF16, device=dv),
+                                          mq=torch.empty(B2 * HL, C, dtype=BF16, device=dv), mo=torch.empty(B2 * C, HL, dtype=BF16, device=dv),
+                                          mq_fm=torch.empty(B2 * HL // 16, C // 64, 2, 64, 8, dtype=BF16, device=dv),
+                                          mo_fm=torch.empty(B2 * C // 16, HL // 64, 2, 64, 8, dtype=BF16, device=dv),
+                                          cs=torch.empty(B2 * HL, dtype=torch.float32, device=dv),
+                                          cb=torch.empty(B2 * HL, dtype=torch.float32, device=dv))
             self._graph = None
             self.B2, self._enc_len = B2, enc.shape[1]
         if not self.self_cross:
             for l in self.cross_layers:
                 ops.gemm(enc, self.w[l + ".attn2.kv"], out=self.kv[l])           # [B2, 77, 2C]
+            for l, f in self.xf.items():
+                self._fold_cross(l, f, B2, enc.shape[1])
+
+    def _fold_cross(self, l: str, f: dict, B2: int, n_keys: int):
+        """Once per prompt: fold the text K / V of cross-attention layer `l` into its q / out projections (operands of
+        ops.xattn_fused, written in place so that a captured step graph stays valid). Data movement in torch, arithmetic on the
+        MFMA GEMM: Mq = scale * Kexp . (Wq diag(gamma2)), Mo = Wo . Vexp^T with Kexp / Vexp the block-diagonal head expansion."""
+        w, xw = self.w, self.xw[l]
+        C = xw["wqt_g"].shape[0]
+        H, LP, d = 8, ops.XATTN_LP, C // 8
+        HL = H * LP
+        kv = self.kv[l]
+        ar = torch.arange(H, device=kv.device)
+        f["kexp"][:, ar, :n_keys, ar, :] = kv[..., :C].reshape(B2, n_keys, H, d).permute(2, 0, 1, 3)
+        f["vexp"][:, ar, :n_keys, ar, :] = kv[..., C:].reshape(B2, n_keys, H, d).permute(2, 0, 1, 3)
+        kexp, vexp = f["kexp"].view(B2 * HL, C), f["vexp"].view(B2, HL, C)
+        scale = 1.0 / math.sqrt(d)
+        ops.gemm(kexp, xw["wqt_g"], out_scale=scale, out=f["mq"])                                 # [B2*HL, C]
+        if C not in self._ones4:
+            o4 = torch.zeros(4, C, dtype=BF16, device=kv.device); o4[0] = 1.0
+            self._ones4[C] = o4
+        f["cs"].copy_(ops.gemm(f["mq"], self._ones4[C], out_f32=True)[:, 0])
+        f["cb"].copy_(ops.gemm(kexp, xw["wqb4"], out_scale=scale, out_f32=True)[:, 0])
+        for b in range(B2):
+            ops.gemm(w[l + ".attn2.to_out.0.weight"], vexp[b], out=f["mo"][b * C:(b + 1) * C])  # [C, HL]
+        f["mq_fm"].copy_(ops.repack_fm16(f["mq"]))
+        f["mo_fm"].copy_(ops.repack_fm16(f["mo"]))
 
     # ------------------------------------------------------------------ blocks
     def _gn(self, n, x, silu, eps=1e-5):
@@ -312,11 +382,18 @@ class UNetEngine:
             else:
                 o = self._self_attn(b, ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"]), heads)
             h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
-            if fuse:
-                o = self._cross_attn(b, h, heads, ln_input=True)
+            xf = self.xf.get(b) if fuse else None
+            # Fused where it wins (measured, scripts/bench_xattn.py: 17 vs 31 us at 2 x 4096 tokens / C = 320, 22 vs 29 us at
+            # 2 x 1024 / 640): with fewer than ~64 row tiles (the 16^2 / 8^2 maps at C = 1280: 46 vs 34 us, 36 vs 29 us) one block's
+            # serial chain of 20 + 20 dependent operand loads is longer than the three launches it replaces, which spread over the chip.
+            if xf is not None and (H * W_) % 16 == 0 and B * H * W_ >= self.xattn_min_rows:   # norm2 + to_q + attention + to_out + residual
+                h = ops.xattn_fused(h, xf["mq_fm"], xf["mo_fm"], xf["cs"], xf["cb"], w[b + ".attn2.to_out.0.bias"], B, heads, self._enc_len)
             else:
-                o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
-            h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
+                if fuse:
+                    o = self._cross_attn(b, h, heads, ln_input=True)
+                else:
+                    o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
+                h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
             if fuse:       # norm3 + GEGLU projection: one launch
                 g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
             else:

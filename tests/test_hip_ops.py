@@ -545,3 +545,36 @@ def test_skinny_fragment_major_folded_rmsnorm(ops, dev, B, N, K):
     ids = ops.lm_head_argmax_fm(Wfm, x.to(dev), N, logits=logits, norm_eps=1e-6)
     close(logits, ref, 1.5e-2, 1e-2, "lm_head_fm folded norm", rel_to_std=True)
     assert ids.cpu().tolist() == logits.float().cpu().argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("B2,n_tok,C,n_keys", [(2, 4096, 320, 77), (2, 1024, 640, 77), (2, 256, 1280, 77), (1, 64, 1280, 77), (2, 48, 64, 33)])
+def test_xattn_fused(ops, dev, B2, n_tok, C, n_keys):
+    """Fused cross-attention sub-block (LayerNorm + to_q + attention over <= 80 text keys + to_out + residual in one launch, the
+    text K / V folded into the projections) against the fp32 composition of the separate ops."""
+    H, d, LP = 8, C // 8, 80
+    x = rnd(B2, n_tok, C, seed=1)
+    Wq, Wo, bo = rnd(C, C, seed=2, scale=1.5 / math.sqrt(C)), rnd(C, C, seed=3, scale=1.0 / math.sqrt(C)), rnd(C, seed=4, scale=0.1)
+    K, V = rnd(B2, n_keys, C, seed=5), rnd(B2, n_keys, C, seed=6)
+    ga, be = (1 + 0.2 * rnd(C, seed=7).float()).to(BF), rnd(C, seed=8, scale=0.2)
+    # fp32 reference
+    y = F.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5)
+    q = (y @ Wq.float().T).view(B2, n_tok, H, d).transpose(1, 2)
+    kh, vh = K.float().view(B2, n_keys, H, d).transpose(1, 2), V.float().view(B2, n_keys, H, d).transpose(1, 2)
+    att = torch.softmax(q @ kh.transpose(-1, -2) / math.sqrt(d), -1) @ vh
+    ref = x.float() + att.transpose(1, 2).reshape(B2, n_tok, C) @ Wo.float().T + bo.float()
+    # fold (what UNetEngine._fold_cross does), with torch fp32 for the small products
+    HL = H * LP
+    kexp, vexp = torch.zeros(B2, H, LP, H, d), torch.zeros(B2, H, LP, H, d)
+    ar = torch.arange(H)
+    kexp[:, ar, :n_keys, ar, :] = K.float().view(B2, n_keys, H, d).permute(2, 0, 1, 3)
+    vexp[:, ar, :n_keys, ar, :] = V.float().view(B2, n_keys, H, d).permute(2, 0, 1, 3)
+    kexp, vexp = kexp.view(B2 * HL, C), vexp.view(B2, HL, C)
+    scale = 1 / math.sqrt(d)
+    mq = ((kexp @ (Wq.float() * ga.float()[None, :])) * scale).to(BF)                       # [B2*HL, C]
+    cs = mq.float().sum(1)
+    cb = (kexp @ (Wq.float() @ be.float())) * scale
+    mo = torch.cat([(Wo.float() @ vexp[b].T) for b in range(B2)], 0).to(BF)                  # [B2*C, HL]
+    got = ops.xattn_fused(x.to(dev), ops.repack_fm16(mq.to(dev)), ops.repack_fm16(mo.to(dev)), cs.to(dev).contiguous(), cb.to(dev).contiguous(),
+                          bo.to(dev), B2, H, n_keys, eps=1e-5)
+    close(got, ref, 2e-2, 1e-2, "xattn_fused", rel_to_std=True)
+    assert float((got.float().cpu() - ref).norm() / ref.norm()) < 6e-3

@@ -47,6 +47,41 @@ def test_unet_step_matches_oracle(dev, sdxl_like):
         assert r < 2.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
 
 
+def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
+    """8-head config (SD-v1.5's head count): every cross-attention sub-block runs as the ONE-launch fused kernel with the prompt's
+    K / V folded into the projections (spider_xattn_fused_bf16). Against the fp32 oracle, and against the unfused HIP path."""
+    from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
+    from spider_amd.unet import UNetConfig, UNetEngine
+    ocfg = UNetCfg.tiny8()
+    w = random_unet_weights(ocfg, seed=4)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 16, 24, generator=g).bfloat16().float()
+    enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    ref = UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng.prepare(torch.tensor([500]), enc.to(dev))
+    assert len(eng.xf) == len(eng.cross_layers) > 0, "the 8-head config must take the fused cross-attention path"
+    fused = eng.step(xn, 0, use_graph=False).permute(0, 3, 1, 2).clone()
+    graph = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
+    assert torch.equal(fused, graph)
+    monkeypatch.setenv("SPIDER_XATTN_FUSE", "0")
+    eng2 = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng2.prepare(torch.tensor([500]), enc.to(dev))
+    assert len(eng2.xf) == 0
+    unfused = eng2.step(xn, 0, use_graph=False).permute(0, 3, 1, 2)
+    r_f, r_u, d = _rel(fused, ref), _rel(unfused, ref), _rel(fused, unfused.float().cpu())
+    print(f"rel L2 vs fp32 oracle: fused {r_f:.4f}  unfused {r_u:.4f}  fused-vs-unfused {d:.4f}")
+    assert r_f < 2.5e-2 and r_f < 1.3 * r_u + 2e-3
+    # a second prompt re-folds in place: same buffers (a captured graph stays valid), new result
+    ptrs = {l: f["mq_fm"].data_ptr() for l, f in eng.xf.items()}
+    enc2 = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
+    eng.prepare(torch.tensor([500]), enc2.to(dev))
+    assert ptrs == {l: f["mq_fm"].data_ptr() for l, f in eng.xf.items()}
+    again = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
+    assert _rel(again, UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc2)) < 2.5e-2
+
+
 @pytest.mark.parametrize("sdxl_like", [False, True])
 def test_unet_blocks_match_oracle(dev, sdxl_like):
     """Every block class in isolation (inputs rounded to bf16, taken from the oracle): one bf16 rounding of the block
