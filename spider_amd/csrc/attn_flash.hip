@@ -132,10 +132,12 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             const uint32_t inv = ld_inv[i] | (uint32_t)((lk_end - 1 - key) >> 31);
             rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, ((uint32_t)key * (uint32_t)p.k_rs * 2u + ld_cb[i]) | inv, 0, 0));
             rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)key * (uint32_t)p.v_rs * 2u + ld_cb[i]) | inv, 0, 0));
-            if (ONES) rv[i].x = (ld_cb[i] == (uint32_t)p.d * 2u && key < lk_end && tid + i * 256 < 64 * C::CPR) ? 0x3F80u : rv[i].x;   // V[key][d] = 1.0
         }
     };
-    auto store_tile = [&](int buf) {
+    // `t` = the tile these registers hold. The ones column (V[key][d] = 1.0) is patched HERE, at the LDS write, not where the
+    // loads are issued: patched at the load, the wave waited for the V loads at the top of every tile (vmcnt right behind the
+    // buffer_load), i.e. their latency sat in front of the QK^T MFMAs instead of behind the whole tile's compute.
+    auto store_tile = [&](int buf, int t) {
         bf16_t* Kd = lds0 + buf * IMG;
         bf16_t* Vd = Kd + 64 * C::KS;
 #pragma unroll
@@ -143,16 +145,23 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             const int c = tid + i * 256;
             if (c < 64 * C::CPR) {
                 const int row = c / C::CPR, ch = c % C::CPR;
+                u32x4 vv = rv[i];
+                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u && t * 64 + row < lk_end) ? 0x3F80u : vv.x;
                 *reinterpret_cast<u32x4*>(Kd + row * C::KS + ch * 8) = rk[i];
-                *reinterpret_cast<u32x4*>(Vd + row * C::VS + ch * 8) = rv[i];
+                *reinterpret_cast<u32x4*>(Vd + row * C::VS + ch * 8) = vv;
             }
         }
     };
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile(0);
+        store_tile(0, t_begin);
     }
+    // Retire the Q loads HERE: their first use is the QK^T MFMA inside the tile loop, where the compiler cannot count how many
+    // K / V prefetch loads were issued after them and waited with vmcnt(0) at the top of EVERY tile -- draining the prefetch of
+    // tile t+1 in front of the MFMAs of tile t instead of behind them.
+#pragma unroll
+    for (int ks = 0; ks < DP / 16; ++ks) asm volatile("" ::"v"(qf[ks]));
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 }
         }
 
-        if (t + 1 < t_end) store_tile(cur ^ 1);   // buffer cur^1 was last read in iteration t-1, before its barrier
+        if (t + 1 < t_end) store_tile(cur ^ 1, t + 1);   // buffer cur^1 was last read in iteration t-1, before its barrier
         __syncthreads();
     }
 
