@@ -249,17 +249,32 @@ def measure_roofline(resp, device):
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
-    pm = os.path.join(ROOT, "profiles", "r01_pmc_decode_hbm.json")
-    if os.path.exists(pm) and bytes_alg == 271633408:
-        try:
-            traffic = json.load(open(pm))["dominant_kernel"]["hbm_read_bytes_corrected"]
-            src = "profiles/r01_pmc_decode_hbm.json"
-        except Exception:
-            pass
+    for tag in ("r02", "r01"):
+        pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode_hbm.json")
+        if os.path.exists(pm) and bytes_alg == 271633408:
+            try:
+                traffic = json.load(open(pm))["dominant_kernel"]["hbm_read_bytes_corrected"]
+                src = f"profiles/{tag}_pmc_decode_hbm.json"
+                break
+            except Exception:
+                pass
     return {"bound": "hbm", "kernel": "gemv_kernel<NB=1,R=1,GATEUP=1,XLDS=1> (decode gate/up + SwiGLU)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
             "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n}
+
+
+def _unet_pmc_traffic(kernel_prefix):
+    """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r02_pmc_unet_hbm.json:
+    averages over every launch of that kernel in the UNet step, not only the roofline shape -- stated in `traffic_source`)."""
+    pm = os.path.join(ROOT, "profiles", "r02_pmc_unet_hbm.json")
+    try:
+        for k in json.load(open(pm))["kernels"]:
+            if k["kernel"].startswith(kernel_prefix):
+                return k["hbm_read_bytes"] + k["hbm_write_bytes"], f"profiles/r02_pmc_unet_hbm.json (average over the {k['launches']} launches of this kernel in the profiled UNet steps)"
+    except Exception:
+        pass
+    return None, None
 
 
 def measure_mfma_roofline(device):
@@ -289,7 +304,8 @@ def measure_mfma_roofline(device):
     flops = 2 * 8192 * 320 * 2880
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,3,CONV> + splitk_reduce (UNet 3x3 conv, 64x64 latent, 320->320, batch 2)",
-            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": _unet_pmc_traffic("gemm_dma_kernel<160, 3, true, 0>")[0], "traffic_source": _unet_pmc_traffic("gemm_dma_kernel<160, 3, true, 0>")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
@@ -321,7 +337,8 @@ def measure_attention_roofline(device):
     flops = 4 * N * N * C * B
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "attn_flash_kernel<64> (UNet self-attention, 64x64 latent: 4096 tokens, 8 heads, d=40, batch 2)",
-            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": _unet_pmc_traffic("attn_flash_kernel<64, true>")[0], "traffic_source": _unet_pmc_traffic("attn_flash_kernel<64, true>")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 

@@ -160,21 +160,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 // instruction), U chunks deep; activations are staged once per block in LDS as bf16 (XLDS) or, when
 // NB*K*2 bytes exceed the LDS budget, re-read through L2.
 // ----------------------------------------------------------------------------------------------
-template <int NB, int R, bool GATEUP, bool XLDS>
-__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+template <int NB, int R, bool GATEUP, bool XLDS, int NWB = 4>
+__global__ __launch_bounds__(NWB * 64) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                    bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ res, const bf16_t* __restrict__ norm_w,
                                                    float eps, int N, int K, int hoist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [NB][K] when XLDS
-    __shared__ float red[4];
+    __shared__ float red[NWB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NR = GATEUP ? 2 * R : R;  // weight rows per wave
     constexpr int U = (NR * NB <= 4) ? 4 : 2;  // chunks in flight per row
 
     // Row pointers first; with `hoist` the first weight chunks are requested BEFORE the activation prologue (the
     // weight stream does not depend on x), so their HBM latency overlaps the RMSNorm / LDS staging below.
-    const int col0 = (blockIdx.x * 4 + wave) * R;
+    const int col0 = (blockIdx.x * NWB + wave) * R;
     const bf16_t* wrow[NR];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
             u32x4* sv = reinterpret_cast<u32x4*>(xs + (size_t)b * K);
             if (norm_w) {
                 float ss = 0.f;
-                for (int i = threadIdx.x; i < nv; i += 256) {
+                for (int i = threadIdx.x; i < nv; i += NWB * 64) {
                     u32x4 a = xv[i];
                     uint32_t aw[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
                         ss += lo * lo + hi * hi;
                     }
                 }
-                const float rs = rsqrtf(block_sum<4>(ss, red) / (float)K + eps);
+                const float rs = rsqrtf(block_sum<NWB>(ss, red) / (float)K + eps);
                 const u32x4* wv = reinterpret_cast<const u32x4*>(norm_w);
-                for (int i = threadIdx.x; i < nv; i += 256) {
+                for (int i = threadIdx.x; i < nv; i += NWB * 64) {
                     u32x4 a = xv[i], wq = wv[i];
                     uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w}, o[4];
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
                     sv[i] = ov;
                 }
             } else {
-                for (int i = threadIdx.x; i < nv; i += 256) sv[i] = xv[i];
+                for (int i = threadIdx.x; i < nv; i += NWB * 64) sv[i] = xv[i];
             }
         }
         __syncthreads();
@@ -1181,10 +1181,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_fm_kernel(const bf16_t* __rest
     }
 }
 
+#define GEMV_ARGS (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w, eps, N, K, hoist
+// wide8: 8 waves per block share one LDS copy of the activations (long-K projections: the 38 KB copy of a K = 18944 vector per
+// 4-row block is 25 % of the block's weight bytes and caps the resident waves per CU)
 #define GEMV_LAUNCH(NB_, R_, GU_, XL_)                                                                         \
-    gemv_kernel<NB_, R_, GU_, XL_><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(          \
-        (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res,             \
-        (const bf16_t*)norm_w, eps, N, K, hoist)
+    do {                                                                                                        \
+        if (wide8) gemv_kernel<NB_, R_, GU_, XL_, 8><<<(N + 8 * R_ - 1) / (8 * R_), 512, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(GEMV_ARGS); \
+        else gemv_kernel<NB_, R_, GU_, XL_, 4><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(GEMV_ARGS); \
+    } while (0)
 
 static int gemv_env_r() {
     static const int v = [] { const char* e = getenv("SPIDER_GEMV_R"); return e ? atoi(e) : 0; }();
@@ -1205,6 +1209,8 @@ static int gemv_dispatch(const void* W, const void* x, void* out, const void* bi
     if (GU && R > 2) R = 2;
     if (NB > 4 && R > 2) R = 2;
     const int grid = (N + 4 * R - 1) / (4 * R);
+    static const int wide_env = [] { const char* e = getenv("SPIDER_GEMV_WIDE8"); return e ? atoi(e) : -1; }();
+    const bool wide8 = wide_env >= 0 ? wide_env != 0 : (!GU && K >= 8192 && NB == 1);
 #define GEMV_PICK(R_)                                   \
     do {                                                \
         if (xlds) GEMV_LAUNCH(NB, R_, GU, true);        \
