@@ -223,6 +223,10 @@ int spider_lincomb_f32(const float* const* host_ins, const float* host_coefs, in
 int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream);
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream);
 
+/* StoryDiffusion keep vector -> bit words for spider_attn_bf16's keep_bits (cal_attn_mask_xl, utils/gradio_utils.py:241-287, reduced to
+ * the random per-key keep decision): bit j % 64 of word j / 64 = (u[j] < thr) for j < n_valid, 0 beyond. u [n] fp32 on the device. */
+int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, float thr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

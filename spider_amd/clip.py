@@ -98,12 +98,21 @@ class CLIPTextEngine:
         return cls(cfg, w, device)
 
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor, return_all: bool = False):
+    def encode(self, ids: torch.Tensor, return_all: bool = False, use_graph: bool = True):
         """ids [B, S<=77] int -> last_hidden_state [B, S, H] bf16. With return_all: dict(last, penultimate, pooled) --
         SDXL conditions on hidden_states[-2] of both encoders and on the projected pooled state of the second
-        (StableDiffusionXLPipeline.encode_prompt, reached from Comic_Generation.py:440)."""
-        c = self.cfg
+        (StableDiffusionXLPipeline.encode_prompt, reached from Comic_Generation.py:440).
+        The plain form replays one hipGraph per id shape (12-32 layers x 7 launches of a few microseconds each)."""
         ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        if use_graph and not return_all:
+            if not hasattr(self, "_graph"):
+                from .graphs import GraphRunner
+                self._graph = GraphRunner(lambda i: self._encode(i, False))
+            return self._graph(ids)
+        return self._encode(ids, return_all)
+
+    def _encode(self, ids: torch.Tensor, return_all: bool):
+        c = self.cfg
         B, S = ids.shape
         h = ops.add(ops.embed(self.tok, ids), self.pos[:S][None].expand(B, S, c.hidden).contiguous())
         d = c.hidden // c.heads

@@ -50,6 +50,10 @@ struct GemmArgs {
     // without ups lim_h/lim_w = Hin/Win. cin64: a 64-wide K tile never straddles two taps (uniform tap per tile).
     int conv, Hin, Win, Cin, Hout, Wout, kh, kw, stride, pad_h, pad_w, dil, ups, lim_h, lim_w, cin64;
     int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
+    // tile order: 0 = m fastest (neighbouring blocks share a W tile: LLM prefill, W >> A), 1 = n fastest (they share the A tile:
+    // the UNet's 8192-row activations against 320..2560 output columns -- with m fastest every column tile re-streamed all of A
+    // through its XCD's 4 MiB L2: FETCH_SIZE 58 MB per GEGLU projection whose operands are 7 MB)
+    int n_fast;
     // LayerNorm folded into the GEMM (LN instantiations): C = rstd[m] * (A.W'^T - mean[m] * colsum[n]) + colbias[n], with
     // W' = W * diag(gamma) (folded by the caller), colsum[n] = sum_k W'[n,k], colbias[n] = sum_k beta[k] W[n,k] + bias[n];
     // the row statistics of A (K = the whole normalised row) are accumulated by the block itself while it stages A.
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int ncols = GEGLU ? 2 * p.N : p.N;   // GEGLU: a BN-wide W tile yields BN/2 output columns
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (ncols + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = bid % tiles_m, tn = bid / tiles_m;  // m fastest: neighbours share the W tile
+    const int tm = p.n_fast ? bid / tiles_n : bid % tiles_m, tn = p.n_fast ? bid % tiles_n : bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
 
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int tm = p.n_fast ? bid / tiles_n : bid % tiles_m, tn = p.n_fast ? bid % tiles_n : bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
 
@@ -843,6 +847,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // SPIDER_GEMM_TILE = 160 / 161 (4-stage ring) / 129 (128 x 128 DMA tile): force the LDS-DMA kernel (tuning aid)
     static const int dbg = env_int("SPIDER_GEMM_DBG");
     a.dbg = dbg;
+    static const int nfast_env = getenv("SPIDER_GEMM_NFAST") ? atoi(getenv("SPIDER_GEMM_NFAST")) : -1;
+    a.n_fast = nfast_env >= 0 ? nfast_env : (a.M > ncols ? 1 : 0);
     int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : (force_tile == 65 ? 64 : 0));
     // Measured on MI355X (scripts/bench_gemm.py with GEMM_CFGS): with >= 2048 rows and >= 16 K tiles the LDS-DMA kernel wins
     // (UNet convs at 64^2 / 32^2: 33 vs 46 us, 48 vs 70, 32 vs 43, 47 vs 64; at 16^2 with 8 K splits 30 vs 41, 48 vs 63); below that the register-staged

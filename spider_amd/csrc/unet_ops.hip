@@ -732,6 +732,16 @@ inline int grid_for(size_t n) {
 
 }  // namespace
 
+// StoryDiffusion keep vector -> bit words (cal_attn_mask_xl reduced to its information content, gradio_utils.py:241-287):
+// bit j of word w = (u[64 w + j] < thr) && (64 w + j < n_valid). One ballot per wave: no host round trip per UNet step.
+__global__ __launch_bounds__(256) void pack_keep_kernel(const float* __restrict__ u, unsigned long long* __restrict__ words, int n,
+                                                        int n_valid, float thr) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = idx < n && idx < n_valid && u[idx] < thr;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && idx < ((n + 63) / 64) * 64) words[idx >> 6] = m;
+}
+
 extern "C" {
 
 int spider_groupnorm_nchunk(int HW) {
@@ -969,6 +979,14 @@ int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, int n
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad shape");
     nhwc_to_nchw_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(x, y, B, C, HW, mul, add, clamp01);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// u [n] fp32 uniforms in [0, 1); words [ceil(n / 64)] uint64: bit j % 64 of word j / 64 = (u[j] < thr) for j < n_valid, else 0
+int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, float thr, void* stream) {
+    SPIDER_CHECK(n > 0 && n_valid >= 0, "pack_keep_bits: bad length");
+    pack_keep_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(u, (unsigned long long*)words, n, n_valid, thr);
     SPIDER_LAUNCH_OK();
     return 0;
 }

@@ -70,6 +70,7 @@ SIGNATURES = {
     "spider_cfg_combine_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "spider_lincomb_f32": (_i, [_vp, _vp, _i, _vp, _l, _vp]),
     "spider_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "spider_pack_keep_bits_f32": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "spider_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }
 

@@ -632,3 +632,13 @@ def softmax_rows(x, scale=1.0, n_valid=None, out=None):
     _lib.call("spider_softmax_rows_f32_bf16", _p(x), _p(out), x.numel() // n, n, n if n_valid is None else n_valid, float(scale),
               _stream())
     return out
+
+
+def pack_keep_bits(u: torch.Tensor, thr: float, n_valid: int) -> torch.Tensor:
+    """u [n] fp32 uniforms on the device -> int64 [ceil(n / 64)] bit words: bit j = (u[j] < thr) for j < n_valid (keep vector of
+    StoryDiffusion's consistent self-attention, layout of spider_attn_bf16's keep_bits). No host synchronisation."""
+    _chk(u, torch.float32, "u")
+    n = u.numel()
+    words = torch.empty((n + 63) // 64, dtype=torch.int64, device=u.device)
+    _lib.call("spider_pack_keep_bits_f32", _p(u), _p(words), n, int(n_valid), float(thr), _stream())
+    return words

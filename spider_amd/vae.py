@@ -147,9 +147,18 @@ class VAEDecoderEngine:
         return out.view(B, H, W_, C)
 
     @torch.no_grad()
-    def decode(self, latents: torch.Tensor, to_image: bool = True) -> torch.Tensor:
+    def decode(self, latents: torch.Tensor, to_image: bool = True, use_graph: bool = True) -> torch.Tensor:
         """latents fp32 NCHW [B,4,h,w] (scheduler space) -> image fp32 NCHW [B,3,8h,8w] in [0,1].
-        to_image=False returns the raw decoder output (AudioLDM's mel spectrogram, custom_ad.py:288-291)."""
+        to_image=False returns the raw decoder output (AudioLDM's mel spectrogram, custom_ad.py:288-291).
+        One hipGraph per latent shape (the decoder is ~150 launches of 5-40 us kernels)."""
+        if use_graph:
+            if not hasattr(self, "_graphs"):
+                from .graphs import GraphRunner
+                self._graphs = {True: GraphRunner(lambda z: self._decode(z, True)), False: GraphRunner(lambda z: self._decode(z, False))}
+            return self._graphs[bool(to_image)](latents.contiguous())
+        return self._decode(latents, to_image)
+
+    def _decode(self, latents: torch.Tensor, to_image: bool) -> torch.Tensor:
         c, w = self.cfg, self.w
         z = ops.latent_to_nhwc(latents.contiguous())
         z = ops.conv2d_small_cin(z, w["post_quant_conv.weight_scaled"], w["post_quant_conv.bias"]) if c.latent % 8 == 0 else \

@@ -216,3 +216,19 @@ def test_story_generation_api(dev):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert pipe.unet.self_attn_hook is None
+
+
+def test_keep_bits_packed_on_device_match_host_packing(dev):
+    """The production mask path (device uniforms -> one ballot kernel) gives exactly the words of the host packing used by the
+    reference-pinned tests, incl. the forced-False tail beyond id_length blocks and a ragged last word."""
+    from spider_amd import ops
+    from spider_amd.story import StoryState, pack_keep_bits
+    for n, n_valid, thr in ((5 * 576, 4 * 576, 0.5), (5 * 100, 4 * 100, 0.3), (130, 130, 0.9)):
+        u = torch.rand(n, generator=torch.Generator().manual_seed(n))
+        keep = u < thr
+        keep[n_valid:] = False
+        got = ops.pack_keep_bits(u.to(dev), thr, n_valid).cpu()
+        assert torch.equal(got, pack_keep_bits(keep)), (n, n_valid)
+    st = StoryState(total_count=1, height=64, width=64)
+    st.regen_masks(dev)
+    assert st.keep1024 is None and st.keep_bits(True, 4 * 4, dev).is_cuda and st.keep_bits(False, 5 * 16, dev).dtype == torch.int64
