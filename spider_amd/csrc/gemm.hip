@@ -566,12 +566,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int NS, bool CONV, int EPI>
+template <int BN, int NS, bool CONV, int EPI, int BM = 128>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
-    constexpr int BM = 128;
+    // BM = 128: wave tile 32 x BN/2. BM = 64 (wave tile 16 x BN/2): twice the row tiles for problems whose 128-row tiling leaves
+    // the chip half empty -- the UNet's 3x3 convs at 8192 rows then need no split-K, i.e. no fp32 slab round trip through HBM
+    // (42 MB written + re-read per conv against a 5 MB output) and no reduce launch.
+    static_assert(BM == 128 || BM == 64, "row tile");
     constexpr int ROWS = BM + BN;
-    constexpr int STAGE = ROWS * 128;                 // bytes per stage: [A tile 128 rows | W tile BN rows], 128-byte rows
-    constexpr int MT = 2, NT = BN / 32;               // 16x16 MFMA tiles per wave (wave tile 32 x BN/2)
+    constexpr int STAGE = ROWS * 128;                 // bytes per stage: [A tile BM rows | W tile BN rows], 128-byte rows
+    constexpr int MT = BM / 64, NT = BN / 32;         // 16x16 MFMA tiles per wave (wave tile BM/4 x BN/2)
     constexpr int AJ = BM / 64;                       // A pieces per wave (8 rows each, 8 waves)
     constexpr int WP = BN / 8;                        // W pieces in all
     constexpr int WJ = (WP + 7) / 8;                  // W pieces per wave, upper bound
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
-    const int a_rd = (wm * 32 + frow) * 128, w_rd = (BM + wn * (BN / 2) + frow) * 128;
+    const int a_rd = (wm * (BM / 4) + frow) * 128, w_rd = (BM + wn * (BN / 2) + frow) * 128;
     bf16x8 af[MT], wf[NT];
     auto read_frags = [&](int stage, int ks) {
         const char* sb = smem + stage * STAGE;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     }
     wait_vmcnt<0>();                            // the masked tail DMAs must not outlive the workgroup's LDS allocation
 
-    write_out<MT, NT, EPI>(p, acc, m0 + wm * 32, n0 + wn * (BN / 2), split, lane);
+    write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane);
 }
 
 // split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
@@ -771,30 +774,30 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
 }
 
 // LDS-DMA kernel launch: BN = 160 or 128, NS-stage ring in dynamic LDS (> 64 KiB: raised once per instantiation)
-template <int BN, int NS, bool CONV, int EPI>
+template <int BN, int NS, bool CONV, int EPI, int BM = 128>
 void launch_dma_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
-    constexpr int smem = NS * (128 + BN) * 128;
+    constexpr int smem = NS * (BM + BN) * 128;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<BN, NS, CONV, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<BN, NS, CONV, EPI, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         once = true;
     }
-    gemm_dma_kernel<BN, NS, CONV, EPI><<<grid, 512, smem, st>>>(a);
+    gemm_dma_kernel<BN, NS, CONV, EPI, BM><<<grid, 512, smem, st>>>(a);
 }
 
-template <int BN, int NS>
+template <int BN, int NS, int BM = 128>
 void launch_dma(const GemmArgs& a, int tiles, hipStream_t st) {
     dim3 grid(tiles, a.splits);
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
     if (a.conv) {
-        if (epi == 3) launch_dma_inst<BN, NS, true, 3>(a, grid, st);
-        else if (epi == 1) launch_dma_inst<BN, NS, true, 1>(a, grid, st);
-        else launch_dma_inst<BN, NS, true, 0>(a, grid, st);
+        if (epi == 3) launch_dma_inst<BN, NS, true, 3, BM>(a, grid, st);
+        else if (epi == 1) launch_dma_inst<BN, NS, true, 1, BM>(a, grid, st);
+        else launch_dma_inst<BN, NS, true, 0, BM>(a, grid, st);
     } else {
-        if (epi == 3) launch_dma_inst<BN, NS, false, 3>(a, grid, st);
-        else if (epi == 1) launch_dma_inst<BN, NS, false, 1>(a, grid, st);
-        else launch_dma_inst<BN, NS, false, 0>(a, grid, st);
+        if (epi == 3) launch_dma_inst<BN, NS, false, 3, BM>(a, grid, st);
+        else if (epi == 1) launch_dma_inst<BN, NS, false, 1, BM>(a, grid, st);
+        else launch_dma_inst<BN, NS, false, 0, BM>(a, grid, st);
     }
 }
 
@@ -856,8 +859,14 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // Only where N fills the 160-wide tiles (<= 8 % padding: the VAE's 128 / 256 / 512 channels would waste 25 %), and for
     // plain linears only with a long K (at K = 1280 the tower / FF projections measured slower on it).
     const int n160 = (a.N + 159) / 160;
+    int dma_bm = 128;
+    static const int bm64_env = getenv("SPIDER_GEMM_BM64") ? atoi(getenv("SPIDER_GEMM_BM64")) : 1;
     if (!force_tile && !a.geglu && a.M >= (a.conv ? 512 : 2048) && nk >= (a.conv && a.M >= 2048 ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
-        const int tdma = ((a.M + 127) / 128) * n160;
+        // 64-row tiles when the 128-row tiling gives at most ~half a wave of blocks (<= 160) AND K is short (< 64 tiles): the
+        // 8192 x 320 x 2880 convs -> 256 tiles, no split-K (measured 29.7 vs 33.8 us); with a longer K the 16 x 80 wave tile's
+        // lower MFMA density costs more than the slab round trip of 2 splits (640 -> 320 at 64^2: 55 vs 49 us)
+        if (bm64_env && ((a.M + 127) / 128) * n160 <= 160 && a.M >= 1024 && nk < 64) dma_bm = 64;
+        const int tdma = ((a.M + dma_bm - 1) / dma_bm) * n160;
         int ds = 1;
         if (nk >= 40) {
             ds = (256 + tdma / 2) / tdma;
@@ -884,9 +893,10 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
     if (dma_bn && !a.geglu) {
-        const int tdma = ((a.M + 127) / 128) * ((a.N + dma_bn - 1) / dma_bn);
+        const int tdma = ((a.M + dma_bm - 1) / dma_bm) * ((a.N + dma_bn - 1) / dma_bn);
         if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
         else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
+        else if (dma_bn == 160 && dma_bm == 64) launch_dma<160, 4, 64>(a, tdma, st);
         else if (dma_bn == 160) launch_dma<160, 3>(a, tdma, st);
         else launch_dma<128, 4>(a, tdma, st);
     } else if (small) launch_tile<64, 64>(a, tiles, st);
