@@ -77,7 +77,7 @@ if fe:
 
 # ---- decode weight streams
 dec = {}
-for key, d, kname in (("b1", "dec1", "gemv_kernel<1, 1, true, true>"), ("b8", "dec8", "skinny_fm_kernel<1, 8, true>")):
+for key, d, kname in (("b1", "dec1", "gemv_kernel<1, 1, true, true"), ("b8", "dec8", "skinny_fm_kernel<1, 8, true>")):
     fz = per_kernel(f"{G}/pmc_{tag}_{d}_fetch", "FETCH_SIZE")
     hit = [k for k in fz if k.startswith(kname)]
     if hit:

@@ -92,7 +92,8 @@ def test_audio_unet_step_matches_oracle(dev, hw):
         graph = eng.step(xn, i, use_graph=True).permute(0, 3, 1, 2)
         assert torch.equal(eager.cpu(), graph.cpu())
         r = _rel(eager, ref)
-        assert r < 2.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
+        print(f"MEASURED audio_unet_step t={int(t)} rel={r:.5f}")
+        assert r < 1.6e-2, f"t={int(t)}: rel L2 {r:.4f}"      # measured 1.15 - 1.27e-2 (+20 %)
 
 
 def test_audio_vae_decode_matches_oracle(dev):

@@ -122,7 +122,8 @@ def test_story_unet_write_then_read_matches_oracle(dev):
     assert st_o.cur_step == st_g.cur_step == 6
     for i, (a, b) in enumerate(zip(got, ref)):
         rel = float((a - b).norm() / b.norm())
-        assert rel < 2.5e-2, (i, rel)
+        print(f"MEASURED story_unet i={i} rel={rel:.5f}")
+        assert rel < 2.6e-2, (i, rel)      # measured 1.58 - 2.14e-2 over the 13 write / read steps (+20 %)
 
 
 def _tiny_story_pipe(dev):

@@ -1,11 +1,12 @@
 """GPU: native UNet step / denoising loop (spider_amd/unet.py on the HIP kernels) against the fp32 CPU oracle
 (oracle/unet.py -- diffusers-0.25 restatement, parity unpinned upstream) on tiny SD-v1.5-like and SDXL-like configs.
 
-Tolerances are relative L2 errors against the fp32 oracle, derived from bf16 storage (half-ulp 2^-9 = 2.0e-3):
-  * every block (resnet / transformer / conv) measured 1.7e-3 .. 6e-3 in isolation (scripts/debug_unet_blocks.py),
-    i.e. one bf16 rounding of its output; a whole evaluation chains ~25 blocks -> sqrt(25) * 3e-3 ~ 1.5e-2
-    measured; bound 2.5e-2
-  * latents after a coarse 6-8 step loop: measured 2.9e-2 (each coarse step weighs eps heavily); bound 5e-2.
+Tolerances are relative L2 errors against the fp32 oracle, derived from bf16 storage (half-ulp 2^-9 = 2.0e-3) and set at the
+value measured on MI355X + 20 % (round 2; the tests print their measured value as `MEASURED ...` under -s):
+  * every block (resnet / transformer / conv / attention) in isolation: measured 1.7e-3 .. 6.0e-3, bound 8e-3
+    (test_unet_blocks_match_oracle)
+  * a whole evaluation chains ~25 blocks -> sqrt(25) * 3e-3 ~ 1.5e-2: measured 1.44 - 1.58e-2, bound 1.9e-2 (FreeU 1.96e-2 -> 2.4e-2)
+  * latents after a coarse 6-8 step loop: measured 2.4 - 2.7e-2 (each coarse step weighs eps heavily), bound 3.2e-2.
 north_star asks for 1e-3 relative on the latents; a bf16 tensor alone is only exact to 2e-3, so that target needs
 an fp32 residual stream -- tracked in DESIGN.md ("numerics"), not asserted here.
 """
@@ -13,6 +14,12 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+# measured on MI355X (printed by the tests as MEASURED ...) + 20 %: one UNet evaluation 1.44 - 1.58e-2, FreeU 1.96e-2, loops 2.4 - 2.7e-2
+UNET_STEP_BOUND = 1.9e-2
+FREEU_BOUND = 2.4e-2
+LOOP_BOUND = 3.2e-2
 
 
 def _rel(a, b):
@@ -44,7 +51,8 @@ def test_unet_step_matches_oracle(dev, sdxl_like):
         graph = eng.step(xn, i, use_graph=True).permute(0, 3, 1, 2)
         assert torch.equal(eager.cpu(), graph.cpu()), "hipGraph replay must be bit-identical to eager launches"
         r = _rel(eager, ref)
-        assert r < 2.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
+        print(f"MEASURED unet_step sdxl_like={sdxl_like} t={int(t)} rel={r:.5f}")
+        assert r < UNET_STEP_BOUND, f"t={int(t)}: rel L2 {r:.4f}"
 
 
 def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
@@ -72,14 +80,14 @@ def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
     unfused = eng2.step(xn, 0, use_graph=False).permute(0, 3, 1, 2)
     r_f, r_u, d = _rel(fused, ref), _rel(unfused, ref), _rel(fused, unfused.float().cpu())
     print(f"rel L2 vs fp32 oracle: fused {r_f:.4f}  unfused {r_u:.4f}  fused-vs-unfused {d:.4f}")
-    assert r_f < 2.5e-2 and r_f < 1.3 * r_u + 2e-3
+    assert r_f < UNET_STEP_BOUND and r_f < 1.3 * r_u + 2e-3
     # a second prompt re-folds in place: same buffers (a captured graph stays valid), new result
     ptrs = {l: f["mq_fm"].data_ptr() for l, f in eng.xf.items()}
     enc2 = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
     eng.prepare(torch.tensor([500]), enc2.to(dev))
     assert ptrs == {l: f["mq_fm"].data_ptr() for l, f in eng.xf.items()}
     again = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
-    assert _rel(again, UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc2)) < 2.5e-2
+    assert _rel(again, UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc2)) < UNET_STEP_BOUND
 
 
 @pytest.mark.parametrize("sdxl_like", [False, True])
@@ -164,7 +172,7 @@ def test_unet_step_vs_bf16_reference_emulation(dev):
     got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), 0, use_graph=False).permute(0, 3, 1, 2)
     e_hip, e_emul, d = _rel(got, ref32), _rel(ref16, ref32), _rel(got, ref16)
     print(f"rel L2: hip-vs-fp32 {e_hip:.4f}  torch-bf16-vs-fp32 {e_emul:.4f}  hip-vs-torch-bf16 {d:.4f}")
-    assert e_hip < 2.5e-2
+    assert e_hip < UNET_STEP_BOUND
     assert e_hip < 1.5 * e_emul + 2e-3, (e_hip, e_emul)   # not worse than a bf16 run of the reference graph itself
 
 
@@ -184,7 +192,8 @@ def test_denoise_loop_matches_oracle(dev, sched_name, steps):
     got = denoise(eng, sched, lat.to(dev), enc.to(dev), 7.5, steps)
     assert got.shape == lat.shape
     r = _rel(got, ref)
-    assert r < 5e-2, f"latents rel L2 {r:.5f}"
+    print(f"MEASURED denoise_loop {sched_name} rel={r:.5f}")
+    assert r < LOOP_BOUND, f"latents rel L2 {r:.5f}"
 
 
 def test_freeu_matches_oracle(dev):
@@ -203,7 +212,8 @@ def test_freeu_matches_oracle(dev):
     got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), 0, use_graph=False).permute(0, 3, 1, 2)
     ref = oracle.forward(x, torch.tensor(300), enc, added)
     r_on = _rel(got, ref)
-    assert r_on < 2.5e-2
+    print(f"MEASURED freeu rel={r_on:.5f}")
+    assert r_on < FREEU_BOUND
     oracle.freeu = None
     r_off = _rel(got, oracle.forward(x, torch.tensor(300), enc, added))
     assert r_off > 3 * r_on, (r_on, r_off)  # FreeU really changes the result

@@ -1,7 +1,7 @@
 """GPU: the text-to-video path (UNet3DConditionModel behind custom_vd.py:671-676 and
 the TextToVideoSDPipeline loop :664-697) on the HIP kernels against the fp32 CPU oracle (oracle/unet3d.py -- a
 diffusers-0.25 restatement, parity unpinned upstream). Tolerances as in test_unet_engine.py (relative L2, bf16 storage);
-the 3-D UNet chains roughly twice as many blocks per evaluation as the 2-D one: bound 3.5e-2."""
+measured 1.58 - 1.64e-2 on MI355X for one evaluation of the tiny 3-D UNet, bound 2.0e-2 (measured + 20 %)."""
 import numpy as np
 import pytest
 import torch
@@ -62,7 +62,8 @@ def test_unet3d_step_matches_oracle(dev, frames, hw):
         graph = _from_engine(eng.step(xn, i, use_graph=True), 2, frames)
         assert torch.equal(eager.cpu(), graph.cpu()), "hipGraph replay must be bit-identical to eager launches"
         r = _rel(eager, ref)
-        assert r < 3.5e-2, f"t={int(t)}: rel L2 {r:.4f}"
+        print(f"MEASURED unet3d_step frames={frames} t={int(t)} rel={r:.5f}")
+        assert r < 2.0e-2, f"t={int(t)}: rel L2 {r:.4f}"      # measured 1.58 - 1.64e-2 (+20 %)
 
 
 def test_video_denoise_loop_matches_oracle(dev):
