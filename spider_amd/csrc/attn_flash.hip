@@ -16,6 +16,7 @@
 // for its own image block, gradio_utils.py:257-285), so it is passed as a bit vector over the keys plus the
 // image block length instead of a dense [4N,4N] bool matrix.
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace spider;
 
@@ -58,7 +59,11 @@ struct Cfg {
 // ONES (head_dim < DP, e.g. the UNet's d = 40 / 80 in 64 / 96-wide tiles): the first padded V column is staged as 1.0, so
 // the PV MFMA accumulates the softmax denominator (of the bf16-rounded probabilities it actually multiplies) in an O^T
 // row that would otherwise hold zeros -- 32 adds per lane and K tile leave a loop whose SIMD issue port is the bottleneck.
-template <int DP, bool ONES>
+// PLAIN (dense attention: no causal mask, no keep vector, no left padding, no packed tiles -- every UNet / VAE / tower-free call):
+// the mask arithmetic, its scalar state and the per-tile "is this tile fully visible" test are compiled out; every tile but a
+// ragged last one takes the predicate-free path. The general instantiation spilled scalars into VGPR lanes (v_readlane in the
+// tile loop) and spent ~60 SALU + ~80 non-essential VALU instructions per 64-key tile in a loop whose issue port is the limit.
+template <int DP, bool ONES, bool PLAIN>
 __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
     const int hk = hq / (p.Hq / p.Hkv);
     int q0 = qt * 128, lq_end = p.Lq, seg_kbeg = 0, lk_end = p.Lk;
-    if (p.tiles) {
+    if (!PLAIN && p.tiles) {
         const int* rec = p.tiles + 4 * qt;
         q0 = rec[0]; lq_end = rec[0] + rec[1]; seg_kbeg = rec[2]; lk_end = rec[2] + rec[3];
     }
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     }
 
     // ---- key range for this query tile ----
-    const int kbeg = p.kv_beg ? p.kv_beg[b] : seg_kbeg;
+    const int kbeg = PLAIN ? 0 : (p.kv_beg ? p.kv_beg[b] : seg_kbeg);
     int kend = lk_end;
-    if (p.causal) kend = min(kend, q0 + 128 + p.kv_off);
+    if (!PLAIN && p.causal) kend = min(kend, q0 + 128 + p.kv_off);
     const int t_begin = kbeg / 64;
     const int t_end = (kend + 63) / 64;
 
-    const int own_lo = p.blk > 0 ? ((qi + p.q_off) / p.blk) * p.blk : 0;
+    const int own_lo = (!PLAIN && p.blk > 0) ? ((qi + p.q_off) / p.blk) * p.blk : 0;
     const int own_hi = own_lo + p.blk;
     const int caus_max = qi + p.kv_off;  // last visible key when causal
 
@@ -188,8 +193,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         // Fast path (wave-uniform): a tile entirely inside [kbeg, Lk), below the causal diagonal of every row of
         // this wave and without a keep vector needs no per-element predicates: max, one fma + exp2, add.
         const int wave_q0 = q0 + wave * 32;
-        const bool full_tile = (t * 64 >= kbeg) && (t * 64 + 64 <= lk_end) && !p.keep_bits &&
-                               (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off);
+        const bool full_tile = PLAIN ? (t * 64 + 64 <= lk_end)
+                                     : ((t * 64 >= kbeg) && (t * 64 + 64 <= lk_end) && !p.keep_bits &&
+                                        (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off));
         float psum = 0.f, alpha;
         if (full_tile) {
             // four independent chains for the max and for the sum: a single 32-long dependent chain costs its full latency
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             float tmax = fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3]));
             tmax = fmaxf(tmax, partner32(tmax)) * p.scale_log2e;
             const float m_new = fmaxf(m_run, tmax);
-            alpha = exp2f(m_run - m_new);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // <= 0: the bare v_exp_f32 (exp2f() adds a denormal-range fix-up)
             float ps4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             // predicate is needed (per-element `ok ? exp2f(..) : 0` compiled to 32 divergent branches per tile -- the whole
             // consistent-self-attention path and every causal diagonal tile went through them).
             const int key0 = t * 64 + 4 * h32;                       // key = key0 + kt*32 + (r&3) + 8*(r>>2)
-            const int hi_lim = p.causal ? min(lk_end, caus_max + 1) : lk_end;
+            const int hi_lim = (!PLAIN && p.causal) ? min(lk_end, caus_max + 1) : lk_end;
             float tmax = -1e30f;
-            if (p.keep_bits) {
+            if (!PLAIN && p.keep_bits) {
                 const unsigned long long kl = p.keep_bits[t] >> (4 * h32);
                 const uint32_t klo = (uint32_t)kl, khi = (uint32_t)(kl >> 32);
 #pragma unroll
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             }
             tmax = fmaxf(tmax, partner32(tmax));
             const float m_new = fmaxf(m_run, tmax);
-            alpha = exp2f(m_run - m_new);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             const float m_use = m_new < -1e29f ? 0.f : m_new;     // row with no visible key so far: keep every p at 0
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -340,13 +346,241 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form for dense attention over whole 64-key tiles (UNet / VAE-free self-attention: Lk % 64 == 0, >= 2 tiles).
+// With 2 x 8 heads x 4096 queries the grid has exactly two waves per SIMD, so a wave's serial chain QK^T -> softmax -> PV sets
+// the time (the instruction count does not: removing 100 of 350 instructions per tile changed nothing). Here the QK^T MFMAs of
+// tile t+1 are issued under the softmax VALU work of tile t -- two independent dependency chains in one wave:
+//     iteration t:  S_next = K(t+1) . Q^T   ||   P = softmax(S_cur)      then      O^T += V(t)^T . P^T
+// K is consumed one iteration ahead of V, so the two LDS images hold {K(t+1), V(t)} while {K(t+2), V(t+1)} are in registers;
+// one barrier per tile as before.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DP, bool ONES>
+__global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kernel(AttnArgs p) {
+    using C = Cfg<DP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* const Kb = reinterpret_cast<bf16_t*>(smem);                  // 2 x [64][KS]
+    bf16_t* const Vb = Kb + 2 * 64 * C::KS;                              // 2 x [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h32 = lane >> 5, l32 = lane & 31;
+    const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    const int hk = hq / (p.Hq / p.Hkv);
+    const int q0 = qt * 128, lk_end = p.Lk;
+    const int qi = q0 + wave * 32 + l32;
+    const bool q_ok = qi < p.Lq;
+    const bf16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
+    const bf16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
+    const bf16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
+
+    bf16x8 qf[DP / 16];
+#pragma unroll
+    for (int ks = 0; ks < DP / 16; ++ks) {
+        const int dd = ks * 16 + h32 * 8;
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (q_ok && dd < p.d) t = *reinterpret_cast<const u32x4*>(qb + (long)qi * p.q_rs + dd);
+        qf[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+    const int nt = lk_end / 64;
+
+    f32x16 acc_o[DP / 32];
+#pragma unroll
+    for (int i = 0; i < DP / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    auto span = [&](long rs) { const long b_ = ((long)(lk_end - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, span(p.k_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, span(p.v_rs), 0x00020000);
+    u32x4 rk[C::NCH], rv[C::NCH];
+    uint32_t ld_row[C::NCH], ld_cb[C::NCH], ld_inv[C::NCH];
+#pragma unroll
+    for (int i = 0; i < C::NCH; ++i) {
+        const int c = tid + i * 256;
+        ld_row[i] = (uint32_t)(c / C::CPR);
+        ld_cb[i] = (uint32_t)(c % C::CPR) * 16u;
+        ld_inv[i] = ((c < 64 * C::CPR) && (c % C::CPR) * 8 < p.d) ? 0u : 0xFFFFFFFFu;
+    }
+    // tiles past the end are requested with all-ones offsets (zeros): the loop body needs no "is there a next tile" branch
+    auto load_k = [&](int t) {
+        const uint32_t tinv = (uint32_t)((nt - 1 - t) >> 31);
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i)
+            rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, ((uint32_t)(t * 64 + (int)ld_row[i]) * (uint32_t)p.k_rs * 2u + ld_cb[i]) | ld_inv[i] | tinv, 0, 0));
+    };
+    auto load_v = [&](int t) {
+        const uint32_t tinv = (uint32_t)((nt - 1 - t) >> 31);
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i)
+            rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)(t * 64 + (int)ld_row[i]) * (uint32_t)p.v_rs * 2u + ld_cb[i]) | ld_inv[i] | tinv, 0, 0));
+    };
+    auto store_k = [&](int buf) {
+        bf16_t* Kd = Kb + buf * 64 * C::KS;
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < 64 * C::CPR) *reinterpret_cast<u32x4*>(Kd + (c / C::CPR) * C::KS + (c % C::CPR) * 8) = rk[i];
+        }
+    };
+    auto store_v = [&](int buf) {
+        bf16_t* Vd = Vb + buf * 64 * C::VS;
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < 64 * C::CPR) {
+                u32x4 vv = rv[i];
+                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u) ? 0x3F80u : vv.x;       // V[key][d] = 1.0 (every key of a whole tile is valid)
+                *reinterpret_cast<u32x4*>(Vd + (c / C::CPR) * C::VS + (c % C::CPR) * 8) = vv;
+            }
+        }
+    };
+    auto qk = [&](int buf, f32x16 (&s)[2]) {
+        const bf16_t* Ks = Kb + buf * 64 * C::KS;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const bf16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
+#pragma unroll
+            for (int ks = 0; ks < DP / 16; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: K(0), V(0), K(1) staged; S_cur = scores of tile 0
+    load_k(0); load_v(0);
+    store_k(0); store_v(0);
+    load_k(1);
+    store_k(1);
+#pragma unroll
+    for (int ks = 0; ks < DP / 16; ++ks) asm volatile("" ::"v"(qf[ks]));      // retire the Q loads before the loop (see above)
+    __syncthreads();
+    f32x16 sc[2], sn[2];
+    qk(0, sc);
+
+    const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+    for (int t = 0; t < nt; ++t) {
+        load_k(t + 2);
+        load_v(t + 1);
+        // ---- [B] online softmax of tile t (independent of [A]: the scheduler interleaves the two chains)
+        float tm[4] = {sc[0][0], sc[0][1], sc[0][2], sc[0][3]};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tm[r & 3] = fmaxf(tm[r & 3], sc[kt][r]);
+        float tmax = fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3]));
+        tmax = fmaxf(tmax, partner32(tmax)) * p.scale_log2e;
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int i = 0; i < DP / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[i][r] *= alpha;
+        }
+        // ---- [A] S_next = K(t+1) . Q^T   (tile nt reads a zero / stale image: its scores are never used)
+        qk((t + 1) & 1, sn);
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], p.scale_log2e, -m_new));
+                sc[kt][r] = pv;
+                if (!ONES) ps4[r & 3] += pv;
+            }
+        m_run = m_new;
+        if (!ONES) {
+            float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            psum += partner32(psum);
+            l_run = l_run * alpha + psum;
+        }
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                u32x4 t4;
+                t4.x = pack_bf16x2(sc[kt][8 * sx + 0], sc[kt][8 * sx + 1]);
+                t4.y = pack_bf16x2(sc[kt][8 * sx + 2], sc[kt][8 * sx + 3]);
+                t4.z = pack_bf16x2(sc[kt][8 * sx + 4], sc[kt][8 * sx + 5]);
+                t4.w = pack_bf16x2(sc[kt][8 * sx + 6], sc[kt][8 * sx + 7]);
+                pf[kt][sx] = __builtin_bit_cast(bf16x8, t4);
+            }
+        // ---- [C] O^T += V(t)^T . P^T
+        const bf16_t* Vs = Vb + (t & 1) * 64 * C::VS;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const int r0 = kt * 32 + 16 * sx + 4 * h32 + (i16 >> 2);
+                    const int c0 = db * 32 + 16 * g16 + 4 * (i16 & 3);
+                    const bf16_t* a0 = Vs + r0 * C::VS + c0;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * C::VS));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][sx], acc_o[db], 0, 0, 0);
+                }
+        }
+        // ---- stage K(t+2) (its image held K(t), last read in iteration t-1) and V(t+1) (held V(t-1))
+        store_k(t & 1);
+        store_v((t + 1) & 1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) sc[kt] = sn[kt];
+        __syncthreads();
+    }
+
+    if (ONES) {
+        float l = 0.f;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (db * 32 + 8 * g == p.d) l = acc_o[db][4 * g];
+        l_run = __shfl(l, l32, 64);
+    }
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        bf16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
+#pragma unroll
+        for (int db = 0; db < DP / 32; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = db * 32 + 8 * g + 4 * h32;
+                if (dd < p.d) {
+                    u32x2 o2;
+                    o2.x = pack_bf16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
+                    o2.y = pack_bf16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(ob + dd) = o2;
+                }
+            }
+    }
+}
+
 template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
     const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
-    if (a.d < DP) attn_flash_kernel<DP, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
-    else attn_flash_kernel<DP, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    const bool plain = !a.causal && !a.keep_bits && !a.kv_beg && !a.tiles;
+    static const int pipe_env = [] { const char* e = getenv("SPIDER_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+    if (plain && pipe_env && a.Lk % 64 == 0 && a.Lk >= 128 && DP <= 96) {      // software-pipelined dense form (whole 64-key tiles)
+        if (a.d < DP) attn_flash_pipe_kernel<DP, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+        else attn_flash_pipe_kernel<DP, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+        SPIDER_LAUNCH_OK();
+        return 0;
+    }
+    if (a.d < DP) {
+        if (plain) attn_flash_kernel<DP, true, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+        else attn_flash_kernel<DP, true, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    } else {
+        if (plain) attn_flash_kernel<DP, false, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+        else attn_flash_kernel<DP, false, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+    }
     SPIDER_LAUNCH_OK();
     return 0;
 }
