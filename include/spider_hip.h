@@ -178,6 +178,12 @@ int spider_rope_rows_bf16(void* x, const float* cos_sin, long row_stride, int ro
 int spider_groupnorm_nchunk(int HW);
 int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
                                int C, int G, float eps, int silu, void* stream);
+/* The same GroupNorm on the channel concatenation [x1 | x2] without materialising it first: UpBlock2D / UpBlock3D's
+ * torch.cat([hidden_states, res_hidden_states], dim=1) followed by ResnetBlock2D.norm1 (diffusers unet_2d_blocks, called from
+ * custom_sd.py:634-639). x1 [B,HW,C1], x2 [B,HW,C2] are read in place; y [B,HW,C1+C2] is the normalised (+SiLU) result and
+ * cat [B,HW,C1+C2] receives the concatenated input (the resnet's 1x1 conv_shortcut reads it). C1, C2 multiples of 8. */
+int spider_groupnorm_cat_nhwc_bf16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
+                                   void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream);
 int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                           void* stream);
 /* GEGLU (diffusers FeedForward): y[m,n] = x[m,n] * gelu(x[m,inner+n]) */

@@ -17,8 +17,11 @@ namespace {
 // Block = (C/8)*KP threads: thread -> fixed 8-channel vector, pixel lane; so per-channel sums live
 // in registers and are reduced over pixel lanes through LDS. partial: [B, nchunk, G, 2] fp32.
 // ------------------------------------------------------------------------------------------
+// Skip-concat form (x2 != nullptr): the input is the channel concatenation [x | x2] (UpBlock2D's cat([hidden, skip])) with
+// C1 channels in x; the kernel reads the two sources in place and writes the concatenated tensor to `cat` on the way (the
+// shortcut conv and pass 2 read it) -- the separate concat launch and its read pass are gone.
 __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
-                                int nchunk, int KP) {
+                                int nchunk, int KP, const bf16_t* __restrict__ x2, int C1, bf16_t* __restrict__ cat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sm_s = reinterpret_cast<float*>(smem);   // [KP][C]
     float* sm_q = sm_s + KP * C;                    // [KP][C]
@@ -30,7 +33,10 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-    const bf16_t* xb = x + (size_t)b * HW * C;
+    // this thread's 8-channel vector comes from x (row stride ld = C or C1) or, past C1, from x2 (row stride C - C1)
+    const bool second = x2 != nullptr && v * 8 >= C1;
+    const int ld = second ? C - C1 : (x2 ? C1 : C);
+    const bf16_t* xb = (second ? x2 + (size_t)b * HW * ld + (v * 8 - C1) : x + (size_t)b * HW * ld + v * 8);
     // 4 independent 16-byte loads in flight per thread (a runtime-trip loop with one load per iteration would
     // serialise the L2/HBM round trips)
     for (int px = p0 + pl; px < p1; px += 4 * KP) {
@@ -38,7 +44,14 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pp = px + u * KP;
-            a[u] = pp < p1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)pp * C + v * 8) : u32x4{0u, 0u, 0u, 0u};
+            a[u] = pp < p1 ? *reinterpret_cast<const u32x4*>(xb + (size_t)pp * ld) : u32x4{0u, 0u, 0u, 0u};
+        }
+        if (cat) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = px + u * KP;
+                if (pp < p1) *reinterpret_cast<u32x4*>(cat + ((size_t)b * HW + pp) * C + v * 8) = a[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -174,7 +187,8 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
 template <int MAXP, bool SILU>
 __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
                                                        const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C,
-                                                       int G, float eps) {
+                                                       int G, float eps, const bf16_t* __restrict__ x2, int C1,
+                                                       bf16_t* __restrict__ cat) {
     __shared__ float red[4];
     // MAXP channel pairs per thread: HW * cpg / 2 <= 256 * MAXP (host-checked)
     const int g = blockIdx.x, b = blockIdx.y;
@@ -182,6 +196,10 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     const int n = HW * hp;
     const bf16_t* xb = x + (size_t)b * HW * C + g * cpg;
     bf16_t* yb = y + (size_t)b * HW * C + g * cpg;
+    // skip-concat form (see gn_stats_kernel): channel c < C1 from x (row stride C1), else from x2 (row stride C - C1)
+    const bf16_t* x1b = x + (size_t)b * HW * C1;
+    const bf16_t* x2b = x2 ? x2 + (size_t)b * HW * (C - C1) : nullptr;
+    bf16_t* catb = cat ? cat + (size_t)b * HW * C + g * cpg : nullptr;
     // the group's data is read ONCE into registers (all loads independent and in flight together)
     uint32_t v[MAXP];
     int off[MAXP];
@@ -191,7 +209,14 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
         const int ic = i < n ? i : 0;
         const int px = ic / hp, cp = ic - px * hp;
         off[u] = px * C + 2 * cp;
-        v[u] = i < n ? *reinterpret_cast<const uint32_t*>(xb + off[u]) : 0u;
+        if (x2) {
+            const int c = g * cpg + 2 * cp;
+            const bf16_t* src = c < C1 ? x1b + (size_t)px * C1 + c : x2b + (size_t)px * (C - C1) + (c - C1);
+            v[u] = i < n ? *reinterpret_cast<const uint32_t*>(src) : 0u;
+            if (catb && i < n) *reinterpret_cast<uint32_t*>(catb + off[u]) = v[u];
+        } else {
+            v[u] = i < n ? *reinterpret_cast<const uint32_t*>(xb + off[u]) : 0u;
+        }
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
@@ -749,18 +774,23 @@ int spider_groupnorm_nchunk(int HW) {
     return n < 1 ? 1 : (n > 128 ? 128 : n);
 }
 
-// x, y [B, HW, C] bf16 (NHWC); ws >= B * nchunk * G * 2 floats, nchunk = spider_groupnorm_nchunk(HW)
-int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
-                               int C, int G, float eps, int silu, void* stream) {
+// GroupNorm of the channel concatenation [x1 | x2] (UpBlock2D / UpBlock3D: cat([hidden, skip]) -> ResnetBlock.norm1) without a
+// concat launch: x1 [B, HW, C1], x2 [B, HW, C2] are read in place, y [B, HW, C1 + C2] is the normalised result and `cat`
+// (same shape) receives the concatenated input for the resnet's 1x1 shortcut. x2 == nullptr: plain GroupNorm of x1 (C2 = 0).
+static int groupnorm_impl(const void* x, const void* x2, const void* gamma, const void* beta, void* y, void* cat, void* ws, int B,
+                          int HW, int C1, int C2, int G, float eps, int silu, void* stream) {
+    const int C = C1 + C2;
     SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
     if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
         // (measured: a 40-pair variant for 20K-element groups is no faster than the stats + apply pair -- 64 blocks cannot
         // pull enough bandwidth)
         if (silu) gn_small_kernel<20, true><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
-                                                                                        (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps);
+                                                                                        (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps,
+                                                                                        (const bf16_t*)x2, C1, (bf16_t*)cat);
         else gn_small_kernel<20, false><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
-                                                                                     (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps);
+                                                                                     (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps,
+                                                                                     (const bf16_t*)x2, C1, (bf16_t*)cat);
         SPIDER_LAUNCH_OK();
         return 0;
     }
@@ -772,8 +802,9 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
     SPIDER_CHECK(threads <= 1024, "groupnorm: C too large");
     dim3 g1(nchunk, B);
     gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
-                                                                                       G, nchunk, KP);
+                                                                                       G, nchunk, KP, (const bf16_t*)x2, C1, (bf16_t*)cat);
     SPIDER_LAUNCH_OK();
+    if (x2) x = cat;              // pass 2 reads the concatenated copy pass 1 has just written
     int ppb = 4 * KP;             // one round of 4 independent 16-byte loads per thread
     while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;   // keep the grid at <= ~4 blocks per CU
     SPIDER_CHECK(threads >= 128 || threads >= 2 * G, "groupnorm: too few channels for the block layout");
@@ -784,6 +815,18 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
                                                                     (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
     SPIDER_LAUNCH_OK();
     return 0;
+}
+
+// x, y [B, HW, C] bf16 (NHWC); ws >= B * nchunk * G * 2 floats, nchunk = spider_groupnorm_nchunk(HW)
+int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream) {
+    return groupnorm_impl(x, nullptr, gamma, beta, y, nullptr, ws, B, HW, C, 0, G, eps, silu, stream);
+}
+
+int spider_groupnorm_cat_nhwc_bf16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
+                                   void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream) {
+    SPIDER_CHECK(x2 && cat && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "groupnorm_cat: two sources with channels % 8 == 0");
+    return groupnorm_impl(x1, x2, gamma, beta, y, cat, ws, B, HW, C1, C2, G, eps, silu, stream);
 }
 
 int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,

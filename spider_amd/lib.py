@@ -51,6 +51,7 @@ SIGNATURES = {
     "spider_rope_rows_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
     "spider_groupnorm_nchunk": (_i, [_i]),
     "spider_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "spider_groupnorm_cat_nhwc_bf16": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "spider_geglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "spider_swiglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),

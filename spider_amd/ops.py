@@ -449,6 +449,21 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None
     return out
 
 
+def groupnorm_cat(x1, x2, gamma, beta, groups=32, eps=1e-5, silu=False, ws=None):
+    """GroupNorm(+SiLU) of cat([x1, x2], channel) without a concat launch; returns (normalised, concatenated input)."""
+    _chk(x1, BF16, "x1"); _chk(x2, BF16, "x2"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    B, C1, C2 = x1.shape[0], x1.shape[-1], x2.shape[-1]
+    HW = x1.numel() // (B * C1)
+    assert x2.shape[:-1] == x1.shape[:-1] and gamma.numel() == C1 + C2, "groupnorm_cat: sources must share [B, ..., *]"
+    out = torch.empty(*x1.shape[:-1], C1 + C2, dtype=BF16, device=x1.device)
+    cat = torch.empty_like(out)
+    if ws is None:
+        ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x1.device)
+    _lib.call("spider_groupnorm_cat_nhwc_bf16", _p(x1), _p(x2), _p(gamma), _p(beta), _p(out), _p(cat), _p(ws), B, HW, C1, C2,
+              groups, float(eps), int(silu), _stream())
+    return out, cat
+
+
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
     Cn = x.shape[-1]

@@ -327,8 +327,13 @@ class UNetEngine:
         return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu)
 
     def _resnet(self, n, x):
+        """x: the block input, or a (hidden, skip) pair of an up block: norm1 then reads the two tensors in place and hands back
+        their concatenation for the shortcut (no concat launch)."""
         w = self.w
-        a = self._gn(n + ".norm1", x, True)
+        if isinstance(x, tuple):
+            a, x = ops.groupnorm_cat(x[0], x[1], w[n + ".norm1.weight"], w[n + ".norm1.bias"], self.cfg.groups, 1e-5, True)
+        else:
+            a = self._gn(n + ".norm1", x, True)
         h = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n])
         a = self._gn(n + ".norm2", h, True)
         sc = x
@@ -429,7 +434,7 @@ class UNetEngine:
                 hh = h
                 if self.freeu is not None and i < 2:
                     hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", ops.concat_channels(hh, skip))
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (hh, skip))
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], rdepth[i])
             if i != nb - 1:

@@ -221,7 +221,7 @@ class UNet3DEngine(UNetEngine):
         rheads = list(reversed(cfg.heads))
         for i in range(nb):
             for j in range(cfg.layers_per_block + 1):
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", ops.concat_channels(h, skips.pop()))
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (h, skips.pop()))
                 h = self._temp_conv(f"up_blocks.{i}.temp_convs.{j}", h)
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], 1)

@@ -268,6 +268,24 @@ def test_groupnorm(ops, dev, B, HW, C, silu):
     close(ops.groupnorm(x.to(dev), ga.to(dev), be.to(dev), 32, 1e-5, silu), ref, 2e-2, 1.5e-2, "groupnorm")
 
 
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 4096, 320, 320, True), (2, 4096, 640, 320, True), (2, 1024, 1280, 640, False),
+                                             (2, 256, 1280, 1280, True), (2, 64, 1280, 1280, True), (1, 1000, 256, 128, True)])
+def test_groupnorm_of_skip_concat(ops, dev, B, HW, C1, C2, silu):
+    """norm1 of an up block: GroupNorm over cat([hidden, skip]) read in place == the kernel on the materialised concat (bit for
+    bit: same arithmetic, same order), the concatenated copy it hands to the shortcut is exact, and both match torch fp32.
+    (640 + 320 / 1280 + 640: a group straddles the seam between the two tensors.)"""
+    x1 = (rnd(B, HW, C1, seed=1).float() * 2 + 0.5).to(BF).to(dev)
+    x2 = (rnd(B, HW, C2, seed=4).float() * 0.7 - 0.3).to(BF).to(dev)
+    C = C1 + C2
+    ga, be = (1 + 0.2 * rnd(C, seed=2).float()).to(BF).to(dev), rnd(C, seed=3, scale=0.2).to(dev)
+    y, cat = ops.groupnorm_cat(x1, x2, ga, be, 32, 1e-5, silu)
+    xc = torch.cat([x1, x2], -1)
+    assert torch.equal(cat, xc)
+    assert torch.equal(y, ops.groupnorm(xc, ga, be, 32, 1e-5, silu))
+    ref = F.group_norm(xc.float().cpu().transpose(1, 2), 32, ga.float().cpu(), be.float().cpu(), 1e-5).transpose(1, 2)
+    close(y, F.silu(ref) if silu else ref, 2e-2, 1.5e-2, "groupnorm_cat")
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 320), (77, 768), (3, 1280), (10, 2048)])
 def test_layernorm(ops, dev, rows, C):
     x, ga, be = rnd(rows, C, seed=1), (1 + 0.2 * rnd(C, seed=2).float()).to(BF), rnd(C, seed=3, scale=0.2)
