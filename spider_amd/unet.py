@@ -148,6 +148,7 @@ class UNetEngine:
         # Fused cross-attention sub-block (ops.xattn_fused): weight-only halves of the per-prompt fold (prepare() finishes it
         # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
         self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
+        self.gn_cat = os.environ.get("SPIDER_GN_CAT", "1") != "0"     # up-block norm1 reads (hidden, skip) in place (tuning aid)
         self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
         self.xw: Dict[str, dict] = {}
         for b in list(self.ln):
@@ -330,6 +331,8 @@ class UNetEngine:
         """x: the block input, or a (hidden, skip) pair of an up block: norm1 then reads the two tensors in place and hands back
         their concatenation for the shortcut (no concat launch)."""
         w = self.w
+        if isinstance(x, tuple) and not self.gn_cat:
+            x = ops.concat_channels(x[0], x[1])
         if isinstance(x, tuple):
             a, x = ops.groupnorm_cat(x[0], x[1], w[n + ".norm1.weight"], w[n + ".norm1.bias"], self.cfg.groups, 1e-5, True)
         else:
