@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
 
     const int own_lo = (!PLAIN && p.blk > 0) ? ((qi + p.q_off) / p.blk) * p.blk : 0;
     const int own_hi = own_lo + p.blk;
+    // the image block of this wave's first row, and whether its last row lies in the same one (wave-uniform scalars)
+    const int w_first = __builtin_amdgcn_readfirstlane(q0 + wave * 32);
+    const int w_own_lo = (!PLAIN && p.blk > 0) ? ((w_first + p.q_off) / p.blk) * p.blk : 0;
+    const bool own_uniform = !PLAIN && p.blk > 0 && ((w_first + 31 + p.q_off) / p.blk) * p.blk == w_own_lo;
     const int caus_max = qi + p.kv_off;  // last visible key when causal
 
     f32x16 acc_o[DP / 32];
@@ -193,9 +197,18 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         // Fast path (wave-uniform): a tile entirely inside [kbeg, Lk), below the causal diagonal of every row of
         // this wave and without a keep vector needs no per-element predicates: max, one fma + exp2, add.
         const int wave_q0 = q0 + wave * 32;
+        // Keep-vector tiles (consistent self-attention), classified per wave and tile: when the wave's 32 rows share one image
+        // block (always, for block lengths that are multiples of 64), a tile inside that block is fully visible, and a tile
+        // outside it is masked by the keep bits alone -- a per-KEY bias, the same for every query, applied inside the scale fma
+        // (2 extra VALU per score instead of ~9 for the general row-and-key predicate).
+        bool keep_only = false, own_tile = false;
+        if (!PLAIN && p.keep_bits && own_uniform && !p.causal && t * 64 >= kbeg && t * 64 + 64 <= lk_end) {
+            own_tile = t * 64 >= w_own_lo && t * 64 + 64 <= w_own_lo + p.blk;
+            keep_only = t * 64 + 64 <= w_own_lo || t * 64 >= w_own_lo + p.blk;
+        }
         const bool full_tile = PLAIN ? (t * 64 + 64 <= lk_end)
-                                     : ((t * 64 >= kbeg) && (t * 64 + 64 <= lk_end) && !p.keep_bits &&
-                                        (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off));
+                                     : (own_tile || ((t * 64 >= kbeg) && (t * 64 + 64 <= lk_end) && !p.keep_bits &&
+                                                     (!p.causal || t * 64 + 63 <= wave_q0 + p.kv_off)));
         float psum = 0.f, alpha;
         if (full_tile) {
             // four independent chains for the max and for the sum: a single 32-long dependent chain costs its full latency
@@ -226,7 +239,23 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
             const int key0 = t * 64 + 4 * h32;                       // key = key0 + kt*32 + (r&3) + 8*(r>>2)
             const int hi_lim = (!PLAIN && p.causal) ? min(lk_end, caus_max + 1) : lk_end;
             float tmax = -1e30f;
-            if (!PLAIN && p.keep_bits) {
+            if (!PLAIN && keep_only) {
+                const unsigned long long kl = p.keep_bits[t] >> (4 * h32);
+                const uint32_t klo = (uint32_t)kl, khi = (uint32_t)(kl >> 32);
+                float tm[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = kt * 32 + (r & 3) + 8 * (r >> 2);
+                        // all ones where the key is kept -> bias 0, else -1e30 (0xF149F2CA)
+                        const uint32_t kept = (uint32_t)__builtin_amdgcn_sbfe((int)(off < 32 ? klo : khi), off & 31, 1);
+                        const float sv = fmaf(s[kt][r], p.scale_log2e, __uint_as_float(~kept & 0xF149F2CAu));
+                        s[kt][r] = sv;
+                        tm[r & 3] = fmaxf(tm[r & 3], sv);
+                    }
+                tmax = fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3]));
+            } else if (!PLAIN && p.keep_bits) {
                 const unsigned long long kl = p.keep_bits[t] >> (4 * h32);
                 const uint32_t klo = (uint32_t)kl, khi = (uint32_t)(kl >> 32);
 #pragma unroll
