@@ -158,6 +158,20 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
                      int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
                      const int* kv_beg, const void* keep_bits, int blk, int q_off, void* stream);
 
+/* Consistent self-attention (StoryDiffusion SpatialAttnProcessor2_0 + cal_attn_mask_xl, Comic_Generation.py:129-196,
+ * gradio_utils.py:241-287) through visible-key lists: query image i sees key j iff its keep bit is set or j lies in image i's
+ * own block, so instead of scoring all keys and zeroing the masked ones (spider_attn_bf16 keep_bits / blk / q_off) the kernel
+ * walks a per-image list of visible keys -- same softmax, ~40 % fewer keys at keep rate 0.5. head_dim <= 64 (SDXL: 64).
+ * spider_story_key_lists_i32 builds, once per UNet step and resolution, key_idx [n_lists * stride] and the query-tile records
+ * tiles [n_lists * ceil(N/128)][4]; spider_attn_keylist_bf16 consumes them (strides as in spider_attn_bf16). */
+int spider_story_key_lists_i32(const void* keep_bits, int n_keys, int N, int img0, int n_lists, int q_img0, int stride,
+                               int* key_idx, int* tiles, void* stream);
+int spider_attn_keylist_bf16(const void* q, const void* k, const void* v, void* o,
+                             long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                             long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                             int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale,
+                             const int* key_idx, int idx_len, const int* tiles, int n_tiles, void* stream);
+
 /* packed variable-length attention: the per-segment SDPA loop over cu_seqlens of transformers'
  * Qwen2_5OmniVisionAttention / Qwen2_5OmniAudioAttention (window / full-frame / audio-chunk segments), reached from the
  * reference through Qwen2_5OmniModel.generate(**inputs) with images / audios (qwen2.5omni_spider_web.py:461-468).

@@ -21,5 +21,7 @@ for N, H, d in [(2304, 10, 64), (576, 20, 64)]:
     bits = ops.pack_keep_bits(torch.rand(L, device=dev), 0.5, L)
     dense = t(lambda: ops.attention(q, kv[..., :C], kv[..., C:], H))
     keep = t(lambda: ops.attention(q, kv[..., :C], kv[..., C:], H, keep_bits=bits, blk=N, q_off=0))
+    ki, tl = ops.story_key_lists(bits, L, N, 0, 4, 0)
+    kl = t(lambda: ops.attention_keylist(q, kv[..., :C], kv[..., C:], H, ki, tl))
     fl = 4 * 2 * H * L * L * d
-    print(f"4x{N} tokens, {H} heads: dense {dense:7.1f} us ({fl / dense / 1e6:.0f} TF/s)   consistent-SA mask {keep:7.1f} us ({fl / keep / 1e6:.0f} TF/s dense-equivalent)", flush=True)
+    print(f"4x{N} tokens, {H} heads: dense {dense:7.1f} us ({fl / dense / 1e6:.0f} TF/s)   consistent-SA mask {keep:7.1f} us ({fl / keep / 1e6:.0f} TF/s dense-equivalent)   key lists {kl:7.1f} us", flush=True)

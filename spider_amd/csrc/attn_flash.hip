@@ -38,6 +38,11 @@ struct AttnArgs {
     // sequence): one record {q_start, q_len <= 128, k_start, k_len} per block instead of the regular 128-row grid
     const int* tiles;
     int n_tiles;
+    // key-list mode (with `tiles`): a record's key range [k_start, k_start + k_len) counts POSITIONS of key_idx[], whose entries
+    // are the K / V rows to visit -- the consistent-self-attention mask as a per-image list of visible keys (kept keys + the own
+    // image block): masked keys are never loaded or scored instead of being scored and zeroed
+    const int* key_idx;
+    int idx_len;
 };
 
 // value of the partner lane (lane ^ 32) by v_permlane32_swap: a VALU op, where __shfl_xor(x, 32) is a ds_bpermute round trip
@@ -63,7 +68,7 @@ struct Cfg {
 // the mask arithmetic, its scalar state and the per-tile "is this tile fully visible" test are compiled out; every tile but a
 // ragged last one takes the predicate-free path. The general instantiation spilled scalars into VGPR lanes (v_readlane in the
 // tile loop) and spent ~60 SALU + ~80 non-essential VALU instructions per 64-key tile in a loop whose issue port is the limit.
-template <int DP, bool ONES, bool PLAIN>
+template <int DP, bool ONES, bool PLAIN, bool KIDX = false>
 __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,9 +128,12 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     // K / V rows through buffer descriptors: a chunk outside the tile's keys / the head dim gets an all-ones offset and reads
     // zeros in hardware -- no per-load branch (with `ok ? load : 0` the loop carried 4 divergent branches per tile).
     // Ranges are clamped to 4 GiB - 1; attention operands of this path are far below that.
-    auto span = [&](long rs) { const long b_ = ((long)(lk_end - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
+    const int k_rows = KIDX ? p.Lk : lk_end;       // key-list mode: list entries address any row of the K / V view
+    auto span = [&](long rs) { const long b_ = ((long)(k_rows - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
     const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, span(p.k_rs), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, span(p.v_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(KIDX ? p.key_idx : nullptr), 0,
+                                                                            KIDX ? (uint32_t)p.idx_len * 4u : 0u, 0x00020000);
     uint32_t ld_row[C::NCH], ld_cb[C::NCH], ld_inv[C::NCH];
 #pragma unroll
     for (int i = 0; i < C::NCH; ++i) {
@@ -134,13 +142,24 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         ld_cb[i] = (uint32_t)(c % C::CPR) * 16u;
         ld_inv[i] = ((c < 64 * C::CPR) && (c % C::CPR) * 8 < p.d) ? 0u : 0xFFFFFFFFu;
     }
+    // key-list mode: the K / V rows of the NEXT tile to load, fetched one tile ahead of the loads that use them
+    uint32_t kidx[C::NCH];
+    auto load_idx = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i) {
+            const int pos = t * 64 + (int)ld_row[i];
+            const uint32_t inv = (uint32_t)((lk_end - 1 - pos) >> 31);       // positions past the list read 0 (never used: masked)
+            kidx[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc_i, ((uint32_t)pos * 4u) | inv, 0, 0);
+        }
+    };
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
-            const int key = t * 64 + (int)ld_row[i];
-            const uint32_t inv = ld_inv[i] | (uint32_t)((lk_end - 1 - key) >> 31);
-            rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, ((uint32_t)key * (uint32_t)p.k_rs * 2u + ld_cb[i]) | inv, 0, 0));
-            rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)key * (uint32_t)p.v_rs * 2u + ld_cb[i]) | inv, 0, 0));
+            const int pos = t * 64 + (int)ld_row[i];
+            const uint32_t key = KIDX ? kidx[i] : (uint32_t)pos;
+            const uint32_t inv = ld_inv[i] | (uint32_t)((lk_end - 1 - pos) >> 31);
+            rk[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, (key * (uint32_t)p.k_rs * 2u + ld_cb[i]) | inv, 0, 0));
+            rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, (key * (uint32_t)p.v_rs * 2u + ld_cb[i]) | inv, 0, 0));
         }
     };
     // `t` = the tile these registers hold. The ones column (V[key][d] = 1.0) is patched HERE, at the LDS write, not where the
@@ -163,7 +182,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     };
 
     if (t_begin < t_end) {
+        if (KIDX) load_idx(t_begin);
         load_tile(t_begin);
+        if (KIDX) load_idx(t_begin + 1);
         store_tile(0, t_begin);
     }
     // Retire the Q loads HERE: their first use is the QK^T MFMA inside the tile loop, where the compiler cannot count how many
@@ -177,7 +198,10 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         const int cur = (t - t_begin) & 1;
         const bf16_t* Ks = lds0 + cur * IMG;
         const bf16_t* Vs = Ks + 64 * C::KS;
-        if (t + 1 < t_end) load_tile(t + 1);
+        if (t + 1 < t_end) {
+            load_tile(t + 1);
+            if (KIDX) load_idx(t + 2);
+        }
 
         // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
         f32x16 s[2];
@@ -590,11 +614,67 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Visible-key lists of the consistent self-attention (cal_attn_mask_xl, gradio_utils.py:241-287, as a list instead of a mask):
+// query image `img0 + list` sees key j iff keep bit j is set or j lies in its own block [img*N, (img+1)*N). One block per list
+// compacts the visible key indices in increasing order into key_idx[list * stride ...] and writes the query-tile records
+// {q_start, q_len <= 128, k_start = list * stride, k_len = number of visible keys} that attn_flash_kernel<KIDX> walks.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void key_lists_kernel(const unsigned long long* __restrict__ keep, int n_keys, int N, int img0,
+                                                         int q_img0, int stride, int* __restrict__ key_idx, int* __restrict__ tiles) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int list = blockIdx.x, img = img0 + list;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* out = key_idx + (size_t)list * stride;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n_keys; j0 += 1024) {
+        const int j = j0 + threadIdx.x;
+        bool vis = false;
+        if (j < n_keys) vis = ((keep[j >> 6] >> (j & 63)) & 1ull) != 0ull || (j / N == img);
+        const unsigned long long bal = __ballot(vis);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (vis) out[off + rank] = j;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    const int cnt = base_s;
+    const int tpl = (N + 127) / 128;
+    if ((int)threadIdx.x < tpl) {
+        int* rec = tiles + ((size_t)list * tpl + threadIdx.x) * 4;
+        const int qs = threadIdx.x * 128;
+        rec[0] = (img - q_img0) * N + qs;
+        rec[1] = min(128, N - qs);
+        rec[2] = list * stride;
+        rec[3] = cnt;
+    }
+}
+
 template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
     const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
+    if (a.key_idx) {
+        if constexpr (DP == 64) {       // the StoryDiffusion / SDXL heads (d = 64; smaller heads ride in the same 64-wide tile)
+            if (a.d < DP) attn_flash_kernel<DP, true, false, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+            else attn_flash_kernel<DP, false, false, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+            SPIDER_LAUNCH_OK();
+            return 0;
+        }
+        spider_set_error("attn_keylist: head_dim must be <= 64");
+        return -1;
+    }
     const bool plain = !a.causal && !a.keep_bits && !a.kv_beg && !a.tiles;
     static const int pipe_env = [] { const char* e = getenv("SPIDER_ATTN_PIPE"); return e ? atoi(e) : 1; }();
     if (plain && pipe_env && a.Lk % 64 == 0 && a.Lk >= 128 && DP <= 96) {      // software-pipelined dense form (whole 64-key tiles)
@@ -648,6 +728,47 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
     if (d <= 96) return launch<96>(a, stream);
     if (d <= 128) return launch<128>(a, stream);
     return launch<160>(a, stream);
+}
+
+// Consistent self-attention through visible-key lists (see key_lists_kernel): same result as spider_attn_bf16 with keep_bits /
+// blk / q_off -- masked keys contribute exactly zero there and are skipped here -- at the cost of the visible keys only.
+//   key_idx [idx_len] int32, tiles [n_tiles][4] from spider_story_key_lists_i32; q [B, Lq, ...], k / v [B, Lk, ...] strided as in
+//   spider_attn_bf16; head_dim 64 (the SDXL UNet of StoryDiffusion/Comic_Generation.py).
+int spider_attn_keylist_bf16(const void* q, const void* k, const void* v, void* o,
+                             long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                             long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                             int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale,
+                             const int* key_idx, int idx_len, const int* tiles, int n_tiles, void* stream) {
+    SPIDER_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Lq > 0 && Lk > 0, "attn_keylist: bad shape");
+    SPIDER_CHECK(d > 0 && d % 8 == 0 && d <= 64, "attn_keylist: head_dim must be a multiple of 8 and <= 64");
+    SPIDER_CHECK(key_idx && tiles && idx_len > 0 && n_tiles > 0, "attn_keylist: key lists and tile records required");
+    SPIDER_CHECK(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0, "attn_keylist: row strides must keep 16-byte alignment");
+    SPIDER_CHECK(q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 && o_hs % 4 == 0, "attn_keylist: head strides must keep 16-byte alignment");
+    SPIDER_CHECK(q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 4 == 0, "attn_keylist: batch strides must keep 16-byte alignment");
+    SPIDER_CHECK((long)Lk * k_rs * 2 < (1L << 32) && (long)Lk * v_rs * 2 < (1L << 32), "attn_keylist: one (batch, head) K / V view must span < 4 GiB");
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q_bs = q_bs; a.q_hs = q_hs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_rs = k_rs;
+    a.v_bs = v_bs; a.v_hs = v_hs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_hs = o_hs; a.o_rs = o_rs;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Lq = Lq; a.Lk = Lk; a.d = d;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    a.tiles = tiles; a.n_tiles = n_tiles; a.key_idx = key_idx; a.idx_len = idx_len;
+    return launch<64>(a, stream);
+}
+
+// Build the visible-key lists and query-tile records for spider_attn_keylist_bf16. keep_bits: uint64 words over n_keys keys
+// (spider_pack_keep_bits_f32); N = tokens per image; list l serves query image img0 + l, whose rows start at
+// (img0 + l - q_img0) * N in the q tensor (q_img0 = img0 when q holds only those images, 0 when it holds all of them).
+// key_idx: n_lists * stride int32 (stride >= n_keys, multiple of 64); tiles: n_lists * ceil(N / 128) records of 4 int32.
+int spider_story_key_lists_i32(const void* keep_bits, int n_keys, int N, int img0, int n_lists, int q_img0, int stride,
+                               int* key_idx, int* tiles, void* stream) {
+    SPIDER_CHECK(keep_bits && key_idx && tiles && n_keys > 0 && N > 0 && n_lists > 0, "key_lists: bad arguments");
+    SPIDER_CHECK(stride >= n_keys && stride % 64 == 0, "key_lists: stride must cover the keys and be a multiple of 64");
+    SPIDER_CHECK((N + 127) / 128 <= 1024, "key_lists: image block too long");
+    key_lists_kernel<<<n_lists, 1024, 0, (hipStream_t)stream>>>((const unsigned long long*)keep_bits, n_keys, N, img0, q_img0, stride,
+                                                               key_idx, tiles);
+    SPIDER_LAUNCH_OK();
+    return 0;
 }
 
 // Packed variable-length attention (no mask tensor): q/k/v/o are [total_rows, heads, d] views with the given row

@@ -47,6 +47,8 @@ SIGNATURES = {
     "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _l, _vp]),
     "spider_conv_nhwc_ex_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _vp, _l, _vp]),
     "spider_attn_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "spider_story_key_lists_i32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "spider_attn_keylist_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _vp, _i, _vp, _i, _vp]),
     "spider_attn_varlen_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "spider_rope_rows_bf16": (_i, [_vp, _vp, _l, _i, _i, _i, _vp]),
     "spider_groupnorm_nchunk": (_i, [_i]),

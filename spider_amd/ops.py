@@ -370,6 +370,36 @@ def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_of
     return out
 
 
+def story_key_lists(keep_bits, n_keys: int, N: int, img0: int, n_lists: int, q_img0: int):
+    """Visible-key lists of the consistent self-attention: list l (query image img0 + l) = keys whose keep bit is set or that lie in
+    the image's own block of N tokens. Returns (key_idx int32 [n_lists * stride], tiles int32 [n_lists * ceil(N/128), 4])."""
+    _chk(keep_bits, torch.int64, "keep_bits")
+    assert keep_bits.numel() * 64 >= n_keys
+    stride = (n_keys + 63) // 64 * 64
+    key_idx = torch.empty(n_lists * stride, dtype=torch.int32, device=keep_bits.device)
+    tiles = torch.empty(n_lists * ((N + 127) // 128), 4, dtype=torch.int32, device=keep_bits.device)
+    _lib.call("spider_story_key_lists_i32", _p(keep_bits), n_keys, N, img0, n_lists, q_img0, stride, _p(key_idx), _p(tiles), _stream())
+    return key_idx, tiles
+
+
+def attention_keylist(q, k, v, n_heads, key_idx, tiles, scale=None, out=None):
+    """Consistent self-attention over visible-key lists (story_key_lists): q [B,Lq,H*64], k / v [B,Lk,H*64]."""
+    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    _chk(key_idx, torch.int32, "key_idx"); _chk(tiles, torch.int32, "tiles")
+    B, Lq, Cq = q.shape
+    Lk, d = k.shape[1], Cq // n_heads
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and tiles.dim() == 2 and tiles.shape[1] == 4
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    if out is None:
+        out = torch.empty(B, Lq, Cq, dtype=BF16, device=q.device)
+    _lib.call("spider_attn_keylist_bf16", _p(q), _p(k), _p(v), _p(out),
+              q.stride(0), d, q.stride(1), k.stride(0), d, k.stride(1), v.stride(0), d, v.stride(1),
+              out.stride(0), d, out.stride(1), B, n_heads, n_heads, Lq, Lk, d, float(scale),
+              _p(key_idx), key_idx.numel(), _p(tiles), tiles.shape[0], _stream())
+    return out
+
+
 def varlen_tiles(cu_seqlens, device) -> torch.Tensor:
     """cu_seqlens (python ints / tensor, [n_seg + 1]) -> int32 [n_tiles, 4] records {q_start, q_len <= 128, k_start, k_len}
     for attention_varlen: every segment is cut into query tiles of at most 128 rows that all see the whole segment."""

@@ -241,6 +241,40 @@ def test_attention_consistent_mask(ops, dev, N, heads, d, read_mode):
     close(out, _attn_ref(q, k, v, heads, heads, mask=mask), 1.5e-2, 1.5e-2, "consistent attention")
 
 
+@pytest.mark.parametrize("N,heads,d,read_mode", [(64, 4, 64, False), (256, 10, 64, False), (64, 4, 64, True), (200, 3, 64, False),
+                                                  (576, 5, 64, True), (128, 4, 16, False), (64, 2, 40, True)])
+def test_attention_consistent_keylists(ops, dev, N, heads, d, read_mode):
+    """The visible-key-list form of the consistent self-attention (masked keys skipped, not scored) == the dense
+    cal_attn_mask_xl mask (gradio_utils.py:241-287) == the keep-bits kernel; the lists themselves are checked exactly.
+    N = 200 / 576: image blocks that are not multiples of the 128-row query tile (ragged last tile per image)."""
+    C = heads * d
+    g = torch.Generator().manual_seed(9)
+    keep = (torch.rand(5 * N, generator=g) < 0.5).clone(); keep[4 * N:] = False
+    dense = keep[None].repeat(5, 1)
+    for i in range(5):
+        dense[i, i * N:(i + 1) * N] = True
+    if read_mode:
+        Lq, Lk, q_off, img0, n_lists = N, 5 * N, 4 * N, 4, 1
+    else:
+        Lq, Lk, q_off, img0, n_lists = 4 * N, 4 * N, 0, 0, 4
+    mask = dense[img0:img0 + n_lists, None, :Lk].repeat(1, N, 1).reshape(Lq, Lk)
+    bits = ops.pack_keep_bits((~keep).float().to(dev), 0.5, 4 * N)       # u < thr <=> keep
+    ki, tl = ops.story_key_lists(bits, Lk, N, img0, n_lists, img0)
+    stride = (Lk + 63) // 64 * 64
+    tpl = (N + 127) // 128
+    for l in range(n_lists):
+        want = torch.nonzero(dense[img0 + l, :Lk]).flatten().to(torch.int32)
+        rec = tl[l * tpl:(l + 1) * tpl].cpu()
+        assert int(rec[0, 3]) == want.numel() and int(rec[0, 2]) == l * stride
+        assert torch.equal(ki[l * stride:l * stride + want.numel()].cpu(), want)
+        assert rec[:, 0].tolist() == [l * N + 128 * t for t in range(tpl)] and int(rec[:, 1].sum()) == N
+    q, k, v = rnd(2, Lq, C, seed=1), rnd(2, Lk, C, seed=2), rnd(2, Lk, C, seed=3)
+    out = ops.attention_keylist(q.to(dev), k.to(dev), v.to(dev), heads, ki, tl)
+    close(out, _attn_ref(q, k, v, heads, heads, mask=mask), 1.5e-2, 1.5e-2, "key-list attention")
+    ref2 = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads, keep_bits=bits, blk=N, q_off=q_off)
+    close(out, ref2.float().cpu(), 1.5e-2, 1.5e-2, "key-list vs keep-bits kernel")
+
+
 def test_attention_prefill_cache_leftpad(ops, dev):
     from oracle.llama import attention
     B, S, n_q, n_kv, d, T = 2, 70, 8, 2, 128, 96

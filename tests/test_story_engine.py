@@ -19,7 +19,8 @@ class _Eng:
         self.w = w
 
 
-def test_consistent_attention_matches_reference_sequence(dev, golden_dir):
+@pytest.mark.parametrize("key_lists", [True, False])
+def test_consistent_attention_matches_reference_sequence(dev, golden_dir, key_lists):
     from spider_amd.story import ConsistentSelfAttention, StoryState
     z = np.load(os.path.join(golden_dir, "story_ref.npz"))
     C, heads, hh, ww = [int(v) for v in z["seq_cfg"]]
@@ -29,6 +30,7 @@ def test_consistent_attention_matches_reference_sequence(dev, golden_dir):
                     uniforms=lambda n: torch.rand((1, n), dtype=torch.float32).reshape(-1))
     st.regen_masks(dev)
     hook = ConsistentSelfAttention(st)
+    hook.key_lists = key_lists       # visible-key lists (masked keys skipped) / keep-bits mask kernel: both pinned to the reference
     engs, outw = {}, {}
     for tag in ("sa", "sb"):
         t = lambda k: torch.from_numpy(z[f"seq_{tag}_{k}"])
