@@ -718,6 +718,199 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles for the LARGE problems (>= one tile per CU): 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 (128 accumulator
+// registers), ONE block per CU, both operands by LDS-DMA into two K-tile buffers of four 16 KiB half-tiles [A rows 0-127 | A rows
+// 128-255 | W rows 0-127 | W rows 128-255]. A K tile is four phases of 16 MFMAs, one C quadrant each, in the order
+// (a0,b0) (a0,b1) (a1,b1) (a1,b0), so each phase reads at most one new A sub-block (8 ds_read_b128) and one new W sub-block (4);
+// each phase also issues ONE half-tile of DMA (2 instructions per wave). The two wave groups wr = 0 / 1 (which share the SIMDs
+// pairwise) run half a phase apart -- one executes its read / DMA-issue slot while the other runs its MFMA cluster -- through one
+// extra barrier at the start of group 1 and at the end of group 0 (equal barrier counts for every wave).
+//   DMA schedule (K tile kt, buffers cur = kt & 1, nxt):  P1: A-h1(kt+1) -> nxt   P2: W-h1(kt+1) -> nxt
+//                                                       P3: W-h0(kt+2) -> cur   P4: A-h0(kt+2) -> cur
+//   WAR: a region is re-staged at least one phase after its last fragment read, and every read slot retires its reads (lgkmcnt(0))
+//   before its barrier. RAW: before the barrier that ends phase 4 every wave waits vmcnt(4): all but its last two half-tile shares
+//   (P3 / P4 of this K tile, for K tile kt+2) have landed, i.e. K tile kt+1 is complete when phase 1 reads it.
+// The wave tile needs 24 fragment reads per 64 MFMAs (the 128 x 160 kernel above: 14 per 20).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CONV, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
+    constexpr int HT = 128 * 128;                     // bytes of a half-tile (128 rows x 128 B)
+    constexpr int KT_BYTES = 4 * HT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = p.n_fast ? bid / tiles_n : bid % tiles_m, tn = p.n_fast ? bid % tiles_n : bid / tiles_m;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int split = blockIdx.y;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+
+    // a DMA piece = 8 rows x 128 B (one wave instruction); a half-tile = 16 pieces, this wave issues pieces wave and 8 + wave
+    const int prow = lane >> 3, slot = lane & 7;
+    uint32_t a_base[2][2], a_inv[2][2], w_base[2][2], w_inv[2][2], gch[2];
+    int a_oy[2][2], a_ox[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (j * 8 + wave) * 8 + prow;       // row inside the half-tile
+        gch[j] = (uint32_t)(slot ^ ((R >> 1) & 7));    // source-side XOR swizzle of the 16-byte chunk (image linear in lane order)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + h * 128 + R;
+            const bool okm = m < p.M;
+            const int mc = okm ? m : 0;
+            a_inv[h][j] = okm ? 0u : 0xFFFFFFFFu;
+            if (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int b = mc / hw, rem = mc % hw;
+                a_oy[h][j] = rem / p.Wout;
+                a_ox[h][j] = rem % p.Wout;
+                a_base[h][j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+            } else {
+                a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
+                a_oy[h][j] = a_ox[h][j] = 0;
+            }
+            const int n = n0 + h * 128 + R;
+            const bool okn = n < p.N;
+            w_inv[h][j] = okn ? 0u : 0xFFFFFFFFu;
+            w_base[h][j] = okn ? (uint32_t)n * (uint32_t)p.K * 2u + gch[j] * 16u : 0u;
+        }
+    }
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
+
+    // one half-tile share of this wave: kind 0 = A, 1 = W; tiles >= kt1 and chunks >= K are all-ones offsets (DMA writes zeros)
+    auto issue = [&](int kind, int h, int kt, int buf) {
+        char* sb = smem + buf * KT_BYTES + (kind * 2 + h) * HT;
+        const uint32_t kbyte = (uint32_t)kt * (BK * 2);
+        const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)gch[j] * 8)) >> 31) | t_inv;
+            uint32_t off;
+            if (kind == 0) {
+                if (CONV) {
+                    const int kk = p.cin64 ? kt * BK : kt * BK + (int)gch[j] * 8;
+                    const int tap = kk / p.Cin;
+                    const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? (int)gch[j] * 8 : 0)) * 2u;
+                    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                    int iy = a_oy[h][j] * p.stride + ky * p.dil - p.pad_h;
+                    int ix = a_ox[h][j] * p.stride + kx * p.dil - p.pad_w;
+                    const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    off = (a_base[h][j] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[h][j] | k_inv;
+                } else {
+                    off = (a_base[h][j] + kbyte) | a_inv[h][j] | k_inv;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            } else {
+                off = (w_base[h][j] + kbyte) | w_inv[h][j] | k_inv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int a_rd = (0 * 2 + wr) * HT + frow * 128;                                  // this wave's A half
+    const int w_rd = (1 * 2 + (wc >> 1)) * HT + ((wc & 1) * 64 + frow) * 128;         // its 64 W rows inside their half
+    bf16x8 af[2][4], wf[2][2][2];          // A sub-block [ks][i]; W sub-blocks b0 / b1 [ks][j]
+    auto read_a = [&](int buf, int qa) {
+        const char* sb = smem + buf * KT_BYTES + a_rd + qa * 64 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+    };
+    auto read_w = [&](int buf, int qb) {
+        const char* sb = smem + buf * KT_BYTES + w_rd + qb * 32 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wf[qb][ks][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+    };
+    auto mfmas = [&](int qa, int qb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qb][ks][j], af[ks][i], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_end = [&]() {                 // fragment reads retired (their region may be re-staged from the next phase on), then the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: K tile kt0 whole, W-h0 / A-h0 of kt0 + 1 (the order the loop would have issued them in)
+    issue(1, 0, kt0, 0); issue(0, 0, kt0, 0); issue(0, 1, kt0, 0); issue(1, 1, kt0, 0);
+    issue(1, 0, kt0 + 1, 1); issue(0, 0, kt0 + 1, 1);
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // group 1 runs half a phase behind group 0
+
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int nxt = cur ^ 1;
+        // ---- phase 1: quadrant (a0, b0)
+        read_w(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0, 1, kt + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_end();
+        mfmas(0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (a0, b1)
+        read_w(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(1, 1, kt + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_end();
+        mfmas(0, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (a1, b1)
+        read_a(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(1, 0, kt + 2, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_end();
+        mfmas(1, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 4: quadrant (a1, b0); K tile kt + 1 must have landed before the barrier that opens group 0's next read slot
+        issue(0, 0, kt + 2, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wr == 1) wait_vmcnt<4>();
+        slot_end();
+        mfmas(1, 0);
+        if (wr == 0) wait_vmcnt<4>();
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // matches group 1's extra barrier at the start
+    wait_vmcnt<0>();                                  // the masked tail DMAs must not outlive the workgroup's LDS allocation
+
+    write_out<8, 4, EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, split, lane);
+}
+
 // split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
@@ -783,6 +976,32 @@ void launch_dma_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
         once = true;
     }
     gemm_dma_kernel<BN, NS, CONV, EPI, BM><<<grid, 512, smem, st>>>(a);
+}
+
+template <bool CONV, int EPI>
+void launch_p8_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int smem = 2 * 4 * 128 * 128;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<CONV, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        once = true;
+    }
+    gemm_p8_kernel<CONV, EPI><<<grid, 512, smem, st>>>(a);
+}
+
+void launch_p8(const GemmArgs& a, hipStream_t st) {
+    dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), a.splits);
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
+    if (a.conv) {
+        if (epi == 3) launch_p8_inst<true, 3>(a, grid, st);
+        else if (epi == 1) launch_p8_inst<true, 1>(a, grid, st);
+        else launch_p8_inst<true, 0>(a, grid, st);
+    } else {
+        if (epi == 3) launch_p8_inst<false, 3>(a, grid, st);
+        else if (epi == 1) launch_p8_inst<false, 1>(a, grid, st);
+        else launch_p8_inst<false, 0>(a, grid, st);
+    }
 }
 
 template <int BN, int NS, int BM = 128>
@@ -882,6 +1101,25 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
             splits = ds;
         }
     }
+    // 256^2 tiles (gemm_p8_kernel) for the large problems. Measured on MI355X (scripts/bench_gemm.py, tile 256): LLM prefill
+    // gate/up 474 -> 345 us (1.21 PFLOP/s), down 262 -> 179, o 76 -> 58, qkv 79 -> 72; SDXL story linears 78 -> 68 / 83 -> 65 /
+    // 98 -> 74 us and its 48^2 / 24^2 convs 165 -> 153, 319 -> 303, 342 -> 307, 184 -> 167; it loses where the 256-wide tiles
+    // pad N (N = 320: 0.625 of the tile area used, 189 -> 235 us) or fewer than ~160 blocks exist (4608 x 1280 x 1280: 29 -> 32).
+    static const int p8_env = getenv("SPIDER_GEMM_P8") ? atoi(getenv("SPIDER_GEMM_P8")) : 1;
+    bool use_p8 = false;
+    if (p8_env && !force_tile && !force_splits && !a.geglu && !a.ln_colsum && nk >= 8) {
+        const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        if ((double)a.M * a.N >= 0.75 * 65536.0 * (double)t256) {
+            int s = 1;
+            if (t256 < 160 && a.ws) {
+                s = (int)((192 + t256 - 1) / t256);
+                if (s > nk / 16) s = nk / 16;
+                if (s < 1) s = 1;
+                while (s > 1 && (size_t)s * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --s;
+            }
+            if (t256 * s >= 160) { use_p8 = true; splits = s; dma_bn = 0; }
+        }
+    }
     if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)
     if (!a.ws || splits < 1 || a.geglu) splits = 1;
     while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
@@ -892,7 +1130,9 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     }
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
-    if (dma_bn && !a.geglu) {
+    if (use_p8 || (force_tile == 256 && !a.geglu && !a.ln_colsum)) {
+        launch_p8(a, st);
+    } else if (dma_bn && !a.geglu) {
         const int tdma = ((a.M + dma_bm - 1) / dma_bm) * ((a.N + dma_bn - 1) / dma_bn);
         if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
         else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
