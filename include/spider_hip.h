@@ -116,9 +116,11 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
  * ff.net.0.proj; diffusers-0.25 attention.py, reached from custom_sd.py:634-639). The normalisation is folded:
  *   Wf = W * diag(gamma) (bf16 [N,K]), colsum[n] = sum_k Wf[n,k] (fp32), colbias[n] = sum_k beta[k] W[n,k] + bias[n] (fp32)
  * are prepared once per layer by the caller; the kernel takes the row statistics of A while it stages the rows and applies
- * C = rstd * (A.Wf^T - mean * colsum) + colbias in the epilogue. Rows of A are K wide (lda = K). */
+ * C = rstd * (A.Wf^T - mean * colsum) + colbias in the epilogue. Rows of A are K wide (lda = K).
+ * ws (optional, >= ceil(M/256)*256*8 bytes): lets large problems run on the 256x256 LDS-DMA kernel, whose row statistics
+ * come from a preceding one-wave-per-row pass instead of the staging loop. */
 int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
-                        int M, int N, int K, int ldc, int act, float eps, void* stream);
+                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream);
 
 /* Fused cross-attention sub-block of BasicTransformerBlock (diffusers-0.25 attention.py, reached from custom_sd.py:634-639):
  *   out = x + to_out( softmax( to_q(LayerNorm(x)) K^T / sqrt(d) ) V )      for 8 heads and <= 80 text keys, ONE launch.

@@ -60,6 +60,9 @@ struct GemmArgs {
     const float* ln_colsum;
     const float* ln_bias;
     float ln_eps;
+    // the 256^2 LDS-DMA kernel never sees A in registers: its LN form reads {mean, rstd} per row from this array, filled by
+    // ln_row_stats_kernel just before the launch (padded to a multiple of 256 rows)
+    const float2* ln_rows;
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -733,8 +736,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
 //   (P3 / P4 of this K tile, for K tile kt+2) have landed, i.e. K tile kt+1 is complete when phase 1 reads it.
 // The wave tile needs 24 fragment reads per 64 MFMAs (the 128 x 160 kernel above: 14 per 20).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CONV, int EPI>
+template <bool CONV, int EPI, bool LN = false>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
+    constexpr bool GEGLU = EPI == 2;
     constexpr int HT = 128 * 128;                     // bytes of a half-tile (128 rows x 128 B)
     constexpr int KT_BYTES = 4 * HT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -743,7 +747,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int ncols = GEGLU ? 2 * p.N : p.N;     // GEGLU: a 256-row W tile yields 128 output columns
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (ncols + 255) / 256;
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = p.n_fast ? bid / tiles_n : bid % tiles_m, tn = p.n_fast ? bid % tiles_n : bid / tiles_m;
     const int m0 = tm * 256, n0 = tn * 256;
@@ -776,8 +781,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
                 a_oy[h][j] = a_ox[h][j] = 0;
             }
-            const int n = n0 + h * 128 + R;
-            const bool okn = n < p.N;
+            int n = n0 + h * 128 + R;
+            bool okn = n < p.N;
+            if (GEGLU) {
+                // each wave column (64 W-tile rows) holds the 32 value rows and then the 32 gate rows of the same 32 output columns,
+                // so a lane finds value and gate of one output element in its own accumulators (n-tiles j and j + 2)
+                const int wcol = 2 * h + R / 64, within = R % 64;
+                const int oc = n0 / 2 + wcol * 32 + within % 32;
+                okn = oc < p.N;
+                n = (within >= 32 ? p.N : 0) + oc;
+            }
             w_inv[h][j] = okn ? 0u : 0xFFFFFFFFu;
             w_base[h][j] = okn ? (uint32_t)n * (uint32_t)p.K * 2u + gch[j] * 16u : 0u;
         }
@@ -908,7 +921,69 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();        // matches group 1's extra barrier at the start
     wait_vmcnt<0>();                                  // the masked tail DMAs must not outlive the workgroup's LDS allocation
 
-    write_out<8, 4, EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, split, lane);
+    if (GEGLU) {      // value tile j and gate tile j + 2 of the same lane (diffusers GEGLU: hidden * gelu(gate))
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            float2 ms = float2{0.f, 1.f};
+            if (LN && m < p.M) ms = p.ln_rows[m];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = (n0 / 2) + wc * 32 + j * 16 + (lane >> 4) * 4;
+                if (m < p.M && n < p.N) {
+                    float r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ne = n + e < p.N ? n + e : p.N - 1;
+                        float v = acc[i][j][e], g = acc[i][j + 2][e];
+                        if (LN) {
+                            v = ms.y * (v - ms.x * p.ln_colsum[ne]) + p.ln_bias[ne];
+                            g = ms.y * (g - ms.x * p.ln_colsum[p.N + ne]) + p.ln_bias[p.N + ne];
+                        } else if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
+                        v = bf16_to_f32(f32_to_bf16(v));
+                        g = bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16_to_f32(f32_to_bf16(g)))));
+                        r[e] = v * g;
+                    }
+                    if (n + 3 < p.N) {
+                        u32x2 o;
+                        o.x = pack_bf16x2(r[0], r[1]);
+                        o.y = pack_bf16x2(r[2], r[3]);
+                        *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(r[e]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    write_out<8, 4, EPI, LN>(p, acc, m0 + wr * 128, n0 + wc * 64, split, lane, p.ln_rows, 0);
+}
+
+// {mean, rstd} of every row of A [M, K] (K % 8 == 0): one wave per row, fp32 sums -- the statistics the LN instantiations of
+// gemm_kernel accumulate while staging A (same formulas: var = max(E[x^2] - mean^2, 0)), for the kernel that stages by DMA
+__global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restrict__ A, float2* __restrict__ out, int M, int K, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const u32x4* a = reinterpret_cast<const u32x4*>(A + (size_t)row * K);
+    float s_ = 0.f, q_ = 0.f;
+    for (int c = lane; c < K / 8; c += 64) {
+        const u32x4 v = a[c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float lo = bf16lo_to_f32(w[d]), hi = bf16hi_to_f32(w[d]);
+            s_ += lo + hi;
+            q_ = fmaf(lo, lo, fmaf(hi, hi, q_));
+        }
+    }
+    s_ = wave_sum(s_);
+    q_ = wave_sum(q_);
+    if (lane == 0) {
+        const float mean = s_ / (float)K;
+        const float var = fmaxf(q_ / (float)K - mean * mean, 0.f);
+        out[row] = float2{mean, rsqrtf(var + eps)};
+    }
 }
 
 // split-K: sum the fp32 slabs and apply the epilogue; one thread per 4 consecutive columns
@@ -978,21 +1053,29 @@ void launch_dma_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
     gemm_dma_kernel<BN, NS, CONV, EPI, BM><<<grid, 512, smem, st>>>(a);
 }
 
-template <bool CONV, int EPI>
+template <bool CONV, int EPI, bool LN = false>
 void launch_p8_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int smem = 2 * 4 * 128 * 128;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<CONV, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<CONV, EPI, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         once = true;
     }
-    gemm_p8_kernel<CONV, EPI><<<grid, 512, smem, st>>>(a);
+    gemm_p8_kernel<CONV, EPI, LN><<<grid, 512, smem, st>>>(a);
 }
 
 void launch_p8(const GemmArgs& a, hipStream_t st) {
-    dim3 grid(((a.M + 255) / 256) * ((a.N + 255) / 256), a.splits);
+    const int ncols = a.geglu ? 2 * a.N : a.N;
+    dim3 grid(((a.M + 255) / 256) * ((ncols + 255) / 256), a.splits);
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
+    if (a.ln_colsum) {      // LayerNorm-folded linears: row statistics from ln_row_stats_kernel (launched by the caller)
+        if (a.geglu) launch_p8_inst<false, 2, true>(a, grid, st);
+        else if (epi == 3) launch_p8_inst<false, 3, true>(a, grid, st);
+        else launch_p8_inst<false, 0, true>(a, grid, st);
+        return;
+    }
+    if (a.geglu) { launch_p8_inst<false, 2>(a, grid, st); return; }
     if (a.conv) {
         if (epi == 3) launch_p8_inst<true, 3>(a, grid, st);
         else if (epi == 1) launch_p8_inst<true, 1>(a, grid, st);
@@ -1107,11 +1190,14 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // pad N (N = 320: 0.625 of the tile area used, 189 -> 235 us) or fewer than ~160 blocks exist (4608 x 1280 x 1280: 29 -> 32).
     static const int p8_env = getenv("SPIDER_GEMM_P8") ? atoi(getenv("SPIDER_GEMM_P8")) : 1;
     bool use_p8 = false;
-    if (p8_env && !force_tile && !force_splits && !a.geglu && !a.ln_colsum && nk >= 8) {
-        const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        if ((double)a.M * a.N >= 0.75 * 65536.0 * (double)t256) {
+    const bool p8_fused = a.geglu || a.ln_colsum;     // GEGLU / LayerNorm-folded forms: no split-K on this kernel
+    const size_t ln_rows_bytes = (size_t)((a.M + 255) / 256) * 256 * sizeof(float2);
+    if (p8_env && !force_tile && !force_splits && nk >= 8 && !(a.geglu && a.conv) &&
+        (!a.ln_colsum || (a.ws && ln_rows_bytes <= (size_t)ws_bytes && a.act == 0))) {
+        const long t256 = (long)((a.M + 255) / 256) * ((ncols + 255) / 256);
+        if ((double)a.M * ncols >= 0.75 * 65536.0 * (double)t256) {
             int s = 1;
-            if (t256 < 160 && a.ws) {
+            if (t256 < 160 && a.ws && !p8_fused) {
                 s = (int)((192 + t256 - 1) / t256);
                 if (s > nk / 16) s = nk / 16;
                 if (s < 1) s = 1;
@@ -1131,6 +1217,11 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
     if (use_p8 || (force_tile == 256 && !a.geglu && !a.ln_colsum)) {
+        if (a.ln_colsum) {
+            a.ln_rows = reinterpret_cast<const float2*>(a.ws);
+            ln_row_stats_kernel<<<(a.M + 3) / 4, 256, 0, st>>>(a.A, reinterpret_cast<float2*>(a.ws), a.M, a.K, a.ln_eps);
+            SPIDER_LAUNCH_OK();
+        }
         launch_p8(a, st);
     } else if (dma_bn && !a.geglu) {
         const int tdma = ((a.M + dma_bm - 1) / dma_bm) * ((a.N + dma_bn - 1) / dma_bn);
@@ -1191,7 +1282,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
 // C = rstd * (A.Wf^T - mean * colsum) + colbias in its epilogue. Replaces BasicTransformerBlock.norm1/2/3 + the projection
 // that consumes it (diffusers-0.25 attention.py; call site custom_sd.py:634-639). lda must equal K (whole rows are normalised).
 int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
-                        int M, int N, int K, int ldc, int act, float eps, void* stream) {
+                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm_ln: empty problem");
     SPIDER_CHECK(K % 8 == 0, "gemm_ln: K must be a multiple of 8 (16-byte rows)");
     SPIDER_CHECK(act == 0 || act == 4, "gemm_ln: only the plain and the GEGLU epilogue are built");
@@ -1204,14 +1295,14 @@ int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* col
     a.geglu = act == 4;
     a.N = a.geglu ? N / 2 : N;
     SPIDER_CHECK(a.N % 4 == 0 && ldc % 4 == 0 && ldc >= a.N, "gemm_ln: output width and ldc must be multiples of 4, ldc >= width");
-    a.act = 0; a.act_param = 0.f; a.out_scale = 1.f; a.conv = 0; a.ws = nullptr;
+    a.act = 0; a.act_param = 0.f; a.out_scale = 1.f; a.conv = 0; a.ws = (float*)ws;     // ws: row statistics of the 256^2 form
     a.ln_colsum = colsum; a.ln_bias = colbias; a.ln_eps = eps;
     SPIDER_CHECK((size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 2 < ((size_t)1 << 31),
                  "gemm_ln: operands must be < 2 GiB");
     a.a_bytes = (uint32_t)((size_t)M * K * 2);
     a.w_bytes = (uint32_t)((size_t)N * K * 2);
     set_epilogue_ranges(a);
-    return launch(a, 0, stream);
+    return launch(a, ws ? ws_bytes : 0, stream);
 }
 
 // NHWC conv as implicit GEMM, general form. x [B, Hin, Win, Cin] bf16; w [Cout, kh, kw, Cin] bf16 (OHWI);

@@ -269,7 +269,7 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
     if res is not None:
         _chk(res, BF16, "res")
     _lib.call("spider_gemm_ln_bf16", _p(A), _p(Wf), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out, ACT[act], float(eps),
-              _stream())
+              _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
 

@@ -141,7 +141,10 @@ def test_attn_decode(ops, dev, B, n_q, n_kv, T, nsplit, beg):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1536, 4608, 3584), (77, 320, 768), (8192, 320, 320), (200, 36, 72),
                                    (1, 1280, 320), (130, 132, 1032),
                                    (4096, 320, 2560),      # long-K linear with >= 2048 rows: the LDS-DMA kernel, 4 K splits
-                                   (2100, 312, 2568)])     # same path with ragged M / N / K tails (N, K multiples of 8 / 4 only)
+                                   (2100, 312, 2568),      # same path with ragged M / N / K tails (N, K multiples of 8 / 4 only)
+                                   (4608, 3840, 1280),     # 256^2 LDS-DMA kernel (>= 160 tiles): SDXL 24^2 qkv
+                                   (1536, 3584, 3584),     # 256^2 kernel with 3 K splits (84 tiles): LLM prefill o-proj
+                                   (4000, 2500, 1096)])    # 256^2 kernel, ragged M / N / K tails
 def test_gemm(ops, dev, M, N, K):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     ref = A.float() @ W.float().T
@@ -398,7 +401,9 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
         assert int(cnt.abs().sum()) == 0, "ticket counters must be back to zero after every launch"
 
 
-@pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280)])
+@pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280),
+                                       (4608, 5120, 1280),    # 256^2 LDS-DMA kernel with the GEGLU epilogue (SDXL 24^2 ff1)
+                                       (4000, 2504, 1096)])   # the same, ragged M / N / K
 def test_gemm_fused_geglu(ops, dev, M, inner, K):
     A, W, b = rnd(M, K, seed=1), rnd(2 * inner, K, seed=2, scale=0.05), rnd(2 * inner, seed=3, scale=0.2)
     p = A.float() @ W.float().T + b.float()
@@ -503,7 +508,9 @@ def test_attention_late_max_jump(ops, dev, spike_tile):
 
 
 @pytest.mark.parametrize("M,N,K,mean", [(8192, 960, 320, 0.0), (2048, 640, 640, 3.0), (520, 1280, 1280, -8.0), (77, 72, 64, 0.5),
-                                        (300, 3840, 1280, 0.0), (8192, 320, 320, 1.0)])
+                                        (300, 3840, 1280, 0.0), (8192, 320, 320, 1.0),
+                                        (4608, 10240, 1280, 2.0),     # 256^2 LDS-DMA kernel, row statistics from their own pass
+                                        (4100, 3848, 1096, -1.0)])    # the same, ragged M / N / K
 def test_gemm_layernorm_folded(ops, dev, M, N, K, mean):
     """LayerNorm folded into the consuming GEMM (spider_gemm_ln_bf16) against torch fp32 LayerNorm -> linear, plain / + residual /
     GEGLU; rows with a large common offset (|mean| >> std) exercise the mean-cancellation term."""
