@@ -1199,6 +1199,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
             int s = 1;
             if (t256 < 160 && a.ws && !p8_fused) {
                 s = (int)((192 + t256 - 1) / t256);
+                if (s > 3) s = 3;     // more splits: the slab round trip wins back nothing (2048 x 640 x 11520 conv, 8 splits: 58 vs 48 us)
                 if (s > nk / 16) s = nk / 16;
                 if (s < 1) s = 1;
                 while (s > 1 && (size_t)s * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --s;
