@@ -166,7 +166,10 @@ def test_gemm(ops, dev, M, N, K):
                                                           (1, 16, 12, 128, 64, 3, 2, False), (2, 8, 8, 128, 128, 3, 1, True),
                                                           (2, 16, 16, 192, 64, 1, 1, False), (1, 9, 7, 64, 68, 3, 1, False),
                                                           (2, 16, 16, 640, 1280, 3, 1, False),    # 16^2 map: LDS-DMA kernel, 8 K splits
-                                                          (2, 64, 64, 320, 320, 3, 2, False)])    # stride 2 on the DMA path (M = 2048)
+                                                          (2, 64, 64, 320, 320, 3, 2, False),     # stride 2 on the DMA path (M = 2048)
+                                                          (8, 48, 48, 64, 640, 3, 1, False),      # 256^2 LDS-DMA kernel (216 tiles), halo taps
+                                                          (8, 47, 49, 128, 632, 3, 1, False),     # the same, ragged rows / columns
+                                                          (8, 24, 24, 64, 1280, 3, 1, True)])     # the same through the fused 2x upsample
 def test_conv2d(ops, dev, B, H, W, Cin, Cout, ks, stride, ups):
     x, w, bias = rnd(B, H, W, Cin, seed=1), rnd(Cout, ks, ks, Cin, seed=2, scale=0.05), rnd(Cout, seed=3)
     xin = x.float().permute(0, 3, 1, 2)
