@@ -279,7 +279,7 @@ def _unet_pmc_traffic(kernel_prefix):
 
 def measure_mfma_roofline(device):
     """Largest MFMA-bound kernel class of the UNet step: the 3x3 implicit-GEMM conv (ResnetBlock2D conv at the 64x64 latent,
-    320 -> 320 channels, CFG batch 2: M = 8192 output pixels, N = 320, K = 2880; the LDS-DMA kernel with 2 K splits + reduce).
+    320 -> 320 channels, CFG batch 2: M = 8192 output pixels, N = 320, K = 2880; the LDS-DMA kernel on 64-row tiles, no split-K).
     Algorithmic flops per call = 2*M*N*K; timed live with HIP events over back-to-back calls on torch's current stream."""
     from spider_amd import ops
     x = torch.randn(2, 64, 64, 320, device=device).to(torch.bfloat16)
@@ -303,9 +303,9 @@ def measure_mfma_roofline(device):
     us = e0.elapsed_time(e1) * 1e3 / n
     flops = 2 * 8192 * 320 * 2880
     tf = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,3,CONV> + splitk_reduce (UNet 3x3 conv, 64x64 latent, 320->320, batch 2)",
+    return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,4,CONV,BM=64> (UNet 3x3 conv, 64x64 latent, 320->320, batch 2; 256 tiles of 64 x 160, no split-K)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": _unet_pmc_traffic("gemm_dma_kernel<160, 3, true, 0>")[0], "traffic_source": _unet_pmc_traffic("gemm_dma_kernel<160, 3, true, 0>")[1],
+            "traffic": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64>")[0], "traffic_source": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64>")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
@@ -336,9 +336,9 @@ def measure_attention_roofline(device):
     us = e0.elapsed_time(e1) * 1e3 / n
     flops = 4 * N * N * C * B
     tf = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "attn_flash_kernel<64> (UNet self-attention, 64x64 latent: 4096 tokens, 8 heads, d=40, batch 2)",
+    return {"bound": "mfma", "kernel": "attn_flash_pipe_kernel<64> (UNet self-attention, 64x64 latent: 4096 tokens, 8 heads, d=40, batch 2)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": _unet_pmc_traffic("attn_flash_kernel<64, true>")[0], "traffic_source": _unet_pmc_traffic("attn_flash_kernel<64, true>")[1],
+            "traffic": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true>")[0], "traffic_source": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true>")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 

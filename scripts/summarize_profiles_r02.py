@@ -64,7 +64,10 @@ def per_kernel(path, counter):
 # ---- HBM bytes of the UNet kernels (FETCH_SIZE x2 on gfx950 for wide coalesced reads, WRITE_SIZE as read; KB -> bytes)
 fe, wr = per_kernel(f"{G}/pmc_{tag}_unet_fetch", "FETCH_SIZE"), per_kernel(f"{G}/pmc_{tag}_unet_write", "WRITE_SIZE")
 if fe:
-    top = sorted(fe, key=lambda k: -fe[k][0] * fe[k][1])[:8]
+    ours = [k for k in fe if not k.startswith("at::") and not k.startswith("void at::") and "rocblas" not in k and "rocclr" not in k]
+    top = sorted(ours, key=lambda k: -fe[k][0] * fe[k][1])[:12]
+    for must in ("gemm_dma_kernel<160, 4, true, 0, 64>", "attn_flash_pipe_kernel<64, true>"):      # the bench.py roofline kernels
+        top += [k for k in ours if k.startswith(must) and k not in top]
     out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python scripts/prof_unet.py 4; per-launch averages over all "
                    "launches of the kernel in the UNet step; FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide "
                    "coalesced streams (x2 applied in hbm_read_bytes), WRITE_SIZE is exact for 16-B-per-lane stores (MI355X_MICROARCH.md, HBM section)",
