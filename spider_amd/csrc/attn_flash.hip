@@ -43,6 +43,7 @@ struct AttnArgs {
     // image block): masked keys are never loaded or scored instead of being scored and zeroed
     const int* key_idx;
     int idx_len;
+    int xcd_order;   // 1: remap the launch order so that one XCD walks the q tiles of a (batch, head) (SPIDER_ATTN_XCD, default on)
 };
 
 // value of the partner lane (lane ^ 32) by v_permlane32_swap: a VALU op, where __shfl_xor(x, 32) is a ds_bpermute round trip
@@ -78,7 +79,19 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h32 = lane >> 5, l32 = lane & 31;
-    const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest), so with the plain
+    // (q tile, head, batch) indices every XCD saw every head and pulled all of K / V through its own 4 MiB L2 (PMC: 89 MB fetched
+    // for 16 MB of operands at the UNet's 64^2 self-attention). Remapped, an XCD owns a contiguous run of the logical grid: the
+    // q tiles of one (batch, head) share an L2 and K / V come from HBM once.
+    int qt, hq, b;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int flat = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int L = p.xcd_order ? xcd_remap(flat, gx * gy * (int)gridDim.z) : flat;
+        qt = L % gx;
+        hq = (L / gx) % gy;
+        b = L / (gx * gy);
+    }
     const int hk = hq / (p.Hq / p.Hkv);
     int q0 = qt * 128, lq_end = p.Lq, seg_kbeg = 0, lk_end = p.Lk;
     if (!PLAIN && p.tiles) {
@@ -416,7 +429,19 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     bf16_t* const Vb = Kb + 2 * 64 * C::KS;                              // 2 x [64][VS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h32 = lane >> 5, l32 = lane & 31;
-    const int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest), so with the plain
+    // (q tile, head, batch) indices every XCD saw every head and pulled all of K / V through its own 4 MiB L2 (PMC: 89 MB fetched
+    // for 16 MB of operands at the UNet's 64^2 self-attention). Remapped, an XCD owns a contiguous run of the logical grid: the
+    // q tiles of one (batch, head) share an L2 and K / V come from HBM once.
+    int qt, hq, b;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int flat = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int L = p.xcd_order ? xcd_remap(flat, gx * gy * (int)gridDim.z) : flat;
+        qt = L % gx;
+        hq = (L / gx) % gy;
+        b = L / (gx * gy);
+    }
     const int hk = hq / (p.Hq / p.Hkv);
     const int q0 = qt * 128, lk_end = p.Lk;
     const int qi = q0 + wave * 32 + l32;
@@ -665,6 +690,8 @@ int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
     const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
+    static const int xcd_env = [] { const char* e = getenv("SPIDER_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    const_cast<AttnArgs&>(a).xcd_order = xcd_env;
     if (a.key_idx) {
         if constexpr (DP == 64) {       // the StoryDiffusion / SDXL heads (d = 64; smaller heads ride in the same 64-wide tile)
             if (a.d < DP) attn_flash_kernel<DP, true, false, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
