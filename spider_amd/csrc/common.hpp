@@ -95,6 +95,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 }  // namespace spider
 
+// Dynamic LDS above 64 KiB must be enabled per function AND per device (one process may drive engines on several GPUs): raise it
+// once for each device the function is launched on. `done_mask` is the caller's static bit mask (bit = device ordinal mod 32).
+template <typename F>
+inline void raise_dynamic_lds(F* fn, int bytes, unsigned& done_mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(done_mask & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done_mask |= bit;
+    }
+}
+
 // ---- error plumbing shared by the C-ABI translation units ----
 extern "C" void spider_set_error(const char* msg);
 #define SPIDER_CHECK(cond, msg)            \

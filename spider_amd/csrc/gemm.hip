@@ -1045,22 +1045,16 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
 template <int BN, int NS, bool CONV, int EPI, int BM = 128>
 void launch_dma_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int smem = NS * (BM + BN) * 128;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<BN, NS, CONV, EPI, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        once = true;
-    }
+    static unsigned done = 0;
+    raise_dynamic_lds(&gemm_dma_kernel<BN, NS, CONV, EPI, BM>, smem, done);
     gemm_dma_kernel<BN, NS, CONV, EPI, BM><<<grid, 512, smem, st>>>(a);
 }
 
 template <bool CONV, int EPI, bool LN = false>
 void launch_p8_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
     constexpr int smem = 2 * 4 * 128 * 128;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<CONV, EPI, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        once = true;
-    }
+    static unsigned done = 0;
+    raise_dynamic_lds(&gemm_p8_kernel<CONV, EPI, LN>, smem, done);
     gemm_p8_kernel<CONV, EPI, LN><<<grid, 512, smem, st>>>(a);
 }
 

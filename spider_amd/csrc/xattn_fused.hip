@@ -259,11 +259,8 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
 template <int BM, int CTW>
 int launch_x(const XArgs& a, hipStream_t st) {
     constexpr int smem = 2 * BM * 128 + BM * 8 + BM * XPS;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<BM, CTW>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        once = true;
-    }
+    static unsigned done = 0;
+    raise_dynamic_lds(&xattn_fused_kernel<BM, CTW>, smem, done);
     xattn_fused_kernel<BM, CTW><<<a.rows / BM, 512, smem, st>>>(a);
     SPIDER_LAUNCH_OK();
     return 0;
