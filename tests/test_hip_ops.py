@@ -404,6 +404,25 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
         assert int(cnt.abs().sum()) == 0, "ticket counters must be back to zero after every launch"
 
 
+def test_gemm_256_tile_repeatable_under_load(ops, dev):
+    """Race screen of the 256 x 256 LDS-DMA kernel (counted vmcnt, raw barriers, wave groups half a phase apart): repeated launches
+    must be bit-identical while another stream keeps HBM busy (a DMA tile read before it landed would show up as a differing
+    repeat). Longer form: scripts/exp/p8_race_screen.py."""
+    side = torch.cuda.Stream()
+    junk = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+    A, W = rnd(4608, 1280, seed=1).to(dev), rnd(3840, 1280, seed=2, scale=0.05).to(dev)
+    A2, W2 = rnd(1536, 3584, seed=3).to(dev), rnd(3584, 3584, seed=4, scale=0.05).to(dev)     # 3 K splits
+    x, w = rnd(8, 48, 48, 128, seed=5).to(dev), rnd(640, 3, 3, 128, seed=6, scale=0.03).to(dev)
+    for f in (lambda: ops.gemm(A, W), lambda: ops.gemm(A2, W2), lambda: ops.gemm(A, W, act="geglu"), lambda: ops.conv2d(x, w)):
+        ref = f().clone()
+        for i in range(40):
+            if i % 2 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            assert torch.equal(f(), ref), f"repeat {i} differs"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280),
                                        (4608, 5120, 1280),    # 256^2 LDS-DMA kernel with the GEGLU epilogue (SDXL 24^2 ff1)
                                        (4000, 2504, 1096)])   # the same, ragged M / N / K
