@@ -202,21 +202,26 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     bf16_t* catb = cat ? cat + (size_t)b * HW * C + g * cpg : nullptr;
     // the group's data is read ONCE into registers (all loads independent and in flight together)
     uint32_t v[MAXP];
-    int off[MAXP];
+    int off[MAXP];          // element offset of the pair inside the batch image; the pair's channel offset 2*cp rides in bits 24..31
+    // element i = threadIdx.x + 256 u lives at pixel i / hp, pair i % hp: one division for u = 0, then a carry-step per u (the 20
+    // runtime divisions + 20 modulos per thread of the first version were most of the kernel's instructions, in front of its loads)
+    int px = (int)threadIdx.x / hp, cp = (int)threadIdx.x - px * hp;
+    const int dq = 256 / hp, dr = 256 - dq * hp;
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
         const int i = threadIdx.x + u * 256;
-        const int ic = i < n ? i : 0;
-        const int px = ic / hp, cp = ic - px * hp;
-        off[u] = px * C + 2 * cp;
+        const int o = px * C + 2 * cp;
+        off[u] = o | (cp << 25);
         if (x2) {
             const int c = g * cpg + 2 * cp;
             const bf16_t* src = c < C1 ? x1b + (size_t)px * C1 + c : x2b + (size_t)px * (C - C1) + (c - C1);
             v[u] = i < n ? *reinterpret_cast<const uint32_t*>(src) : 0u;
-            if (catb && i < n) *reinterpret_cast<uint32_t*>(catb + off[u]) = v[u];
+            if (catb && i < n) *reinterpret_cast<uint32_t*>(catb + o) = v[u];
         } else {
-            v[u] = i < n ? *reinterpret_cast<const uint32_t*>(xb + off[u]) : 0u;
+            v[u] = i < n ? *reinterpret_cast<const uint32_t*>(xb + o) : 0u;
         }
+        px += dq; cp += dr;
+        if (cp >= hp) { cp -= hp; ++px; }
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     for (int u = 0; u < MAXP; ++u) {
         const int i = threadIdx.x + u * 256;
         if (i < n) {
-            const int cp2 = off[u] % C;   // = 2*cp (channel offset inside the group)
+            const int cp2 = (int)((unsigned)off[u] >> 25) * 2, o = off[u] & 0x1FFFFFF;     // channel offset inside the group, element offset
             const uint32_t gv = *reinterpret_cast<const uint32_t*>(gamma + g * cpg + cp2);
             const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + cp2);
             float lo = (bf16lo_to_f32(v[u]) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
                 lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
                 hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
             }
-            *reinterpret_cast<uint32_t*>(yb + off[u]) = pack_bf16x2(lo, hi);
+            *reinterpret_cast<uint32_t*>(yb + o) = pack_bf16x2(lo, hi);
         }
     }
 }
