@@ -376,6 +376,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
+    // running tap state of the next K tile to load (CONV with Cin % 64 == 0): see load_tile
+    int run_c = 0, run_ky = 0, run_kx = 0;
+    if (CONV && p.cin64) {
+        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
+        run_c = kk0 - tap0 * p.Cin;
+        run_ky = tap0 / p.kw;
+        run_kx = tap0 - run_ky * p.kw;
+    }
     // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring); branch-free
     auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC]) {
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
@@ -385,11 +393,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + chunk * 8)) >> 31) | (uint32_t)((kt1 - 1 - kt) >> 31);
         if (CONV) {
             // tap of this lane's 8 k-elements: uniform per tile when Cin % 64 == 0, per lane otherwise (Cin % 8 == 0
-            // keeps a 16-byte chunk inside one tap)
-            const int kk = p.cin64 ? kt * BK : kt * BK + chunk * 8;
-            const int tap = kk / p.Cin;
-            const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? chunk * 8 : 0)) * 2u;
-            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            // keeps a 16-byte chunk inside one tap). Tiles are requested in increasing kt order, so with Cin % 64 == 0 the
+            // (tap row, tap column, channel) of the tile is carried along instead of being re-derived by two integer divisions
+            // (~35 VALU instructions per K tile and wave, next to 20-40 MFMAs).
+            int ky, kx;
+            uint32_t cbyte;
+            if (p.cin64) {
+                ky = run_ky; kx = run_kx;
+                cbyte = (uint32_t)(run_c + chunk * 8) * 2u;
+                run_c += BK;
+                if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+            } else {
+                const int kk = kt * BK + chunk * 8;
+                const int tap = kk / p.Cin;
+                cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
+                ky = tap / p.kw; kx = tap - ky * p.kw;
+            }
             const int hlim = p.lim_h, wlim = p.lim_w;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
@@ -636,19 +655,40 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
 
     // DMA of K tile kt into ring stage `stage` (wave-uniform); tiles >= kt1 / chunks >= K are all-ones offsets -> zeros
+    // running tap state of the next K tile to issue (CONV with Cin % 64 == 0; tiles are issued in increasing kt order): the
+    // tap row / column / channel are carried along instead of re-derived by two integer divisions per tile
+    int run_c = 0, run_ky = 0, run_kx = 0;
+    if (CONV && p.cin64) {
+        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
+        run_c = kk0 - tap0 * p.Cin;
+        run_ky = tap0 / p.kw;
+        run_kx = tap0 - run_ky * p.kw;
+    }
     auto issue = [&](int kt, int stage) {
         char* sb = smem + stage * STAGE;
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
         const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
+        const int t_c = run_c, t_ky = run_ky, t_kx = run_kx;
+        if (CONV && p.cin64) {
+            run_c += BK;
+            if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)a_gch[j] * 8)) >> 31) | t_inv;
             uint32_t off;
             if (CONV) {
-                const int kk = p.cin64 ? kt * BK : kt * BK + (int)a_gch[j] * 8;
-                const int tap = kk / p.Cin;
-                const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? (int)a_gch[j] * 8 : 0)) * 2u;
-                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                int ky, kx;
+                uint32_t cbyte;
+                if (p.cin64) {
+                    ky = t_ky; kx = t_kx;
+                    cbyte = (uint32_t)(t_c + (int)a_gch[j] * 8) * 2u;
+                } else {
+                    const int kk = kt * BK + (int)a_gch[j] * 8;
+                    const int tap = kk / p.Cin;
+                    cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
+                    ky = tap / p.kw; kx = tap - ky * p.kw;
+                }
                 int iy = a_oy[j] * p.stride + ky * p.dil - p.pad_h;
                 int ix = a_ox[j] * p.stride + kx * p.dil - p.pad_w;
                 const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
@@ -799,21 +839,43 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
 
+    // running tap state of the next K tile of each A half (CONV with Cin % 64 == 0): each half's shares are issued in increasing
+    // kt order, so tap row / column / channel are carried along instead of re-derived by two integer divisions per share
+    int run_c[2] = {0, 0}, run_ky[2] = {0, 0}, run_kx[2] = {0, 0};
+    if (CONV && p.cin64) {
+        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
+        run_c[0] = run_c[1] = kk0 - tap0 * p.Cin;
+        run_ky[0] = run_ky[1] = tap0 / p.kw;
+        run_kx[0] = run_kx[1] = tap0 - run_ky[0] * p.kw;
+    }
     // one half-tile share of this wave: kind 0 = A, 1 = W; tiles >= kt1 and chunks >= K are all-ones offsets (DMA writes zeros)
     auto issue = [&](int kind, int h, int kt, int buf) {
         char* sb = smem + buf * KT_BYTES + (kind * 2 + h) * HT;
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
         const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
+        int t_c = 0, t_ky = 0, t_kx = 0;
+        if (CONV && kind == 0 && p.cin64) {
+            t_c = run_c[h]; t_ky = run_ky[h]; t_kx = run_kx[h];
+            run_c[h] += BK;
+            if (run_c[h] >= p.Cin) { run_c[h] = 0; if (++run_kx[h] == p.kw) { run_kx[h] = 0; ++run_ky[h]; } }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)gch[j] * 8)) >> 31) | t_inv;
             uint32_t off;
             if (kind == 0) {
                 if (CONV) {
-                    const int kk = p.cin64 ? kt * BK : kt * BK + (int)gch[j] * 8;
-                    const int tap = kk / p.Cin;
-                    const uint32_t cbyte = (uint32_t)(kk - tap * p.Cin + (p.cin64 ? (int)gch[j] * 8 : 0)) * 2u;
-                    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                    int ky, kx;
+                    uint32_t cbyte;
+                    if (p.cin64) {
+                        ky = t_ky; kx = t_kx;
+                        cbyte = (uint32_t)(t_c + (int)gch[j] * 8) * 2u;
+                    } else {
+                        const int kk = kt * BK + (int)gch[j] * 8;
+                        const int tap = kk / p.Cin;
+                        cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
+                        ky = tap / p.kw; kx = tap - ky * p.kw;
+                    }
                     int iy = a_oy[h][j] * p.stride + ky * p.dil - p.pad_h;
                     int ix = a_ox[h][j] * p.stride + kx * p.dil - p.pad_w;
                     const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
