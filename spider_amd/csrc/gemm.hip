@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // Validity is carried as all-ones / zero masks OR-ed into the offset (pure ALU): a select would be turned into a
     // divergent branch by the compiler, which again hides the loads from its vmcnt bookkeeping.
     uint32_t a_base[AC], a_inv[AC];   // byte offset of the row (linear) / image (conv); a_inv = ~0 for rows >= M
+    uint32_t a_lin[AC];
     int a_oy[AC], a_ox[AC];
     uint32_t w_base[WC], w_inv[WC];
 #pragma unroll
@@ -347,12 +348,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int b = mc / hw, rem = mc % hw;
-            a_oy[i] = rem / p.Wout;
-            a_ox[i] = rem % p.Wout;
+            a_oy[i] = (rem / p.Wout) * p.stride - p.pad_h;      // input row / column of tap (0, 0)
+            a_ox[i] = (rem % p.Wout) * p.stride - p.pad_w;
             a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+            a_lin[i] = a_base[i] + (uint32_t)(a_oy[i] * p.Win + a_ox[i]) * (uint32_t)p.Cin * 2u;   // + tap offset = the tap's pixel (no upsample)
         } else {
             a_base[i] = (uint32_t)mc * (uint32_t)p.lda * 2u + chunk * 16u;
             a_oy[i] = a_ox[i] = 0;
+            a_lin[i] = 0;
         }
     }
 #pragma unroll
@@ -410,14 +413,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 ky = tap / p.kw; kx = tap - ky * p.kw;
             }
             const int hlim = p.lim_h, wlim = p.lim_w;
+            const int dy = ky * p.dil, dx = kx * p.dil;                                   // wave-uniform tap displacement
+            const uint32_t tap_off = (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
-                int iy = a_oy[i] * p.stride + ky * p.dil - p.pad_h;
-                int ix = a_ox[i] * p.stride + kx * p.dil - p.pad_w;
+                const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
                 // sign bit set if any of iy, ix, hlim-1-iy, wlim-1-ix is negative -> halo mask
                 const uint32_t halo = (uint32_t)((iy | ix | (hlim - 1 - iy) | (wlim - 1 - ix)) >> 31);
-                if (p.ups) { iy >>= 1; ix >>= 1; }
-                const uint32_t off = (a_base[i] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[i] | k_inv;
+                uint32_t lin = a_lin[i] + tap_off;
+                if (p.ups) lin = a_base[i] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * 2u + cbyte;
+                const uint32_t off = lin | halo | a_inv[i] | k_inv;
                 ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
             }
         } else {
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
 
     // this lane's slot in a piece: row prow of 8, 16-byte slot `slot` of 8; the global chunk it fetches is slot ^ swizzle(row)
     const int prow = lane >> 3, slot = lane & 7;
-    uint32_t a_base[AJ], a_inv[AJ], a_gch[AJ];
+    uint32_t a_base[AJ], a_inv[AJ], a_gch[AJ], a_lin[AJ];
     int a_oy[AJ], a_ox[AJ];
     uint32_t w_base[WJ], w_inv[WJ], w_gch[WJ];
 #pragma unroll
@@ -632,12 +637,14 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int b = mc / hw, rem = mc % hw;
-            a_oy[j] = rem / p.Wout;
-            a_ox[j] = rem % p.Wout;
+            a_oy[j] = (rem / p.Wout) * p.stride - p.pad_h;
+            a_ox[j] = (rem % p.Wout) * p.stride - p.pad_w;
             a_base[j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+            a_lin[j] = a_base[j] + (uint32_t)(a_oy[j] * p.Win + a_ox[j]) * (uint32_t)p.Cin * 2u;
         } else {
             a_base[j] = (uint32_t)mc * (uint32_t)p.lda * 2u + a_gch[j] * 16u;
             a_oy[j] = a_ox[j] = 0;
+            a_lin[j] = 0;
         }
     }
 #pragma unroll
@@ -689,11 +696,12 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
                     cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
                     ky = tap / p.kw; kx = tap - ky * p.kw;
                 }
-                int iy = a_oy[j] * p.stride + ky * p.dil - p.pad_h;
-                int ix = a_ox[j] * p.stride + kx * p.dil - p.pad_w;
+                const int dy = ky * p.dil, dx = kx * p.dil;
+                const int iy = a_oy[j] + dy, ix = a_ox[j] + dx;
                 const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
-                if (p.ups) { iy >>= 1; ix >>= 1; }
-                off = (a_base[j] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[j] | k_inv;
+                uint32_t lin = a_lin[j] + (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
+                if (p.ups) lin = a_base[j] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * 2u + cbyte;
+                off = lin | halo | a_inv[j] | k_inv;
             } else {
                 off = (a_base[j] + kbyte) | a_inv[j] | k_inv;
             }
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 
     // a DMA piece = 8 rows x 128 B (one wave instruction); a half-tile = 16 pieces, this wave issues pieces wave and 8 + wave
     const int prow = lane >> 3, slot = lane & 7;
-    uint32_t a_base[2][2], a_inv[2][2], w_base[2][2], w_inv[2][2], gch[2];
+    uint32_t a_base[2][2], a_inv[2][2], a_lin[2][2], w_base[2][2], w_inv[2][2], gch[2];
     int a_oy[2][2], a_ox[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -814,12 +822,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
             if (CONV) {
                 const int hw = p.Hout * p.Wout;
                 const int b = mc / hw, rem = mc % hw;
-                a_oy[h][j] = rem / p.Wout;
-                a_ox[h][j] = rem % p.Wout;
+                a_oy[h][j] = (rem / p.Wout) * p.stride - p.pad_h;
+                a_ox[h][j] = (rem % p.Wout) * p.stride - p.pad_w;
                 a_base[h][j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+                a_lin[h][j] = a_base[h][j] + (uint32_t)(a_oy[h][j] * p.Win + a_ox[h][j]) * (uint32_t)p.Cin * 2u;
             } else {
                 a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
                 a_oy[h][j] = a_ox[h][j] = 0;
+                a_lin[h][j] = 0;
             }
             int n = n0 + h * 128 + R;
             bool okn = n < p.N;
@@ -876,11 +886,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                         cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
                         ky = tap / p.kw; kx = tap - ky * p.kw;
                     }
-                    int iy = a_oy[h][j] * p.stride + ky * p.dil - p.pad_h;
-                    int ix = a_ox[h][j] * p.stride + kx * p.dil - p.pad_w;
+                    const int dy = ky * p.dil, dx = kx * p.dil;
+                    const int iy = a_oy[h][j] + dy, ix = a_ox[h][j] + dx;
                     const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
-                    if (p.ups) { iy >>= 1; ix >>= 1; }
-                    off = (a_base[h][j] + (uint32_t)(iy * p.Win + ix) * (uint32_t)p.Cin * 2u + cbyte) | halo | a_inv[h][j] | k_inv;
+                    uint32_t lin = a_lin[h][j] + (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
+                    if (p.ups) lin = a_base[h][j] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * 2u + cbyte;
+                    off = lin | halo | a_inv[h][j] | k_inv;
                 } else {
                     off = (a_base[h][j] + kbyte) | a_inv[h][j] | k_inv;
                 }
