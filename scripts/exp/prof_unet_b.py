@@ -1,0 +1,22 @@
+"""Profiling aid: N graph-replayed SD-v1.5 UNet steps at CFG batch 2 (run under rocprofv3 --kernel-trace --stats)."""
+import sys, torch
+from spider_amd import ops
+from spider_amd.schedulers import PNDMScheduler
+from spider_amd.unet import UNetConfig, UNetEngine
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+unet = UNetEngine.random_init(UNetConfig.sd15(), dev, seed=1)
+g = torch.Generator(device=dev).manual_seed(0)
+lat = torch.randn(1, 4, 64, 64, generator=g, device=dev)
+enc = torch.randn(int(sys.argv[2]) if len(sys.argv) > 2 else 2, 77, 768, generator=g, device=dev).bfloat16()
+ts = PNDMScheduler().set_timesteps(40)
+unet.prepare(ts, enc)
+x2 = ops.latent_to_nhwc(lat, reps=int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+unet.step(x2, 0)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(n):
+    unet.step(x2, i)
+e1.record(); e1.synchronize()
+print("unet step ms", e0.elapsed_time(e1) / n)
