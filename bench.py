@@ -309,6 +309,38 @@ def measure_mfma_roofline(device):
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
+def measure_prefill_gemm_roofline(device, cfg, prompt_len):
+    """Largest MFMA-bound kernel of the LLM prefill: the fused gate/up projection (LlamaMLP.gate_proj / up_proj over the prompt,
+    modeling_llama3.py:197-199): [prompt, 2 * inter, hidden] on the 256 x 256 LDS-DMA kernel. Timed live, graph-replayed."""
+    from spider_amd import ops
+    M, N, K = prompt_len, 2 * cfg.inter, cfg.hidden
+    A = torch.randn(M, K, device=device).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
+    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(A, W, out=out)
+    torch.cuda.synchronize(device)
+    n = 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            ops.gemm(A, W, out=out)
+    g.replay()
+    torch.cuda.synchronize(device)
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    g.replay()
+    e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 2 * M * N * K
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": f"gemm_p8_kernel (LLM prefill gate/up projection, {M} x {N} x {K}, 256 x 256 tiles)",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
+
+
 def measure_attention_roofline(device):
     """The UNet's largest attention: self-attention at the 64x64 latent (4096 tokens, 8 heads, d = 40, CFG batch 2).
     Algorithmic flops = 4 * N^2 * C * B (QK^T + PV, d = 40 as stored -- the kernel pads d to 64 inside its tiles)."""
@@ -699,6 +731,7 @@ def text_image_extras(args, resp, device):
         extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
                                        "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
                                                "not the headline value"}
+    extra["roofline_prefill_gemm"] = measure_prefill_gemm_roofline(device, resp.llm.cfg, a.prompt_len)
     extra["roofline_unet_conv"] = measure_mfma_roofline(device)
     extra["roofline_unet_attention"] = measure_attention_roofline(device)
     extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / 2500.0, 4)
