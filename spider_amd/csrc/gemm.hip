@@ -1033,6 +1033,207 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     write_out<8, 4, EPI, LN>(p, acc, m0 + wr * 128, n0 + wc * 64, split, lane, p.ln_rows, 0);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 128 tiles for the MID-SIZE problems (too few 256^2 tiles to fill the chip, e.g. 4608 x 1280: 90 of them but 180 of these):
+// 8 waves = 4 (M) x 2 (N), wave tile 64 x 64, a K tile = TWO phases of 16 MFMAs ((a, b0) then (a, b1)), a 3-stage ring of K tiles
+// (A rows 0-127 | A rows 128-255 | W: 48 KiB each) filled two K tiles ahead by LDS-DMA -- every share of K tile kt+2 is issued
+// during K tile kt into the stage K tile kt-1 has left, and one vmcnt(6) per K tile retires K tile kt+1 before it is read. The
+// two wave groups (waves 0-3 / 4-7, which share the SIMDs) run half a phase apart as in gemm_p8_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CONV, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
+    constexpr int HT = 128 * 128;                     // bytes of a half-tile (128 rows x 128 B)
+    constexpr int KT_BYTES = 3 * HT;                  // [A-h0 | A-h1 | W]
+    constexpr int NSTG = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;           // 64-row block of the tile, 64-column block
+    const int grp = wave >> 2;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 127) / 128;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = p.n_fast ? bid / tiles_n : bid % tiles_m, tn = p.n_fast ? bid % tiles_n : bid / tiles_m;
+    const int m0 = tm * 256, n0 = tn * 128;
+    const int split = blockIdx.y;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+
+    const int prow = lane >> 3, slot = lane & 7;
+    uint32_t a_base[2][2], a_inv[2][2], a_lin[2][2], w_base[2], w_inv[2], gch[2];
+    int a_oy[2][2], a_ox[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (j * 8 + wave) * 8 + prow;       // row inside the half-tile
+        gch[j] = (uint32_t)(slot ^ ((R >> 1) & 7));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + h * 128 + R;
+            const bool okm = m < p.M;
+            const int mc = okm ? m : 0;
+            a_inv[h][j] = okm ? 0u : 0xFFFFFFFFu;
+            if (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int b = mc / hw, rem = mc % hw;
+                a_oy[h][j] = (rem / p.Wout) * p.stride - p.pad_h;
+                a_ox[h][j] = (rem % p.Wout) * p.stride - p.pad_w;
+                a_base[h][j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
+                a_lin[h][j] = a_base[h][j] + (uint32_t)(a_oy[h][j] * p.Win + a_ox[h][j]) * (uint32_t)p.Cin * 2u;
+            } else {
+                a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
+                a_oy[h][j] = a_ox[h][j] = 0;
+                a_lin[h][j] = 0;
+            }
+        }
+        const int n = n0 + R;
+        const bool okn = n < p.N;
+        w_inv[j] = okn ? 0u : 0xFFFFFFFFu;
+        w_base[j] = okn ? (uint32_t)n * (uint32_t)p.K * 2u + gch[j] * 16u : 0u;
+    }
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
+
+    int run_c = 0, run_ky = 0, run_kx = 0;            // tap state of the next K tile (CONV, Cin % 64 == 0): tiles are issued in order
+    if (CONV && p.cin64) {
+        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
+        run_c = kk0 - tap0 * p.Cin;
+        run_ky = tap0 / p.kw;
+        run_kx = tap0 - run_ky * p.kw;
+    }
+    int t_c = 0, t_ky = 0, t_kx = 0;                  // tap of the K tile currently being issued (set by begin_tile)
+    auto begin_tile = [&]() {
+        t_c = run_c; t_ky = run_ky; t_kx = run_kx;
+        if (CONV && p.cin64) {
+            run_c += BK;
+            if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+        }
+    };
+    // this wave's share (2 DMA instructions) of one half-tile of K tile kt: part 0 / 1 = A rows 0-127 / 128-255, part 2 = W
+    auto issue = [&](int part, int kt, int stg) {
+        char* sb = smem + stg * KT_BYTES + part * HT;
+        const uint32_t kbyte = (uint32_t)kt * (BK * 2);
+        const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)gch[j] * 8)) >> 31) | t_inv;
+            uint32_t off;
+            if (part < 2) {
+                const int h = part;
+                if (CONV) {
+                    int ky, kx;
+                    uint32_t cbyte;
+                    if (p.cin64) {
+                        ky = t_ky; kx = t_kx;
+                        cbyte = (uint32_t)(t_c + (int)gch[j] * 8) * 2u;
+                    } else {
+                        const int kk = kt * BK + (int)gch[j] * 8;
+                        const int tap = kk / p.Cin;
+                        cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
+                        ky = tap / p.kw; kx = tap - ky * p.kw;
+                    }
+                    const int dy = ky * p.dil, dx = kx * p.dil;
+                    const int iy = a_oy[h][j] + dy, ix = a_ox[h][j] + dx;
+                    const uint32_t halo = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31);
+                    uint32_t lin = a_lin[h][j] + (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
+                    if (p.ups) lin = a_base[h][j] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * 2u + cbyte;
+                    off = lin | halo | a_inv[h][j] | k_inv;
+                } else {
+                    off = (a_base[h][j] + kbyte) | a_inv[h][j] | k_inv;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            } else {
+                off = (w_base[j] + kbyte) | w_inv[j] | k_inv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int a_rd = (wr >> 1) * HT + ((wr & 1) * 64 + frow) * 128;       // this wave's 64 A rows inside their half
+    const int w_rd = 2 * HT + (wc * 64 + frow) * 128;                     // its 64 W rows
+    bf16x8 af[2][4], wf[2][2][2];
+    auto read_a = [&](int stg) {
+        const char* sb = smem + stg * KT_BYTES + a_rd;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+    };
+    auto read_w = [&](int stg, int qb) {
+        const char* sb = smem + stg * KT_BYTES + w_rd + qb * 32 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wf[qb][ks][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+    };
+    auto mfmas = [&](int qb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qb][ks][j], af[ks][i], acc[i][qb * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: K tiles kt0 and kt0 + 1 in stages 0 and 1
+    begin_tile(); issue(0, kt0, 0); issue(1, kt0, 0); issue(2, kt0, 0);
+    begin_tile(); issue(0, kt0 + 1, 1); issue(1, kt0 + 1, 1); issue(2, kt0 + 1, 1);
+    wait_vmcnt<6>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs half a phase behind group 0
+
+    int stg = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        int fill = stg + 2;                           // stage of K tile kt + 2 = the stage K tile kt - 1 has left
+        if (fill >= NSTG) fill -= NSTG;
+        // ---- phase 1: (a, b0)
+        read_w(stg, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(stg);
+        __builtin_amdgcn_sched_barrier(0);
+        begin_tile();
+        issue(0, kt + 2, fill);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_end();
+        mfmas(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: (a, b1); K tile kt + 1 must have landed before the barrier that opens group 0's next read slot
+        read_w(stg, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(1, kt + 2, fill);
+        issue(2, kt + 2, fill);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) wait_vmcnt<6>();
+        slot_end();
+        mfmas(1);
+        if (grp == 0) wait_vmcnt<6>();
+        __builtin_amdgcn_s_barrier();
+        if (++stg == NSTG) stg = 0;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // matches group 1's extra barrier at the start
+    wait_vmcnt<0>();
+
+    write_out<4, 4, EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, split, lane);
+}
+
 // {mean, rstd} of every row of A [M, K] (K % 8 == 0): one wave per row, fp32 sums -- the statistics the LN instantiations of
 // gemm_kernel accumulate while staging A (same formulas: var = max(E[x^2] - mean^2, 0)), for the kernel that stages by DMA
 __global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restrict__ A, float2* __restrict__ out, int M, int K, float eps) {
@@ -1154,6 +1355,29 @@ void launch_p8(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+template <bool CONV, int EPI>
+void launch_p8h_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int smem = 3 * 3 * 128 * 128;      // 144 KiB
+    static unsigned done = 0;
+    raise_dynamic_lds(&gemm_p8h_kernel<CONV, EPI>, smem, done);
+    gemm_p8h_kernel<CONV, EPI><<<grid, 512, smem, st>>>(a);
+}
+
+void launch_p8h(const GemmArgs& a, hipStream_t st) {
+    dim3 grid(((a.M + 255) / 256) * ((a.N + 127) / 128), a.splits);
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
+    if (a.conv) {
+        if (epi == 3) launch_p8h_inst<true, 3>(a, grid, st);
+        else if (epi == 1) launch_p8h_inst<true, 1>(a, grid, st);
+        else launch_p8h_inst<true, 0>(a, grid, st);
+    } else {
+        if (epi == 3) launch_p8h_inst<false, 3>(a, grid, st);
+        else if (epi == 1) launch_p8h_inst<false, 1>(a, grid, st);
+        else launch_p8h_inst<false, 0>(a, grid, st);
+    }
+}
+
 template <int BN, int NS, int BM = 128>
 void launch_dma(const GemmArgs& a, int tiles, hipStream_t st) {
     dim3 grid(tiles, a.splits);
@@ -1257,6 +1481,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // pad N (N = 320: 0.625 of the tile area used, 189 -> 235 us) or fewer than ~160 blocks exist (4608 x 1280 x 1280: 29 -> 32).
     static const int p8_env = getenv("SPIDER_GEMM_P8") ? atoi(getenv("SPIDER_GEMM_P8")) : 1;
     bool use_p8 = false;
+    int p8_splits = 1, p8_rounds = 1;
     const bool p8_fused = a.geglu || a.ln_colsum;     // GEGLU / LayerNorm-folded forms: no split-K on this kernel
     const size_t ln_rows_bytes = (size_t)((a.M + 255) / 256) * 256 * sizeof(float2);
     if (p8_env && !force_tile && !force_splits && nk >= 8 && !(a.geglu && a.conv) &&
@@ -1271,9 +1496,27 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
                 if (s < 1) s = 1;
                 while (s > 1 && (size_t)s * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --s;
             }
-            if (t256 * s >= 160) { use_p8 = true; splits = s; dma_bn = 0; }
+            if (t256 * s >= 160) { use_p8 = true; p8_splits = s; p8_rounds = (int)((t256 * s + 255) / 256); }
         }
     }
+    // 256 x 128 tiles (gemm_p8h_kernel) for the linears that leave the 256^2 grid under-filled: measured (us, best other kernel ->
+    // this one) SDXL 24^2 to_out 4608 x 1280 x 1280 28.5 -> 21.9, ff2 74.3 -> 64.2, qkv 66.7 -> 61.5, LLM prefill qkv 71.3 -> 58.8,
+    // o 58.0 -> 48.8; it loses where the 256^2 grid fills its rounds (18432-row SDXL linears, gate/up), on long K that the 256^2
+    // kernel splits (down projection) and on every conv. Cost model: rounds of 256 blocks, a 256 x 128 round = 0.625 of a 256^2 one.
+    bool use_p8h = false;
+    static const int p8h_env = getenv("SPIDER_GEMM_P8H") ? atoi(getenv("SPIDER_GEMM_P8H")) : 1;
+    if (p8_env && p8h_env && !force_tile && !force_splits && !p8_fused && !a.conv && nk >= 5) {
+        const long th = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+        const int rounds_h = (int)((th + 255) / 256);
+        const bool fits = (double)a.M * a.N >= 0.8 * 32768.0 * (double)th && th >= 160 && th <= 768;   // <= 3 rounds: the measured range
+        if (fits) {
+            if (!use_p8) use_p8h = true;
+            else if (p8_splits == 1) use_p8h = 0.625 * rounds_h < (double)p8_rounds;
+            else use_p8h = nk < 128;                 // the 256^2 kernel would split K: worth it only for a long K
+        }
+    }
+    if (use_p8h) { use_p8 = false; splits = 1; dma_bn = 0; }
+    if (use_p8) { splits = p8_splits; dma_bn = 0; }
     if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)
     if (!a.ws || splits < 1 || a.geglu) splits = 1;
     while (splits > 1 && (size_t)splits * a.M * a.N * sizeof(float) > (size_t)ws_bytes) --splits;
@@ -1284,7 +1527,9 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     }
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
-    if (use_p8 || (force_tile == 256 && !a.geglu && !a.ln_colsum)) {
+    if (use_p8h || (force_tile == 257 && !a.geglu && !a.ln_colsum)) {
+        launch_p8h(a, st);
+    } else if (use_p8 || (force_tile == 256 && !a.geglu && !a.ln_colsum)) {
         if (a.ln_colsum) {
             a.ln_rows = reinterpret_cast<const float2*>(a.ws);
             ln_row_stats_kernel<<<(a.M + 3) / 4, 256, 0, st>>>(a.A, reinterpret_cast<float2*>(a.ws), a.M, a.K, a.ln_eps);
