@@ -411,9 +411,12 @@ def test_gemm_256_tile_repeatable_under_load(ops, dev):
     side = torch.cuda.Stream()
     junk = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
     A, W = rnd(4608, 1280, seed=1).to(dev), rnd(3840, 1280, seed=2, scale=0.05).to(dev)
-    A2, W2 = rnd(1536, 3584, seed=3).to(dev), rnd(3584, 3584, seed=4, scale=0.05).to(dev)     # 3 K splits
+    A2, W2 = rnd(1536, 3584, seed=3).to(dev), rnd(3584, 3584, seed=4, scale=0.05).to(dev)     # 256 x 128 tiles (168 of them)
+    W3 = rnd(10240, 1280, seed=7, scale=0.05).to(dev)                                         # 256 x 256 tiles (720)
+    A4, W4 = rnd(1536, 18944, seed=8).to(dev), rnd(3584, 18944, seed=9, scale=0.02).to(dev)   # 256 x 256 tiles, 3 K splits
     x, w = rnd(8, 48, 48, 128, seed=5).to(dev), rnd(640, 3, 3, 128, seed=6, scale=0.03).to(dev)
-    for f in (lambda: ops.gemm(A, W), lambda: ops.gemm(A2, W2), lambda: ops.gemm(A, W, act="geglu"), lambda: ops.conv2d(x, w)):
+    for f in (lambda: ops.gemm(A, W), lambda: ops.gemm(A2, W2), lambda: ops.gemm(A, W3), lambda: ops.gemm(A4, W4),
+              lambda: ops.gemm(A, W, act="geglu"), lambda: ops.conv2d(x, w)):
         ref = f().clone()
         for i in range(40):
             if i % 2 == 0:
