@@ -249,6 +249,66 @@ int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, floa
  * the random per-key keep decision): bit j % 64 of word j / 64 = (u[j] < thr) for j < n_valid, 0 beyond. u [n] fp32 on the device. */
 int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, float thr, void* stream);
 
+/* ======================= IEEE-half (f16) instantiations of the diffusion-side operators =======================
+ * The reference runs its diffusion decoders in torch.float16 (spider_decoder.py:109,114,130,136,153,159; base_model.py:211;
+ * StoryDiffusion/Comic_Generation.py:313). Every operator above that the UNet / VAE / text-encoder engines use also exists with
+ * f16 tensors (raw uint16 IEEE-half bit patterns) in place of bf16: same arguments, same semantics, fp32 accumulation,
+ * mfma_f32_*_f16 at the bf16 rate; outputs beyond +-65504 round to +-inf as torch.float16 does. The LLM decode operators
+ * exist in bf16 only (the reference's LLM dtype). */
+int spider_gemm_f16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
+                     const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
+                     float out_scale, void* ws, long ws_bytes, void* stream);
+int spider_gemm_ln_f16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
+                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream);
+int spider_xattn_fused_f16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
+                            const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
+                            void* stream);
+int spider_conv2d_nhwc_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                            const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
+                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream);
+int spider_conv_nhwc_ex_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
+                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                             float out_scale, void* ws, long ws_bytes, void* stream);
+int spider_attn_f16(const void* q, const void* k, const void* v, void* o,
+                     long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                     long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                     int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
+                     const int* kv_beg, const void* keep_bits, int blk, int q_off, void* stream);
+int spider_attn_keylist_f16(const void* q, const void* k, const void* v, void* o,
+                             long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
+                             long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
+                             int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale,
+                             const int* key_idx, int idx_len, const int* tiles, int n_tiles, void* stream);
+int spider_attn_varlen_f16(const void* q, const void* k, const void* v, void* o, long q_rs, long k_rs, long v_rs, long o_rs,
+                            int total_rows, int Hq, int Hkv, int d, float scale, const int* tiles, int n_tiles, void* stream);
+int spider_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
+                               int C, int G, float eps, int silu, void* stream);
+int spider_groupnorm_cat_nhwc_f16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
+                                   void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream);
+int spider_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                          void* stream);
+int spider_geglu_f16(const void* x, void* y, int M, int inner, void* stream);
+int spider_swiglu_f16(const void* x, void* y, int M, int inner, void* stream);
+int spider_concat_channels_f16(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream);
+int spider_act_f16(const void* x, void* y, long n, int act, void* stream);
+int spider_add_f16(const void* a, const void* b, void* y, long n, void* stream);
+int spider_act_ex_f16(const void* x, void* y, long n, int act, float param, void* stream);
+int spider_add_scaled_f16(const void* a, const void* b, void* y, long n, float scale, void* stream);
+int spider_axpby_f16(const void* a, const void* b, void* y, long n, float alpha, float beta, void* stream);
+int spider_mean_tokens_f16(const void* x, void* y, int B, int T, int C, void* stream);
+int spider_moe_combine_f16(const void* const* host_xs, int E, const void* logits, int ld, void* y, int B, long per_batch,
+                            void* stream);
+int spider_col2im1d_f32_f16(const float* cols, const void* bias, void* y, int B, int L_in, int k, int stride, int pad,
+                             int Cout, void* stream);
+int spider_l2_normalize_rows_f16(const void* x, void* y, int rows, int n, float eps, void* stream);
+int spider_conv2d_small_cin_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+                                 int Cout, int ks, void* stream);
+int spider_conv2d_small_cout_f16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
+                                  int W, int Cin, int Cout, int ks, void* stream);
+int spider_latent_to_nhwc_f16(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream);
+int spider_softmax_rows_f32_f16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,10 +59,11 @@ def _shapes(c: ClapTextConfig) -> dict:
 
 
 class ClapTextEngine:
-    def __init__(self, cfg: ClapTextConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: ClapTextConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+        assert dtype in (torch.bfloat16, torch.float16), "ClapTextEngine: dtype must be bfloat16 or float16"
         self.cfg, self.device = cfg, torch.device(device)
-        self.dtype = BF16
-        g = lambda k: weights[k].to(device=self.device, dtype=BF16).contiguous()
+        self.dtype = dtype
+        g = lambda k: weights[k].to(device=self.device, dtype=dtype).contiguous()
         e = "text_model.embeddings."
         self.tok = g(e + "word_embeddings.weight")
         # position + the single token-type row, added once
@@ -85,7 +86,7 @@ class ClapTextEngine:
         self.p2 = (g("text_projection.linear2.weight"), g("text_projection.linear2.bias"))
 
     @classmethod
-    def random_init(cls, cfg: ClapTextConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: ClapTextConfig, device="cuda:0", seed=0, dtype=BF16):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _shapes(cfg).items():
@@ -96,10 +97,10 @@ class ClapTextEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) * 0.02
             w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
         import glob, json, os
         from safetensors import safe_open
         cfg = ClapTextConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
@@ -108,7 +109,7 @@ class ClapTextEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     def _encode_one(self, ids: torch.Tensor) -> torch.Tensor:
         """ids [n] int32 (no padding) -> pooled+projected embedding [1, proj_dim] bf16."""
@@ -116,7 +117,7 @@ class ClapTextEngine:
         n = ids.shape[0]
         H, d = c.hidden, c.hidden // c.heads
         # RoBERTa position ids of an unpadded sequence: pad_id+1 .. pad_id+n
-        emb = (ops.embed(self.tok, ids[None]).float() + self.pos[c.pad_id + 1: c.pad_id + 1 + n][None]).to(BF16)
+        emb = (ops.embed(self.tok, ids[None]).float() + self.pos[c.pad_id + 1: c.pad_id + 1 + n][None]).to(self.dtype)
         h = ops.layernorm(emb, *self.ln_e, c.eps)
         for lw in self.layers:
             qkv = ops.gemm(h, lw["w_qkv"], bias=lw["b_qkv"])

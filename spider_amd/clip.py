@@ -55,9 +55,10 @@ def _shapes(c: CLIPTextConfig) -> dict:
 
 
 class CLIPTextEngine:
-    def __init__(self, cfg: CLIPTextConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        self.cfg, self.device = cfg, torch.device(device)
-        g = lambda k: weights[k].to(device=self.device, dtype=BF16).contiguous()
+    def __init__(self, cfg: CLIPTextConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+        assert dtype in (torch.bfloat16, torch.float16), "CLIPTextEngine: dtype must be bfloat16 or float16"
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        g = lambda k: weights[k].to(device=self.device, dtype=dtype).contiguous()
         self.tok, self.pos = g("text_model.embeddings.token_embedding.weight"), g("text_model.embeddings.position_embedding.weight")
         self.layers = []
         for l in range(cfg.layers):
@@ -72,7 +73,7 @@ class CLIPTextEngine:
         self.text_projection = g("text_projection.weight") if "text_projection.weight" in weights else None
 
     @classmethod
-    def random_init(cls, cfg: CLIPTextConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: CLIPTextConfig, device="cuda:0", seed=0, dtype=BF16):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _shapes(cfg).items():
@@ -83,10 +84,10 @@ class CLIPTextEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) * 0.02
             w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
         import glob, json, os
         from safetensors import safe_open
         cfg = CLIPTextConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
@@ -95,7 +96,7 @@ class CLIPTextEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @torch.no_grad()
     def encode(self, ids: torch.Tensor, return_all: bool = False, use_graph: bool = True):

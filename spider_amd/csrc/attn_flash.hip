@@ -23,7 +23,7 @@ using namespace spider;
 namespace {
 
 struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    const h16_t* q; const h16_t* k; const h16_t* v; h16_t* o;
     long q_bs, q_hs, q_rs;   // element strides: batch, head, row
     long k_bs, k_hs, k_rs;
     long v_bs, v_hs, v_rs;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two LDS images [K tile | V tile]: tile t+1 is written while tile t is still being read -> one barrier per tile
     constexpr int IMG = 64 * (C::KS + C::VS);
-    bf16_t* const lds0 = reinterpret_cast<bf16_t*>(smem);
+    h16_t* const lds0 = reinterpret_cast<h16_t*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h32 = lane >> 5, l32 = lane & 31;
@@ -101,18 +101,18 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     const int qi = q0 + wave * 32 + l32;  // this lane's query row
     const bool q_ok = qi < lq_end;
 
-    const bf16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
-    const bf16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
-    const bf16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
+    const h16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
+    const h16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
+    const h16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[qi][16*ks + 8*h32 + 0..7] ----
-    bf16x8 qf[DP / 16];
+    h16x8 qf[DP / 16];
 #pragma unroll
     for (int ks = 0; ks < DP / 16; ++ks) {
         const int dd = ks * 16 + h32 * 8;
         u32x4 t = {0u, 0u, 0u, 0u};
         if (q_ok && dd < p.d) t = *reinterpret_cast<const u32x4*>(qb + (long)qi * p.q_rs + dd);
-        qf[ks] = __builtin_bit_cast(bf16x8, t);
+        qf[ks] = __builtin_bit_cast(h16x8, t);
     }
 
     // ---- key range for this query tile ----
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     // Ranges are clamped to 4 GiB - 1; attention operands of this path are far below that.
     const int k_rows = KIDX ? p.Lk : lk_end;       // key-list mode: list entries address any row of the K / V view
     auto span = [&](long rs) { const long b_ = ((long)(k_rows - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
-    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, span(p.k_rs), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, span(p.v_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(kb), 0, span(p.k_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(vb), 0, span(p.v_rs), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(KIDX ? p.key_idx : nullptr), 0,
                                                                             KIDX ? (uint32_t)p.idx_len * 4u : 0u, 0x00020000);
     uint32_t ld_row[C::NCH], ld_cb[C::NCH], ld_inv[C::NCH];
@@ -179,15 +179,15 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     // loads are issued: patched at the load, the wave waited for the V loads at the top of every tile (vmcnt right behind the
     // buffer_load), i.e. their latency sat in front of the QK^T MFMAs instead of behind the whole tile's compute.
     auto store_tile = [&](int buf, int t) {
-        bf16_t* Kd = lds0 + buf * IMG;
-        bf16_t* Vd = Kd + 64 * C::KS;
+        h16_t* Kd = lds0 + buf * IMG;
+        h16_t* Vd = Kd + 64 * C::KS;
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
             const int c = tid + i * 256;
             if (c < 64 * C::CPR) {
                 const int row = c / C::CPR, ch = c % C::CPR;
                 u32x4 vv = rv[i];
-                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u && t * 64 + row < lk_end) ? 0x3F80u : vv.x;
+                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u && t * 64 + row < lk_end) ? H16_ONE : vv.x;
                 *reinterpret_cast<u32x4*>(Kd + row * C::KS + ch * 8) = rk[i];
                 *reinterpret_cast<u32x4*>(Vd + row * C::VS + ch * 8) = vv;
             }
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
-        const bf16_t* Ks = lds0 + cur * IMG;
-        const bf16_t* Vs = Ks + 64 * C::KS;
+        const h16_t* Ks = lds0 + cur * IMG;
+        const h16_t* Vs = Ks + 64 * C::KS;
         if (t + 1 < t_end) {
             load_tile(t + 1);
             if (KIDX) load_idx(t + 2);
@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const bf16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
+            const h16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
 #pragma unroll
             for (int ks = 0; ks < DP / 16; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(krow + ks * 16);
+                s[kt] = mfma_32x32x16_h16(kf, qf[ks], s[kt]);
             }
         }
 
@@ -346,17 +346,17 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
         }
 
         // ---- P^T as the B operand: registers 8s..8s+7 of each half, packed to bf16 ----
-        bf16x8 pf[2][2];
+        h16x8 pf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
                 u32x4 t4;
-                t4.x = pack_bf16x2(s[kt][8 * sx + 0], s[kt][8 * sx + 1]);
-                t4.y = pack_bf16x2(s[kt][8 * sx + 2], s[kt][8 * sx + 3]);
-                t4.z = pack_bf16x2(s[kt][8 * sx + 4], s[kt][8 * sx + 5]);
-                t4.w = pack_bf16x2(s[kt][8 * sx + 6], s[kt][8 * sx + 7]);
-                pf[kt][sx] = __builtin_bit_cast(bf16x8, t4);
+                t4.x = pack_h16x2(s[kt][8 * sx + 0], s[kt][8 * sx + 1]);
+                t4.y = pack_h16x2(s[kt][8 * sx + 2], s[kt][8 * sx + 3]);
+                t4.z = pack_h16x2(s[kt][8 * sx + 4], s[kt][8 * sx + 5]);
+                t4.w = pack_h16x2(s[kt][8 * sx + 6], s[kt][8 * sx + 7]);
+                pf[kt][sx] = __builtin_bit_cast(h16x8, t4);
             }
 
         // ---- O^T += V^T . P^T ; V^T fragments by transposed LDS reads of the row-major V tile ----
@@ -370,13 +370,13 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 for (int sx = 0; sx < 2; ++sx) {
                     const int r0 = kt * 32 + 16 * sx + 4 * h32 + (i16 >> 2);
                     const int c0 = db * 32 + 16 * g16 + 4 * (i16 & 3);
-                    const bf16_t* a0 = Vs + r0 * C::VS + c0;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(a0));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(a0 + 8 * C::VS));
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][sx], acc_o[db], 0, 0, 0);
+                    const h16_t* a0 = Vs + r0 * C::VS + c0;
+                    const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) h16x4*)(a0));
+                    const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) h16x4*)(a0 + 8 * C::VS));
+                    const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc_o[db] = mfma_32x32x16_h16(vf, pf[kt][sx], acc_o[db]);
                 }
         }
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
     }
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        bf16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
+        h16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
 #pragma unroll
         for (int db = 0; db < DP / 32; ++db)
 #pragma unroll
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
                 const int dd = db * 32 + 8 * g + 4 * h32;
                 if (dd < p.d) {
                     u32x2 o2;
-                    o2.x = pack_bf16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
-                    o2.y = pack_bf16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+                    o2.x = pack_h16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
+                    o2.y = pack_h16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
                     *reinterpret_cast<u32x2*>(ob + dd) = o2;
                 }
             }
@@ -425,8 +425,8 @@ template <int DP, bool ONES>
 __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* const Kb = reinterpret_cast<bf16_t*>(smem);                  // 2 x [64][KS]
-    bf16_t* const Vb = Kb + 2 * 64 * C::KS;                              // 2 x [64][VS]
+    h16_t* const Kb = reinterpret_cast<h16_t*>(smem);                  // 2 x [64][KS]
+    h16_t* const Vb = Kb + 2 * 64 * C::KS;                              // 2 x [64][VS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h32 = lane >> 5, l32 = lane & 31;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest), so with the plain
@@ -446,17 +446,17 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     const int q0 = qt * 128, lk_end = p.Lk;
     const int qi = q0 + wave * 32 + l32;
     const bool q_ok = qi < p.Lq;
-    const bf16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
-    const bf16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
-    const bf16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
+    const h16_t* qb = p.q + b * p.q_bs + hq * p.q_hs;
+    const h16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
+    const h16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
 
-    bf16x8 qf[DP / 16];
+    h16x8 qf[DP / 16];
 #pragma unroll
     for (int ks = 0; ks < DP / 16; ++ks) {
         const int dd = ks * 16 + h32 * 8;
         u32x4 t = {0u, 0u, 0u, 0u};
         if (q_ok && dd < p.d) t = *reinterpret_cast<const u32x4*>(qb + (long)qi * p.q_rs + dd);
-        qf[ks] = __builtin_bit_cast(bf16x8, t);
+        qf[ks] = __builtin_bit_cast(h16x8, t);
     }
     const int nt = lk_end / 64;
 
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     float m_run = -1e30f, l_run = 0.f;
 
     auto span = [&](long rs) { const long b_ = ((long)(lk_end - 1) * rs + p.d) * 2; return (uint32_t)(b_ < 0xFFFFFFFFl ? b_ : 0xFFFFFFFFl); };
-    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, span(p.k_rs), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, span(p.v_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(kb), 0, span(p.k_rs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(vb), 0, span(p.v_rs), 0x00020000);
     u32x4 rk[C::NCH], rv[C::NCH];
     uint32_t ld_row[C::NCH], ld_cb[C::NCH], ld_inv[C::NCH];
 #pragma unroll
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
             rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, ((uint32_t)(t * 64 + (int)ld_row[i]) * (uint32_t)p.v_rs * 2u + ld_cb[i]) | ld_inv[i] | tinv, 0, 0));
     };
     auto store_k = [&](int buf) {
-        bf16_t* Kd = Kb + buf * 64 * C::KS;
+        h16_t* Kd = Kb + buf * 64 * C::KS;
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
             const int c = tid + i * 256;
@@ -501,28 +501,28 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
         }
     };
     auto store_v = [&](int buf) {
-        bf16_t* Vd = Vb + buf * 64 * C::VS;
+        h16_t* Vd = Vb + buf * 64 * C::VS;
 #pragma unroll
         for (int i = 0; i < C::NCH; ++i) {
             const int c = tid + i * 256;
             if (c < 64 * C::CPR) {
                 u32x4 vv = rv[i];
-                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u) ? 0x3F80u : vv.x;       // V[key][d] = 1.0 (every key of a whole tile is valid)
+                if (ONES) vv.x = (ld_cb[i] == (uint32_t)p.d * 2u) ? H16_ONE : vv.x;       // V[key][d] = 1.0 (every key of a whole tile is valid)
                 *reinterpret_cast<u32x4*>(Vd + (c / C::CPR) * C::VS + (c % C::CPR) * 8) = vv;
             }
         }
     };
     auto qk = [&](int buf, f32x16 (&s)[2]) {
-        const bf16_t* Ks = Kb + buf * 64 * C::KS;
+        const h16_t* Ks = Kb + buf * 64 * C::KS;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const bf16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
+            const h16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
 #pragma unroll
             for (int ks = 0; ks < DP / 16; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(krow + ks * 16);
+                s[kt] = mfma_32x32x16_h16(kf, qf[ks], s[kt]);
             }
         }
     };
@@ -537,6 +537,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     __syncthreads();
     f32x16 sc[2], sn[2];
     qk(0, sc);
+    // Iteration 0 re-stages K image 0 (store_k(0) -> K(2)) with no barrier of its own in front of it: every wave must have
+    // finished the prologue's reads of K(0) first, or a wave running ahead overwrites rows a stalled sibling still scores against.
+    __syncthreads();
 
     const int g16 = (lane >> 4) & 1, i16 = lane & 15;
     for (int t = 0; t < nt; ++t) {
@@ -575,20 +578,20 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
             psum += partner32(psum);
             l_run = l_run * alpha + psum;
         }
-        bf16x8 pf[2][2];
+        h16x8 pf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx) {
                 u32x4 t4;
-                t4.x = pack_bf16x2(sc[kt][8 * sx + 0], sc[kt][8 * sx + 1]);
-                t4.y = pack_bf16x2(sc[kt][8 * sx + 2], sc[kt][8 * sx + 3]);
-                t4.z = pack_bf16x2(sc[kt][8 * sx + 4], sc[kt][8 * sx + 5]);
-                t4.w = pack_bf16x2(sc[kt][8 * sx + 6], sc[kt][8 * sx + 7]);
-                pf[kt][sx] = __builtin_bit_cast(bf16x8, t4);
+                t4.x = pack_h16x2(sc[kt][8 * sx + 0], sc[kt][8 * sx + 1]);
+                t4.y = pack_h16x2(sc[kt][8 * sx + 2], sc[kt][8 * sx + 3]);
+                t4.z = pack_h16x2(sc[kt][8 * sx + 4], sc[kt][8 * sx + 5]);
+                t4.w = pack_h16x2(sc[kt][8 * sx + 6], sc[kt][8 * sx + 7]);
+                pf[kt][sx] = __builtin_bit_cast(h16x8, t4);
             }
         // ---- [C] O^T += V(t)^T . P^T
-        const bf16_t* Vs = Vb + (t & 1) * 64 * C::VS;
+        const h16_t* Vs = Vb + (t & 1) * 64 * C::VS;
 #pragma unroll
         for (int db = 0; db < DP / 32; ++db) {
 #pragma unroll
@@ -597,11 +600,11 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
                 for (int sx = 0; sx < 2; ++sx) {
                     const int r0 = kt * 32 + 16 * sx + 4 * h32 + (i16 >> 2);
                     const int c0 = db * 32 + 16 * g16 + 4 * (i16 & 3);
-                    const bf16_t* a0 = Vs + r0 * C::VS + c0;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * C::VS));
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][sx], acc_o[db], 0, 0, 0);
+                    const h16_t* a0 = Vs + r0 * C::VS + c0;
+                    const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(a0));
+                    const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(a0 + 8 * C::VS));
+                    const h16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc_o[db] = mfma_32x32x16_h16(vf, pf[kt][sx], acc_o[db]);
                 }
         }
         // ---- stage K(t+2) (its image held K(t), last read in iteration t-1) and V(t+1) (held V(t-1))
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     }
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        bf16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
+        h16_t* ob = p.o + b * p.o_bs + hq * p.o_hs + (long)qi * p.o_rs;
 #pragma unroll
         for (int db = 0; db < DP / 32; ++db)
 #pragma unroll
@@ -631,14 +634,15 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
                 const int dd = db * 32 + 8 * g + 4 * h32;
                 if (dd < p.d) {
                     u32x2 o2;
-                    o2.x = pack_bf16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
-                    o2.y = pack_bf16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+                    o2.x = pack_h16x2(acc_o[db][4 * g + 0] * inv, acc_o[db][4 * g + 1] * inv);
+                    o2.y = pack_h16x2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
                     *reinterpret_cast<u32x2*>(ob + dd) = o2;
                 }
             }
     }
 }
 
+#ifndef SPIDER_F16
 // ------------------------------------------------------------------------------------------------------------------
 // Visible-key lists of the consistent self-attention (cal_attn_mask_xl, gradio_utils.py:241-287, as a list instead of a mask):
 // query image `img0 + list` sees key j iff keep bit j is set or j lies in its own block [img*N, (img+1)*N). One block per list
@@ -685,11 +689,13 @@ __global__ __launch_bounds__(1024) void key_lists_kernel(const unsigned long lon
     }
 }
 
+#endif
+
 template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
     dim3 grid(a.tiles ? a.n_tiles : (a.Lq + 127) / 128, a.Hq, a.B);
-    const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(bf16_t);
+    const size_t smem = (size_t)2 * 64 * (C::KS + C::VS) * sizeof(h16_t);
     static const int xcd_env = [] { const char* e = getenv("SPIDER_ATTN_XCD"); return e ? atoi(e) : 1; }();
     const_cast<AttnArgs&>(a).xcd_order = xcd_env;
     if (a.key_idx) {
@@ -731,7 +737,7 @@ extern "C" {
 //   kv_beg      : optional device int[B]; keys below kv_beg[b] are masked
 //   keep_bits   : optional device uint64[ceil(Lk/64)] column keep vector; a key is visible if its bit is
 //                 set OR it lies in the query's own image block ((i + q_off) / blk == j / blk)
-int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
+int SPIDER_FN(spider_attn)(const void* q, const void* k, const void* v, void* o,
                      long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
                      long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
                      int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale, int causal, int kv_off,
@@ -744,7 +750,7 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
     SPIDER_CHECK(!keep_bits || blk > 0, "attn: keep_bits needs the image block length");
     SPIDER_CHECK((long)Lk * k_rs * 2 < (1L << 32) && (long)Lk * v_rs * 2 < (1L << 32), "attn: one (batch, head) K / V view must span < 4 GiB");
     AttnArgs a{};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q = (const h16_t*)q; a.k = (const h16_t*)k; a.v = (const h16_t*)v; a.o = (h16_t*)o;
     a.q_bs = q_bs; a.q_hs = q_hs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_rs = k_rs;
     a.v_bs = v_bs; a.v_hs = v_hs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_hs = o_hs; a.o_rs = o_rs;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Lq = Lq; a.Lk = Lk; a.d = d;
@@ -761,7 +767,7 @@ int spider_attn_bf16(const void* q, const void* k, const void* v, void* o,
 // blk / q_off -- masked keys contribute exactly zero there and are skipped here -- at the cost of the visible keys only.
 //   key_idx [idx_len] int32, tiles [n_tiles][4] from spider_story_key_lists_i32; q [B, Lq, ...], k / v [B, Lk, ...] strided as in
 //   spider_attn_bf16; head_dim 64 (the SDXL UNet of StoryDiffusion/Comic_Generation.py).
-int spider_attn_keylist_bf16(const void* q, const void* k, const void* v, void* o,
+int SPIDER_FN(spider_attn_keylist)(const void* q, const void* k, const void* v, void* o,
                              long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
                              long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,
                              int B, int Hq, int Hkv, int Lq, int Lk, int d, float scale,
@@ -774,7 +780,7 @@ int spider_attn_keylist_bf16(const void* q, const void* k, const void* v, void* 
     SPIDER_CHECK(q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 4 == 0, "attn_keylist: batch strides must keep 16-byte alignment");
     SPIDER_CHECK((long)Lk * k_rs * 2 < (1L << 32) && (long)Lk * v_rs * 2 < (1L << 32), "attn_keylist: one (batch, head) K / V view must span < 4 GiB");
     AttnArgs a{};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q = (const h16_t*)q; a.k = (const h16_t*)k; a.v = (const h16_t*)v; a.o = (h16_t*)o;
     a.q_bs = q_bs; a.q_hs = q_hs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_rs = k_rs;
     a.v_bs = v_bs; a.v_hs = v_hs; a.v_rs = v_rs; a.o_bs = o_bs; a.o_hs = o_hs; a.o_rs = o_rs;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Lq = Lq; a.Lk = Lk; a.d = d;
@@ -783,6 +789,7 @@ int spider_attn_keylist_bf16(const void* q, const void* k, const void* v, void* 
     return launch<64>(a, stream);
 }
 
+#ifndef SPIDER_F16   // dtype-free: built once (bf16 translation unit)
 // Build the visible-key lists and query-tile records for spider_attn_keylist_bf16. keep_bits: uint64 words over n_keys keys
 // (spider_pack_keep_bits_f32); N = tokens per image; list l serves query image img0 + l, whose rows start at
 // (img0 + l - q_img0) * N in the q tensor (q_img0 = img0 when q holds only those images, 0 when it holds all of them).
@@ -798,20 +805,22 @@ int spider_story_key_lists_i32(const void* keep_bits, int n_keys, int N, int img
     return 0;
 }
 
+#endif
+
 // Packed variable-length attention (no mask tensor): q/k/v/o are [total_rows, heads, d] views with the given row
 // strides (head stride = d); `tiles` is a device int[n_tiles][4] = {q_start, q_len (1..128), k_start, k_len}: the
 // block computes softmax(q[q_start : q_start+q_len] k[k_start : k_start+k_len]^T * scale) v[...]. The host cuts each
 // cu_seqlens segment into <= 128-row query tiles that all see the segment's keys -- the per-segment SDPA loop of
 // transformers' Qwen2_5OmniVisionAttention / Qwen2_5OmniAudioAttention (reached through Qwen2_5OmniModel.generate,
 // qwen2.5omni_spider_web.py:468) without materialising a block-diagonal mask.
-int spider_attn_varlen_bf16(const void* q, const void* k, const void* v, void* o, long q_rs, long k_rs, long v_rs, long o_rs,
+int SPIDER_FN(spider_attn_varlen)(const void* q, const void* k, const void* v, void* o, long q_rs, long k_rs, long v_rs, long o_rs,
                             int total_rows, int Hq, int Hkv, int d, float scale, const int* tiles, int n_tiles, void* stream) {
     SPIDER_CHECK(total_rows > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && n_tiles > 0 && tiles, "attn_varlen: bad shape");
     SPIDER_CHECK(d > 0 && d % 8 == 0 && d <= 160, "attn_varlen: head_dim must be a multiple of 8 and <= 160");
     SPIDER_CHECK(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0, "attn_varlen: row strides must keep 16-byte alignment");
     SPIDER_CHECK((long)total_rows * k_rs * 2 < (1L << 32) && (long)total_rows * v_rs * 2 < (1L << 32), "attn_varlen: K / V views must span < 4 GiB");
     AttnArgs a{};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.q = (const h16_t*)q; a.k = (const h16_t*)k; a.v = (const h16_t*)v; a.o = (h16_t*)o;
     a.q_hs = a.k_hs = a.v_hs = a.o_hs = d;
     a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
     a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Lq = total_rows; a.Lk = total_rows; a.d = d;

@@ -28,12 +28,12 @@ constexpr int LDS_STRIDE = BK;      // elements; 128-byte rows, 16-byte chunks X
 // swizzle every group hits 16 distinct 16-byte slots, and so do the 8-lane groups of the ds_write_b128 stores.
 
 struct GemmArgs {
-    const bf16_t* A;
-    const bf16_t* W;
-    bf16_t* C;
-    const bf16_t* bias;     // [N] or null
-    const bf16_t* res;      // [M, ldc] or null (added after rounding the GEMM result to bf16)
-    const bf16_t* rowbias;  // [M / rows_per_group, N] or null (time-embedding add)
+    const h16_t* A;
+    const h16_t* W;
+    h16_t* C;
+    const h16_t* bias;     // [N] or null
+    const h16_t* res;      // [M, ldc] or null (added after rounding the GEMM result to bf16)
+    const h16_t* rowbias;  // [M / rows_per_group, N] or null (time-embedding add)
     float* C32;             // optional fp32 output instead of bf16
     float* ws;              // split-K workspace [splits, M, N] fp32
     int M, N, K, lda, ldc;
@@ -86,13 +86,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
     if (n + 3 < p.N) {
         if (p.bias) {
             const u32x2 bq = *reinterpret_cast<const u32x2*>(p.bias + n);
-            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
-            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+            v[0] += h16lo_to_f32(bq.x); v[1] += h16hi_to_f32(bq.x);
+            v[2] += h16lo_to_f32(bq.y); v[3] += h16hi_to_f32(bq.y);
         }
         if (p.rowbias) {
             const u32x2 bq = *reinterpret_cast<const u32x2*>(p.rowbias + (size_t)grp * p.N + n);
-            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
-            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+            v[0] += h16lo_to_f32(bq.x); v[1] += h16hi_to_f32(bq.x);
+            v[2] += h16lo_to_f32(bq.y); v[3] += h16hi_to_f32(bq.y);
         }
         if (ACT) {
 #pragma unroll
@@ -100,10 +100,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
         }
         if (p.res) {
             const u32x2 rq = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldc + n);
-            v[0] = bf16_to_f32(f32_to_bf16(v[0])) + bf16lo_to_f32(rq.x);
-            v[1] = bf16_to_f32(f32_to_bf16(v[1])) + bf16hi_to_f32(rq.x);
-            v[2] = bf16_to_f32(f32_to_bf16(v[2])) + bf16lo_to_f32(rq.y);
-            v[3] = bf16_to_f32(f32_to_bf16(v[3])) + bf16hi_to_f32(rq.y);
+            v[0] = h16_to_f32(f32_to_h16(v[0])) + h16lo_to_f32(rq.x);
+            v[1] = h16_to_f32(f32_to_h16(v[1])) + h16hi_to_f32(rq.x);
+            v[2] = h16_to_f32(f32_to_h16(v[2])) + h16lo_to_f32(rq.y);
+            v[3] = h16_to_f32(f32_to_h16(v[3])) + h16hi_to_f32(rq.y);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
@@ -111,20 +111,20 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             *reinterpret_cast<f32x4*>(p.C32 + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
             u32x2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = pack_h16x2(v[0], v[1]);
+            o.y = pack_h16x2(v[2], v[3]);
             *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
         }
     } else {
         for (int e = 0; e < 4 && n + e < p.N; ++e) {
             float t = v[e];
-            if (p.bias) t += bf16_to_f32(p.bias[n + e]);
-            if (p.rowbias) t += bf16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
+            if (p.bias) t += h16_to_f32(p.bias[n + e]);
+            if (p.rowbias) t += h16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
             if (ACT) t = apply_act(p, t);
-            if (p.res) t = bf16_to_f32(f32_to_bf16(t)) + bf16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
+            if (p.res) t = h16_to_f32(f32_to_h16(t)) + h16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
             t *= p.out_scale;
             if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
-            else p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(t);
+            else p.C[(size_t)m * p.ldc + n + e] = f32_to_h16(t);
         }
     }
 }
@@ -140,9 +140,9 @@ struct EpiRsrc {
 
 __device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemmArgs& p) {
     EpiRsrc r;
-    r.bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
-    r.rowbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.rowbias), 0, p.rowbias ? (int)p.rb_bytes : 0, 0x00020000);
-    r.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, p.res ? (int)p.c_bytes : 0, 0x00020000);
+    r.bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
+    r.rowbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.rowbias), 0, p.rowbias ? (int)p.rb_bytes : 0, 0x00020000);
+    r.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.res), 0, p.res ? (int)p.c_bytes : 0, 0x00020000);
     r.c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
     return r;
 }
@@ -155,11 +155,11 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
     // operand presence is uniform (scalar branches); a missing operand costs nothing, a present one is one 8-byte load
     if (p.bias) {
         const u32x2 bq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.bias, noff, 0, 0));
-        v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x); v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+        v[0] += h16lo_to_f32(bq.x); v[1] += h16hi_to_f32(bq.x); v[2] += h16lo_to_f32(bq.y); v[3] += h16hi_to_f32(bq.y);
     }
     if (p.rowbias) {
         const u32x2 rb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.rowbias, (rb_row_byte + (uint32_t)n * 2u) | inv, 0, 0));
-        v[0] += bf16lo_to_f32(rb.x); v[1] += bf16hi_to_f32(rb.x); v[2] += bf16lo_to_f32(rb.y); v[3] += bf16hi_to_f32(rb.y);
+        v[0] += h16lo_to_f32(rb.x); v[1] += h16hi_to_f32(rb.x); v[2] += h16lo_to_f32(rb.y); v[3] += h16hi_to_f32(rb.y);
     }
     if (ACT) {
 #pragma unroll
@@ -167,14 +167,14 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
     }
     if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
         const u32x2 rq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.res, off, 0, 0));
-        v[0] = bf16_to_f32(f32_to_bf16(v[0])) + bf16lo_to_f32(rq.x); v[1] = bf16_to_f32(f32_to_bf16(v[1])) + bf16hi_to_f32(rq.x);
-        v[2] = bf16_to_f32(f32_to_bf16(v[2])) + bf16lo_to_f32(rq.y); v[3] = bf16_to_f32(f32_to_bf16(v[3])) + bf16hi_to_f32(rq.y);
+        v[0] = h16_to_f32(f32_to_h16(v[0])) + h16lo_to_f32(rq.x); v[1] = h16_to_f32(f32_to_h16(v[1])) + h16hi_to_f32(rq.x);
+        v[2] = h16_to_f32(f32_to_h16(v[2])) + h16lo_to_f32(rq.y); v[3] = h16_to_f32(f32_to_h16(v[3])) + h16hi_to_f32(rq.y);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
     u32x2 o;
-    o.x = pack_bf16x2(v[0], v[1]);
-    o.y = pack_bf16x2(v[2], v[3]);
+    o.x = pack_h16x2(v[0], v[1]);
+    o.y = pack_h16x2(v[2], v[3]);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
 }
 
@@ -185,8 +185,8 @@ __device__ __forceinline__ void epilogue_fast8(const GemmArgs& p, const EpiRsrc&
     const uint32_t off = (((uint32_t)m * (uint32_t)p.ldc + (uint32_t)n) * 2u) | inv;
     const uint32_t noff = ((uint32_t)n * 2u) | inv;
     auto add8 = [&](const u32x4 q) {
-        v[0] += bf16lo_to_f32(q.x); v[1] += bf16hi_to_f32(q.x); v[2] += bf16lo_to_f32(q.y); v[3] += bf16hi_to_f32(q.y);
-        v[4] += bf16lo_to_f32(q.z); v[5] += bf16hi_to_f32(q.z); v[6] += bf16lo_to_f32(q.w); v[7] += bf16hi_to_f32(q.w);
+        v[0] += h16lo_to_f32(q.x); v[1] += h16hi_to_f32(q.x); v[2] += h16lo_to_f32(q.y); v[3] += h16hi_to_f32(q.y);
+        v[4] += h16lo_to_f32(q.z); v[5] += h16hi_to_f32(q.z); v[6] += h16lo_to_f32(q.w); v[7] += h16hi_to_f32(q.w);
     };
     if (p.bias) add8(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.bias, noff, 0, 0)));
     if (p.rowbias) add8(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rowbias, (rb_row_byte + (uint32_t)n * 2u) | inv, 0, 0)));
@@ -197,13 +197,13 @@ __device__ __forceinline__ void epilogue_fast8(const GemmArgs& p, const EpiRsrc&
     if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
         const u32x4 rq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res, off, 0, 0));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e]));
+        for (int e = 0; e < 8; ++e) v[e] = h16_to_f32(f32_to_h16(v[e]));
         add8(rq);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
     u32x4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    o.x = pack_h16x2(v[0], v[1]); o.y = pack_h16x2(v[2], v[3]); o.z = pack_h16x2(v[4], v[5]); o.w = pack_h16x2(v[6], v[7]);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
 }
 
@@ -311,7 +311,7 @@ template <int BM, int BN, bool CONV, int EPI, bool LN = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool GEGLU = EPI == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+    h16_t* lds = reinterpret_cast<h16_t*>(smem);
     constexpr int TILE_ELEMS = (BM + BN) * LDS_STRIDE;  // [A tile BM rows | W tile BN rows]
     constexpr int MT = BM / 32, NT = BN / 32;           // 16x16 MFMA tiles per wave (wave sub-tile BM/2 x BN/2)
     constexpr int AC = BM / 32, WC = BN / 32;           // 16-byte chunks per thread per K tile
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // Operands are read through buffer descriptors: an out-of-range offset returns 0 in hardware, so M/N/K tails and
     // the conv halo need no branches. (With predicated loads the compiler lost track of the outstanding-load count and
     // drained the whole prefetch ring with s_waitcnt vmcnt(0) before every LDS store.)
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.W), 0, p.w_bytes, 0x00020000);
     // Validity is carried as all-ones / zero masks OR-ed into the offset (pure ALU): a select would be turned into a
     // divergent branch by the compiler, which again hides the loads from its vmcnt bookkeeping.
     uint32_t a_base[AC], a_inv[AC];   // byte offset of the row (linear) / image (conv); a_inv = ~0 for rows >= M
@@ -443,13 +443,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < AC; ++i) ln_s[i] = ln_q[i] = 0.f;
     auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
-        bf16_t* base = lds + buf * TILE_ELEMS;
+        h16_t* base = lds + buf * TILE_ELEMS;
         if (LN) {   // every K tile passes through here exactly once (masked tiles are zeros)
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const float lo = bf16lo_to_f32(ra[i][d]), hi = bf16hi_to_f32(ra[i][d]);
+                    const float lo = h16lo_to_f32(ra[i][d]), hi = h16hi_to_f32(ra[i][d]);
                     ln_s[i] += lo + hi;
                     ln_q[i] = fmaf(lo, lo, fmaf(hi, hi, ln_q[i]));
                 }
@@ -471,21 +471,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;   // fragment rows are frow + 16*i: same swizzle
     auto compute = [&](int buf) {
-        const bf16_t* abase = lds + buf * TILE_ELEMS + (wm * (BM / 2) + frow) * LDS_STRIDE;
-        const bf16_t* wbase = lds + buf * TILE_ELEMS + (BM + wn * (BN / 2) + frow) * LDS_STRIDE;
+        const h16_t* abase = lds + buf * TILE_ELEMS + (wm * (BM / 2) + frow) * LDS_STRIDE;
+        const h16_t* wbase = lds + buf * TILE_ELEMS + (BM + wn * (BN / 2) + frow) * LDS_STRIDE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + fg) ^ fswz) * 8;
-            bf16x8 af[MT], wf[NT];
+            h16x8 af[MT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abase + i * 16 * LDS_STRIDE + coff);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const h16x8*>(abase + i * 16 * LDS_STRIDE + coff);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wbase + j * 16 * LDS_STRIDE + coff);
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const h16x8*>(wbase + j * 16 * LDS_STRIDE + coff);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_16x16x32_h16(wf[j], af[i], acc[i][j]);
         }
     };
 
@@ -549,18 +549,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                             const float2 ms = ln_stat[m - m0];
                             v = ms.y * (v - ms.x * p.ln_colsum[ne]) + p.ln_bias[ne];
                             g = ms.y * (g - ms.x * p.ln_colsum[p.N + ne]) + p.ln_bias[p.N + ne];
-                        } else if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
-                        v = bf16_to_f32(f32_to_bf16(v));
-                        g = bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16_to_f32(f32_to_bf16(g)))));
+                        } else if (p.bias) { v += h16_to_f32(p.bias[ne]); g += h16_to_f32(p.bias[p.N + ne]); }
+                        v = h16_to_f32(f32_to_h16(v));
+                        g = h16_to_f32(f32_to_h16(gelu_erf_f(h16_to_f32(f32_to_h16(g)))));
                         r[e] = v * g;
                     }
                     if (n + 3 < p.N) {
                         u32x2 o;
-                        o.x = pack_bf16x2(r[0], r[1]);
-                        o.y = pack_bf16x2(r[2], r[3]);
+                        o.x = pack_h16x2(r[0], r[1]);
+                        o.y = pack_h16x2(r[2], r[3]);
                         *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
                     } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(r[e]);
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_h16(r[e]);
                     }
                 }
             }
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
 
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.W), 0, p.w_bytes, 0x00020000);
 
     // this lane's slot in a piece: row prow of 8, 16-byte slot `slot` of 8; the global chunk it fetches is slot ^ swizzle(row)
     const int prow = lane >> 3, slot = lane & 7;
@@ -724,21 +724,21 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
 
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
     const int a_rd = (wm * (BM / 4) + frow) * 128, w_rd = (BM + wn * (BN / 2) + frow) * 128;
-    bf16x8 af[MT], wf[NT];
+    h16x8 af[MT], wf[NT];
     auto read_frags = [&](int stage, int ks) {
         const char* sb = smem + stage * STAGE;
         const int coff = ((ks * 4 + fg) ^ fswz) * 16;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_rd + i * 16 * 128 + coff);
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const h16x8*>(sb + a_rd + i * 16 * 128 + coff);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_rd + j * 16 * 128 + coff);
+        for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const h16x8*>(sb + w_rd + j * 16 * 128 + coff);
     };
     auto mfmas = [&]() {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma_16x16x32_h16(wf[j], af[i], acc[i][j]);
     };
 
     // pieces per tile issued by this wave (vmcnt bookkeeping)
@@ -802,8 +802,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int m0 = tm * 256, n0 = tn * 256;
     const int split = blockIdx.y;
 
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.W), 0, p.w_bytes, 0x00020000);
 
     // a DMA piece = 8 rows x 128 B (one wave instruction); a half-tile = 16 pieces, this wave issues pieces wave and 8 + wave
     const int prow = lane >> 3, slot = lane & 7;
@@ -912,14 +912,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
     const int a_rd = (0 * 2 + wr) * HT + frow * 128;                                  // this wave's A half
     const int w_rd = (1 * 2 + (wc >> 1)) * HT + ((wc & 1) * 64 + frow) * 128;         // its 64 W rows inside their half
-    bf16x8 af[2][4], wf[2][2][2];          // A sub-block [ks][i]; W sub-blocks b0 / b1 [ks][j]
+    h16x8 af[2][4], wf[2][2][2];          // A sub-block [ks][i]; W sub-blocks b0 / b1 [ks][j]
     auto read_a = [&](int buf, int qa) {
         const char* sb = smem + buf * KT_BYTES + a_rd + qa * 64 * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+                af[ks][i] = *reinterpret_cast<const h16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
     };
     auto read_w = [&](int buf, int qb) {
         const char* sb = smem + buf * KT_BYTES + w_rd + qb * 32 * 128;
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                wf[qb][ks][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+                wf[qb][ks][j] = *reinterpret_cast<const h16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
     };
     auto mfmas = [&](int qa, int qb) {
         __builtin_amdgcn_s_setprio(1);
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qb][ks][j], af[ks][i], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+                    acc[qa * 4 + i][qb * 2 + j] = mfma_16x16x32_h16(wf[qb][ks][j], af[ks][i], acc[qa * 4 + i][qb * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto slot_end = [&]() {                 // fragment reads retired (their region may be re-staged from the next phase on), then the barrier
@@ -1012,18 +1012,18 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                         if (LN) {
                             v = ms.y * (v - ms.x * p.ln_colsum[ne]) + p.ln_bias[ne];
                             g = ms.y * (g - ms.x * p.ln_colsum[p.N + ne]) + p.ln_bias[p.N + ne];
-                        } else if (p.bias) { v += bf16_to_f32(p.bias[ne]); g += bf16_to_f32(p.bias[p.N + ne]); }
-                        v = bf16_to_f32(f32_to_bf16(v));
-                        g = bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16_to_f32(f32_to_bf16(g)))));
+                        } else if (p.bias) { v += h16_to_f32(p.bias[ne]); g += h16_to_f32(p.bias[p.N + ne]); }
+                        v = h16_to_f32(f32_to_h16(v));
+                        g = h16_to_f32(f32_to_h16(gelu_erf_f(h16_to_f32(f32_to_h16(g)))));
                         r[e] = v * g;
                     }
                     if (n + 3 < p.N) {
                         u32x2 o;
-                        o.x = pack_bf16x2(r[0], r[1]);
-                        o.y = pack_bf16x2(r[2], r[3]);
+                        o.x = pack_h16x2(r[0], r[1]);
+                        o.y = pack_h16x2(r[2], r[3]);
                         *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
                     } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_bf16(r[e]);
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) p.C[(size_t)m * p.ldc + n + e] = f32_to_h16(r[e]);
                     }
                 }
             }
@@ -1058,8 +1058,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
     const int m0 = tm * 256, n0 = tn * 128;
     const int split = blockIdx.y;
 
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.W), 0, p.w_bytes, 0x00020000);
 
     const int prow = lane >> 3, slot = lane & 7;
     uint32_t a_base[2][2], a_inv[2][2], a_lin[2][2], w_base[2], w_inv[2], gch[2];
@@ -1160,14 +1160,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
     const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
     const int a_rd = (wr >> 1) * HT + ((wr & 1) * 64 + frow) * 128;       // this wave's 64 A rows inside their half
     const int w_rd = 2 * HT + (wc * 64 + frow) * 128;                     // its 64 W rows
-    bf16x8 af[2][4], wf[2][2][2];
+    h16x8 af[2][4], wf[2][2][2];
     auto read_a = [&](int stg) {
         const char* sb = smem + stg * KT_BYTES + a_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+                af[ks][i] = *reinterpret_cast<const h16x8*>(sb + i * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
     };
     auto read_w = [&](int stg, int qb) {
         const char* sb = smem + stg * KT_BYTES + w_rd + qb * 32 * 128;
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                wf[qb][ks][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
+                wf[qb][ks][j] = *reinterpret_cast<const h16x8*>(sb + j * 16 * 128 + (((ks * 4 + fg) ^ fswz) * 16));
     };
     auto mfmas = [&](int qb) {
         __builtin_amdgcn_s_setprio(1);
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[qb][ks][j], af[ks][i], acc[i][qb * 2 + j], 0, 0, 0);
+                    acc[i][qb * 2 + j] = mfma_16x16x32_h16(wf[qb][ks][j], af[ks][i], acc[i][qb * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto slot_end = [&]() {
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
 
 // {mean, rstd} of every row of A [M, K] (K % 8 == 0): one wave per row, fp32 sums -- the statistics the LN instantiations of
 // gemm_kernel accumulate while staging A (same formulas: var = max(E[x^2] - mean^2, 0)), for the kernel that stages by DMA
-__global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restrict__ A, float2* __restrict__ out, int M, int K, float eps) {
+__global__ __launch_bounds__(256) void ln_row_stats_kernel(const h16_t* __restrict__ A, float2* __restrict__ out, int M, int K, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const u32x4* a = reinterpret_cast<const u32x4*>(A + (size_t)row * K);
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restr
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const float lo = bf16lo_to_f32(w[d]), hi = bf16hi_to_f32(w[d]);
+            const float lo = h16lo_to_f32(w[d]), hi = h16hi_to_f32(w[d]);
             s_ += lo + hi;
             q_ = fmaf(lo, lo, fmaf(hi, hi, q_));
         }
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
 
 template <int BM, int BN>
 void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
-    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(bf16_t);
+    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
     dim3 grid(tiles, a.splits);
     // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
@@ -1563,7 +1563,7 @@ extern "C" {
 
 // C = act(A[M,K] . W[N,K]^T + bias + rowbias[row / rows_per_group]) (+ res) , * out_scale
 // ldc applies to C, C32 and res. ws/ws_bytes: optional fp32 split-K workspace (NULL disables split-K).
-int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
+int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
                      float out_scale, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
@@ -1574,8 +1574,8 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
     SPIDER_CHECK(act >= 0 && act <= 7, "gemm: unknown activation");
     SPIDER_CHECK(act != 4 || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU epilogue needs bf16 output, even N, no res/rowbias");
     GemmArgs a{};
-    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.C32 = (float*)C32;
-    a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
+    a.A = (const h16_t*)A; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.C32 = (float*)C32;
+    a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = rows_per_group; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc;
     a.geglu = act == 4;
     a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU output has N/2 columns
@@ -1594,7 +1594,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
 // (fp32) are prepared once per layer by the caller; the kernel computes the row statistics of A on the fly and applies
 // C = rstd * (A.Wf^T - mean * colsum) + colbias in its epilogue. Replaces BasicTransformerBlock.norm1/2/3 + the projection
 // that consumes it (diffusers-0.25 attention.py; call site custom_sd.py:634-639). lda must equal K (whole rows are normalised).
-int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
+int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
                         int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm_ln: empty problem");
     SPIDER_CHECK(K % 8 == 0, "gemm_ln: K must be a multiple of 8 (16-byte rows)");
@@ -1602,8 +1602,8 @@ int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* col
     SPIDER_CHECK(colsum && colbias && C, "gemm_ln: colsum, colbias and C are required");
     SPIDER_CHECK(act != 4 || (!res && N % 2 == 0), "gemm_ln: GEGLU epilogue needs even N and no residual");
     GemmArgs a{};
-    a.A = (const bf16_t*)A; a.W = (const bf16_t*)Wf; a.C = (bf16_t*)C; a.C32 = nullptr;
-    a.bias = nullptr; a.res = (const bf16_t*)res; a.rowbias = nullptr; a.rows_per_group = 0;
+    a.A = (const h16_t*)A; a.W = (const h16_t*)Wf; a.C = (h16_t*)C; a.C32 = nullptr;
+    a.bias = nullptr; a.res = (const h16_t*)res; a.rowbias = nullptr; a.rows_per_group = 0;
     a.M = M; a.K = K; a.lda = K; a.ldc = ldc;
     a.geglu = act == 4;
     a.N = a.geglu ? N / 2 : N;
@@ -1623,7 +1623,7 @@ int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* col
 // up_h x up_w (Upsample2D with an explicit output size, then the conv). 1-D convs are Hin = kh = 1; the
 // (3,1,1) temporal conv of UNet3D is Hin = frames, Win = H*W, kh = 3, kw = 1.
 // rowbias [B, Cout] is the per-image time-embedding add of ResnetBlock2D; res is [B,Hout,Wout,Cout].
-int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
                              float out_scale, void* ws, long ws_bytes, void* stream) {
@@ -1646,8 +1646,8 @@ int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* 
     const int Hout = (Hs + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wout = (Ws + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
     SPIDER_CHECK(Hout > 0 && Wout > 0, "conv: kernel larger than the padded input");
     GemmArgs a{};
-    a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.C = (bf16_t*)y; a.C32 = nullptr;
-    a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.rowbias = (const bf16_t*)rowbias;
+    a.A = (const h16_t*)x; a.W = (const h16_t*)w; a.C = (h16_t*)y; a.C32 = nullptr;
+    a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = Hout * Wout; a.M = B * Hout * Wout; a.N = Cout; a.K = kh * kw * Cin; a.lda = Cin; a.ldc = Cout;
     a.act = act; a.act_param = act_param; a.out_scale = out_scale; a.ws = (float*)ws;
     a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.kh = kh; a.kw = kw; a.stride = stride;
@@ -1661,12 +1661,12 @@ int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* 
 
 // Square-kernel form used by the SD / SDXL UNet and the VAE (ResnetBlock2D convs, Down/Upsample2D, shortcuts).
 // ups=1 fuses the exact nearest-2x upsample.
-int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
+int SPIDER_FN(spider_conv2d_nhwc)(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
                             int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
     SPIDER_CHECK(Cin % 64 == 0, "conv2d: Cin must be a multiple of 64 for the MFMA path (use conv2d_small)");
-    return spider_conv_nhwc_ex_bf16(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, ks, ks, stride, pad, pad, 1,
+    return SPIDER_FN(spider_conv_nhwc_ex)(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, ks, ks, stride, pad, pad, 1,
                                     ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, ws, ws_bytes, stream);
 }
 

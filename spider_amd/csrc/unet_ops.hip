@@ -20,8 +20,8 @@ namespace {
 // Skip-concat form (x2 != nullptr): the input is the channel concatenation [x | x2] (UpBlock2D's cat([hidden, skip])) with
 // C1 channels in x; the kernel reads the two sources in place and writes the concatenated tensor to `cat` on the way (the
 // shortcut conv and pass 2 read it) -- the separate concat launch and its read pass are gone.
-__global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
-                                int nchunk, int KP, const bf16_t* __restrict__ x2, int C1, bf16_t* __restrict__ cat) {
+__global__ void gn_stats_kernel(const h16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
+                                int nchunk, int KP, const h16_t* __restrict__ x2, int C1, h16_t* __restrict__ cat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sm_s = reinterpret_cast<float*>(smem);   // [KP][C]
     float* sm_q = sm_s + KP * C;                    // [KP][C]
@@ -36,7 +36,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
     // this thread's 8-channel vector comes from x (row stride ld = C or C1) or, past C1, from x2 (row stride C - C1)
     const bool second = x2 != nullptr && v * 8 >= C1;
     const int ld = second ? C - C1 : (x2 ? C1 : C);
-    const bf16_t* xb = (second ? x2 + (size_t)b * HW * ld + (v * 8 - C1) : x + (size_t)b * HW * ld + v * 8);
+    const h16_t* xb = (second ? x2 + (size_t)b * HW * ld + (v * 8 - C1) : x + (size_t)b * HW * ld + v * 8);
     // 4 independent 16-byte loads in flight per thread (a runtime-trip loop with one load per iteration would
     // serialise the L2/HBM round trips)
     for (int px = p0 + pl; px < p1; px += 4 * KP) {
@@ -58,7 +58,7 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
             const uint32_t aw[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+                const float lo = h16lo_to_f32(aw[j]), hi = h16hi_to_f32(aw[j]);
                 s[2 * j] += lo; q[2 * j] += lo * lo;
                 s[2 * j + 1] += hi; q[2 * j + 1] += hi * hi;
             }
@@ -90,9 +90,9 @@ __global__ void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict_
 // GroupNorm, pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU; output bf16.
 // Rounds once after the affine (as torch's GroupNorm does) and once more after SiLU.
 template <bool SILU>
-__global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ partial,
-                                const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                                bf16_t* __restrict__ y, int HW, int C, int G, int nchunk,
+__global__ void gn_apply_kernel(const h16_t* __restrict__ x, const float* __restrict__ partial,
+                                const h16_t* __restrict__ gamma, const h16_t* __restrict__ beta,
+                                h16_t* __restrict__ y, int HW, int C, int G, int nchunk,
                                 float eps, int pix_per_block, int KP) {
     // Block = (C/8)*KP threads like pass 1: a thread owns one 8-channel vector for all its pixels, so the per-channel
     // scale a_c = rstd_g * gamma_c and shift b_c = beta_c - mean_g * a_c live in 16 registers and the inner loop is one fma
@@ -143,16 +143,16 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int g = (v * 8 + j) / cpg;
-            const float ga = (j & 1) ? bf16hi_to_f32(gw[j >> 1]) : bf16lo_to_f32(gw[j >> 1]);
-            const float be = (j & 1) ? bf16hi_to_f32(bw[j >> 1]) : bf16lo_to_f32(bw[j >> 1]);
+            const float ga = (j & 1) ? h16hi_to_f32(gw[j >> 1]) : h16lo_to_f32(gw[j >> 1]);
+            const float be = (j & 1) ? h16hi_to_f32(bw[j >> 1]) : h16lo_to_f32(bw[j >> 1]);
             ca[j] = rstd[g] * ga;
             cb[j] = be - mean[g] * ca[j];
         }
     }
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(HW, p0 + pix_per_block);
-    const bf16_t* xb = x + (size_t)b * HW * C + v * 8;
-    bf16_t* yb = y + (size_t)b * HW * C + v * 8;
+    const h16_t* xb = x + (size_t)b * HW * C + v * 8;
+    h16_t* yb = y + (size_t)b * HW * C + v * 8;
     for (int px = p0 + pl; px < p1; px += 4 * KP) {
         u32x4 a[4];
 #pragma unroll
@@ -168,14 +168,14 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xv = (j & 1) ? bf16hi_to_f32(aw[j >> 1]) : bf16lo_to_f32(aw[j >> 1]);
+                const float xv = (j & 1) ? h16hi_to_f32(aw[j >> 1]) : h16lo_to_f32(aw[j >> 1]);
                 float t = fmaf(xv, ca[j], cb[j]);
-                if (SILU) t = silu_f(bf16_to_f32(f32_to_bf16(t)));
+                if (SILU) t = silu_f(h16_to_f32(f32_to_h16(t)));
                 o[j] = t;
             }
             u32x4 ov;
-            ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
-            ov.z = pack_bf16x2(o[4], o[5]); ov.w = pack_bf16x2(o[6], o[7]);
+            ov.x = pack_h16x2(o[0], o[1]); ov.y = pack_h16x2(o[2], o[3]);
+            ov.z = pack_h16x2(o[4], o[5]); ov.w = pack_h16x2(o[6], o[7]);
             *reinterpret_cast<u32x4*>(yb + (size_t)pp * C) = ov;
         }
     }
@@ -185,21 +185,21 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
 // (HW x cpg values, 4-byte pairs, L2-resident) is read twice by the same block. Replaces the stats + apply pair
 // whose two launches dominate at 16x16 / 8x8 latents.
 template <int MAXP, bool SILU>
-__global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
-                                                       const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C,
-                                                       int G, float eps, const bf16_t* __restrict__ x2, int C1,
-                                                       bf16_t* __restrict__ cat) {
+__global__ __launch_bounds__(256) void gn_small_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gamma,
+                                                       const h16_t* __restrict__ beta, h16_t* __restrict__ y, int HW, int C,
+                                                       int G, float eps, const h16_t* __restrict__ x2, int C1,
+                                                       h16_t* __restrict__ cat) {
     __shared__ float red[4];
     // MAXP channel pairs per thread: HW * cpg / 2 <= 256 * MAXP (host-checked)
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = C / G, hp = cpg / 2;          // channel pairs per group
     const int n = HW * hp;
-    const bf16_t* xb = x + (size_t)b * HW * C + g * cpg;
-    bf16_t* yb = y + (size_t)b * HW * C + g * cpg;
+    const h16_t* xb = x + (size_t)b * HW * C + g * cpg;
+    h16_t* yb = y + (size_t)b * HW * C + g * cpg;
     // skip-concat form (see gn_stats_kernel): channel c < C1 from x (row stride C1), else from x2 (row stride C - C1)
-    const bf16_t* x1b = x + (size_t)b * HW * C1;
-    const bf16_t* x2b = x2 ? x2 + (size_t)b * HW * (C - C1) : nullptr;
-    bf16_t* catb = cat ? cat + (size_t)b * HW * C + g * cpg : nullptr;
+    const h16_t* x1b = x + (size_t)b * HW * C1;
+    const h16_t* x2b = x2 ? x2 + (size_t)b * HW * (C - C1) : nullptr;
+    h16_t* catb = cat ? cat + (size_t)b * HW * C + g * cpg : nullptr;
     // the group's data is read ONCE into registers (all loads independent and in flight together)
     uint32_t v[MAXP];
     int off[MAXP];          // element offset of the pair inside the batch image; the pair's channel offset 2*cp rides in bits 24..31
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
         off[u] = o | (cp << 25);
         if (x2) {
             const int c = g * cpg + 2 * cp;
-            const bf16_t* src = c < C1 ? x1b + (size_t)px * C1 + c : x2b + (size_t)px * (C - C1) + (c - C1);
+            const h16_t* src = c < C1 ? x1b + (size_t)px * C1 + c : x2b + (size_t)px * (C - C1) + (c - C1);
             v[u] = i < n ? *reinterpret_cast<const uint32_t*>(src) : 0u;
             if (catb && i < n) *reinterpret_cast<uint32_t*>(catb + o) = v[u];
         } else {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
-        const float lo = bf16lo_to_f32(v[u]), hi = bf16hi_to_f32(v[u]);   // padding entries are zeros
+        const float lo = h16lo_to_f32(v[u]), hi = h16hi_to_f32(v[u]);   // padding entries are zeros
         s += lo + hi;
         q += lo * lo + hi * hi;
     }
@@ -241,13 +241,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
             const int cp2 = (int)((unsigned)off[u] >> 25) * 2, o = off[u] & 0x1FFFFFF;     // channel offset inside the group, element offset
             const uint32_t gv = *reinterpret_cast<const uint32_t*>(gamma + g * cpg + cp2);
             const uint32_t bv = *reinterpret_cast<const uint32_t*>(beta + g * cpg + cp2);
-            float lo = (bf16lo_to_f32(v[u]) - mu) * rs * bf16lo_to_f32(gv) + bf16lo_to_f32(bv);
-            float hi = (bf16hi_to_f32(v[u]) - mu) * rs * bf16hi_to_f32(gv) + bf16hi_to_f32(bv);
+            float lo = (h16lo_to_f32(v[u]) - mu) * rs * h16lo_to_f32(gv) + h16lo_to_f32(bv);
+            float hi = (h16hi_to_f32(v[u]) - mu) * rs * h16hi_to_f32(gv) + h16hi_to_f32(bv);
             if (SILU) {
-                lo = silu_f(bf16_to_f32(f32_to_bf16(lo)));
-                hi = silu_f(bf16_to_f32(f32_to_bf16(hi)));
+                lo = silu_f(h16_to_f32(f32_to_h16(lo)));
+                hi = silu_f(h16_to_f32(f32_to_h16(hi)));
             }
-            *reinterpret_cast<uint32_t*>(yb + o) = pack_bf16x2(lo, hi);
+            *reinterpret_cast<uint32_t*>(yb + o) = pack_h16x2(lo, hi);
         }
     }
 }
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (C <= 8192, multiple of 8), affine, fp32 statistics (two-pass in registers).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
-                                                        const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int C,
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gamma,
+                                                        const h16_t* __restrict__ beta, h16_t* __restrict__ y, int C,
                                                         float eps) {
     __shared__ float red[4];
     const size_t row = blockIdx.x;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[it][2 * j] = bf16lo_to_f32(aw[j]);
-                h[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                h[it][2 * j] = h16lo_to_f32(aw[j]);
+                h[it][2 * j + 1] = h16hi_to_f32(aw[j]);
                 s += h[it][2 * j] + h[it][2 * j + 1];
             }
         }
@@ -299,9 +299,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float lo = (h[it][2 * j] - mu) * rs * bf16lo_to_f32(gw[j]) + bf16lo_to_f32(bw[j]);
-                const float hi = (h[it][2 * j + 1] - mu) * rs * bf16hi_to_f32(gw[j]) + bf16hi_to_f32(bw[j]);
-                o[j] = pack_bf16x2(lo, hi);
+                const float lo = (h[it][2 * j] - mu) * rs * h16lo_to_f32(gw[j]) + h16lo_to_f32(bw[j]);
+                const float hi = (h[it][2 * j + 1] - mu) * rs * h16hi_to_f32(gw[j]) + h16hi_to_f32(bw[j]);
+                o[j] = pack_h16x2(lo, hi);
             }
             u32x4 ov;
             ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // LayerNorm, one WAVE per row (C <= 2048): no LDS, no barriers; 4 rows per block. A 256-thread block per row leaves
 // most lanes idle at C = 320 (40 vectors).
 template <int VPL>
-__global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma,
-                                                             const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ gamma,
+                                                             const h16_t* __restrict__ beta, h16_t* __restrict__ y,
                                                              int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
             const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[it][2 * j] = bf16lo_to_f32(aw[j]);
-                h[it][2 * j + 1] = bf16hi_to_f32(aw[j]);
+                h[it][2 * j] = h16lo_to_f32(aw[j]);
+                h[it][2 * j + 1] = h16hi_to_f32(aw[j]);
                 s += h[it][2 * j] + h[it][2 * j + 1];
             }
         }
@@ -361,17 +361,17 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
         if (i < nv) {
             const uint32_t gw[4] = {gq[it].x, gq[it].y, gq[it].z, gq[it].w}, bw[4] = {bq[it].x, bq[it].y, bq[it].z, bq[it].w};
             u32x4 ov;
-            ov.x = pack_bf16x2((h[it][0] - mu) * rs * bf16lo_to_f32(gw[0]) + bf16lo_to_f32(bw[0]), (h[it][1] - mu) * rs * bf16hi_to_f32(gw[0]) + bf16hi_to_f32(bw[0]));
-            ov.y = pack_bf16x2((h[it][2] - mu) * rs * bf16lo_to_f32(gw[1]) + bf16lo_to_f32(bw[1]), (h[it][3] - mu) * rs * bf16hi_to_f32(gw[1]) + bf16hi_to_f32(bw[1]));
-            ov.z = pack_bf16x2((h[it][4] - mu) * rs * bf16lo_to_f32(gw[2]) + bf16lo_to_f32(bw[2]), (h[it][5] - mu) * rs * bf16hi_to_f32(gw[2]) + bf16hi_to_f32(bw[2]));
-            ov.w = pack_bf16x2((h[it][6] - mu) * rs * bf16lo_to_f32(gw[3]) + bf16lo_to_f32(bw[3]), (h[it][7] - mu) * rs * bf16hi_to_f32(gw[3]) + bf16hi_to_f32(bw[3]));
+            ov.x = pack_h16x2((h[it][0] - mu) * rs * h16lo_to_f32(gw[0]) + h16lo_to_f32(bw[0]), (h[it][1] - mu) * rs * h16hi_to_f32(gw[0]) + h16hi_to_f32(bw[0]));
+            ov.y = pack_h16x2((h[it][2] - mu) * rs * h16lo_to_f32(gw[1]) + h16lo_to_f32(bw[1]), (h[it][3] - mu) * rs * h16hi_to_f32(gw[1]) + h16hi_to_f32(bw[1]));
+            ov.z = pack_h16x2((h[it][4] - mu) * rs * h16lo_to_f32(gw[2]) + h16lo_to_f32(bw[2]), (h[it][5] - mu) * rs * h16hi_to_f32(gw[2]) + h16hi_to_f32(bw[2]));
+            ov.w = pack_h16x2((h[it][6] - mu) * rs * h16lo_to_f32(gw[3]) + h16lo_to_f32(bw[3]), (h[it][7] - mu) * rs * h16hi_to_f32(gw[3]) + h16hi_to_f32(bw[3]));
             *reinterpret_cast<u32x4*>(y + (size_t)row * C + i * 8) = ov;
         }
     }
 }
 
 // GEGLU: y[m, n] = bf16( x[m, n] * bf16(gelu(x[m, inner + n])) ), x [M, 2*inner]
-__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t total_vec,
+__global__ __launch_bounds__(256) void geglu_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, size_t total_vec,
                                                     int inner) {
     const int iv = inner / 8;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (size_t)gridDim.x * 256) {
@@ -383,9 +383,9 @@ __global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = bf16lo_to_f32(aw[j]) * bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16lo_to_f32(gw[j]))));
-            const float hi = bf16hi_to_f32(aw[j]) * bf16_to_f32(f32_to_bf16(gelu_erf_f(bf16hi_to_f32(gw[j]))));
-            o[j] = pack_bf16x2(lo, hi);
+            const float lo = h16lo_to_f32(aw[j]) * h16_to_f32(f32_to_h16(gelu_erf_f(h16lo_to_f32(gw[j]))));
+            const float hi = h16hi_to_f32(aw[j]) * h16_to_f32(f32_to_h16(gelu_erf_f(h16hi_to_f32(gw[j]))));
+            o[j] = pack_h16x2(lo, hi);
         }
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x
 
 // SwiGLU on a fused [gate | up] projection: y[m, n] = bf16( bf16(silu(x[m, n])) * x[m, inner + n] )
 // (prefill form of modeling_llama3.py:197-199; the decode form is fused into gemv_swiglu)
-__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t total_vec,
+__global__ __launch_bounds__(256) void swiglu_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, size_t total_vec,
                                                      int inner) {
     const int iv = inner / 8;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (size_t)gridDim.x * 256) {
@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = bf16_to_f32(f32_to_bf16(silu_f(bf16lo_to_f32(gw[j])))) * bf16lo_to_f32(uw[j]);
-            const float hi = bf16_to_f32(f32_to_bf16(silu_f(bf16hi_to_f32(gw[j])))) * bf16hi_to_f32(uw[j]);
-            o[j] = pack_bf16x2(lo, hi);
+            const float lo = h16_to_f32(f32_to_h16(silu_f(h16lo_to_f32(gw[j])))) * h16lo_to_f32(uw[j]);
+            const float hi = h16_to_f32(f32_to_h16(silu_f(h16hi_to_f32(gw[j])))) * h16hi_to_f32(uw[j]);
+            o[j] = pack_h16x2(lo, hi);
         }
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
 }
 
 // channel concat of two NHWC tensors: y[r, :C1] = a[r], y[r, C1:] = b[r]
-__global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                     bf16_t* __restrict__ y, size_t rows, int C1, int C2) {
+__global__ __launch_bounds__(256) void concat_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b,
+                                                     h16_t* __restrict__ y, size_t rows, int C1, int C2) {
     const int cv = (C1 + C2) / 8, c1v = C1 / 8;
     const size_t total = rows * cv;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ 
 }
 
 // elementwise unary on bf16 (act: 1 silu, 2 gelu, 3 quick-gelu, 5 leaky-relu(param), 6 relu, 7 tanh), n multiple of 8
-__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t nvec, int act,
+__global__ __launch_bounds__(256) void act_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, size_t nvec, int act,
                                                   float param) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(x + idx * 8);
@@ -440,14 +440,14 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
+            float lo = h16lo_to_f32(aw[j]), hi = h16hi_to_f32(aw[j]);
             if (act == 1) { lo = silu_f(lo); hi = silu_f(hi); }
             else if (act == 2) { lo = gelu_erf_f(lo); hi = gelu_erf_f(hi); }
             else if (act == 3) { lo = quick_gelu_f(lo); hi = quick_gelu_f(hi); }
             else if (act == 5) { lo = lo > 0.f ? lo : lo * param; hi = hi > 0.f ? hi : hi * param; }
             else if (act == 6) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
             else if (act == 7) { lo = tanhf(lo); hi = tanhf(hi); }
-            o[j] = pack_bf16x2(lo, hi);
+            o[j] = pack_h16x2(lo, hi);
         }
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
 }
 
 // y = bf16((a + b) * scale) elementwise
-__global__ __launch_bounds__(256) void add_scaled_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                         bf16_t* __restrict__ y, size_t nvec, float scale) {
+__global__ __launch_bounds__(256) void add_scaled_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b,
+                                                         h16_t* __restrict__ y, size_t nvec, float scale) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
         const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
         const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(const bf16_t* __restric
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2((bf16lo_to_f32(pw[j]) + bf16lo_to_f32(qw[j])) * scale, (bf16hi_to_f32(pw[j]) + bf16hi_to_f32(qw[j])) * scale);
+            o[j] = pack_h16x2((h16lo_to_f32(pw[j]) + h16lo_to_f32(qw[j])) * scale, (h16hi_to_f32(pw[j]) + h16hi_to_f32(qw[j])) * scale);
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(const bf16_t* __restric
 }
 
 // y = bf16(alpha * a + beta * b) elementwise
-__global__ __launch_bounds__(256) void axpby_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                    bf16_t* __restrict__ y, size_t nvec, float alpha, float beta) {
+__global__ __launch_bounds__(256) void axpby_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b,
+                                                    h16_t* __restrict__ y, size_t nvec, float alpha, float beta) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
         const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
         const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256) void axpby_kernel(const bf16_t* __restrict__ a
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(alpha * bf16lo_to_f32(pw[j]) + beta * bf16lo_to_f32(qw[j]),
-                               alpha * bf16hi_to_f32(pw[j]) + beta * bf16hi_to_f32(qw[j]));
+            o[j] = pack_h16x2(alpha * h16lo_to_f32(pw[j]) + beta * h16lo_to_f32(qw[j]),
+                               alpha * h16hi_to_f32(pw[j]) + beta * h16hi_to_f32(qw[j]));
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
@@ -491,41 +491,41 @@ __global__ __launch_bounds__(256) void axpby_kernel(const bf16_t* __restrict__ a
 }
 
 // y[b, c] = mean over t of x[b, t, c]   (TextFcLayerMoE router input, layers.py:254)
-__global__ __launch_bounds__(256) void mean_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int T, int C) {
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, int B, int T, int C) {
     const size_t total = (size_t)B * C;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int c = (int)(idx % C);
         const size_t b = idx / C;
         float s = 0.f;
-        for (int t = 0; t < T; ++t) s += bf16_to_f32(x[(b * T + t) * C + c]);
-        y[idx] = f32_to_bf16(s / (float)T);
+        for (int t = 0; t < T; ++t) s += h16_to_f32(x[(b * T + t) * C + c]);
+        y[idx] = f32_to_h16(s / (float)T);
     }
 }
 
 // TextFcLayerMoE mixing (layers.py:255-267): r = sigmoid(logits[b, :]) / sum, out[b, t, :] = sum_e r[e] * x_e[b, t, :]
 struct MoeCombine {
-    const bf16_t* x[8];
+    const h16_t* x[8];
     int E;
 };
-__global__ __launch_bounds__(256) void moe_combine_kernel(MoeCombine mc, const bf16_t* __restrict__ logits, int ld, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void moe_combine_kernel(MoeCombine mc, const h16_t* __restrict__ logits, int ld, h16_t* __restrict__ y,
                                                           int B, size_t per_batch) {
     const size_t total = (size_t)B * per_batch;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const size_t b = idx / per_batch;
         float r[8], rs = 0.f;
         for (int e = 0; e < mc.E; ++e) {
-            r[e] = 1.f / (1.f + __expf(-bf16_to_f32(logits[b * ld + e])));
+            r[e] = 1.f / (1.f + __expf(-h16_to_f32(logits[b * ld + e])));
             rs += r[e];
         }
         float acc = 0.f;
-        for (int e = 0; e < mc.E; ++e) acc += bf16_to_f32(f32_to_bf16(bf16_to_f32(mc.x[e][idx]) * bf16_to_f32(f32_to_bf16(r[e] / rs))));
-        y[idx] = f32_to_bf16(acc);
+        for (int e = 0; e < mc.E; ++e) acc += h16_to_f32(f32_to_h16(h16_to_f32(mc.x[e][idx]) * h16_to_f32(f32_to_h16(r[e] / rs))));
+        y[idx] = f32_to_h16(acc);
     }
 }
 
 // ConvTranspose1d overlap-add (see spider_col2im1d_f32_bf16): one thread per (b, t, 4 output channels)
-__global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__ cols, const bf16_t* __restrict__ bias,
-                                                       bf16_t* __restrict__ y, int B, int L_in, int L_out, int k, int stride,
+__global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__ cols, const h16_t* __restrict__ bias,
+                                                       h16_t* __restrict__ y, int B, int L_in, int L_out, int k, int stride,
                                                        int pad, int Cout) {
     const int c4 = Cout / 4;
     const size_t total = (size_t)B * L_out * c4;
@@ -543,30 +543,30 @@ __global__ __launch_bounds__(256) void col2im1d_kernel(const float* __restrict__
         }
         if (bias) {
             const u32x2 bq = *reinterpret_cast<const u32x2*>(bias + cq * 4);
-            v[0] += bf16lo_to_f32(bq.x); v[1] += bf16hi_to_f32(bq.x);
-            v[2] += bf16lo_to_f32(bq.y); v[3] += bf16hi_to_f32(bq.y);
+            v[0] += h16lo_to_f32(bq.x); v[1] += h16hi_to_f32(bq.x);
+            v[2] += h16lo_to_f32(bq.y); v[3] += h16hi_to_f32(bq.y);
         }
         u32x2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
+        o.x = pack_h16x2(v[0], v[1]);
+        o.y = pack_h16x2(v[2], v[3]);
         *reinterpret_cast<u32x2*>(y + (((size_t)b * L_out + t) * Cout) + cq * 4) = o;
     }
 }
 
 // row-wise L2 normalisation, one block per row
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int n, float eps) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const h16_t* __restrict__ x, h16_t* __restrict__ y, int n, float eps) {
     __shared__ float red[4];
-    const bf16_t* xr = x + (size_t)blockIdx.x * n;
-    bf16_t* yr = y + (size_t)blockIdx.x * n;
+    const h16_t* xr = x + (size_t)blockIdx.x * n;
+    h16_t* yr = y + (size_t)blockIdx.x * n;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float v = bf16_to_f32(xr[i]); ss += v * v; }
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = h16_to_f32(xr[i]); ss += v * v; }
     const float inv = 1.f / fmaxf(sqrtf(block_sum<4>(ss, red)), eps);
-    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_bf16(bf16_to_f32(xr[i]) * inv);
+    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_h16(h16_to_f32(xr[i]) * inv);
 }
 
 // y = bf16(a + b) elementwise
-__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                                  bf16_t* __restrict__ y, size_t nvec) {
+__global__ __launch_bounds__(256) void add_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b,
+                                                  h16_t* __restrict__ y, size_t nvec) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
         const u32x4 p = *reinterpret_cast<const u32x4*>(a + idx * 8);
         const u32x4 q = *reinterpret_cast<const u32x4*>(b + idx * 8);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(bf16lo_to_f32(pw[j]) + bf16lo_to_f32(qw[j]), bf16hi_to_f32(pw[j]) + bf16hi_to_f32(qw[j]));
+            o[j] = pack_h16x2(h16lo_to_f32(pw[j]) + h16lo_to_f32(qw[j]), h16hi_to_f32(pw[j]) + h16hi_to_f32(qw[j]));
         u32x4 ov;
         ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
         *reinterpret_cast<u32x4*>(y + idx * 8) = ov;
@@ -585,13 +585,13 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
 // Small convolutions that do not fit the MFMA tile (Cin = 4 conv_in, Cout = 3/4 conv_out).
 // ------------------------------------------------------------------------------------------
 // Cin <= 8: one thread per (pixel, 8 output channels). w [Cout, ks, ks, Cin] staged in LDS as fp32.
-__global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                             const h16_t* __restrict__ bias, h16_t* __restrict__ y,
                                                              int B, int H, int W, int Cin, int Cout, int ks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = reinterpret_cast<float*>(smem);
     const int kk = ks * ks * Cin;
-    for (int i = threadIdx.x; i < Cout * kk; i += 256) ws[(i % kk) * Cout + i / kk] = bf16_to_f32(w[i]);
+    for (int i = threadIdx.x; i < Cout * kk; i += 256) ws[(i % kk) * Cout + i / kk] = h16_to_f32(w[i]);
     __syncthreads();
     const int cov = Cout / 8;
     const size_t total = (size_t)B * H * W * cov;
@@ -602,16 +602,16 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __res
         const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
         float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias ? bf16_to_f32(bias[v * 8 + j]) : 0.f;
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? h16_to_f32(bias[v * 8 + j]) : 0.f;
         for (int ky = 0; ky < ks; ++ky) {
             const int iy = oy + ky - pad;
             if (iy < 0 || iy >= H) continue;
             for (int kx = 0; kx < ks; ++kx) {
                 const int ix = ox + kx - pad;
                 if (ix < 0 || ix >= W) continue;
-                const bf16_t* src = x + (((size_t)b * H + iy) * W + ix) * Cin;
+                const h16_t* src = x + (((size_t)b * H + iy) * W + ix) * Cin;
                 for (int c = 0; c < Cin; ++c) {
-                    const float xv = bf16_to_f32(src[c]);
+                    const float xv = h16_to_f32(src[c]);
                     const float* wk = ws + ((ky * ks + kx) * Cin + c) * Cout + v * 8;
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
                     acc[0] += xv * w0[0]; acc[1] += xv * w0[1]; acc[2] += xv * w0[2]; acc[3] += xv * w0[3];
@@ -620,20 +620,20 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __res
             }
         }
         u32x4 ov;
-        ov.x = pack_bf16x2(acc[0], acc[1]); ov.y = pack_bf16x2(acc[2], acc[3]);
-        ov.z = pack_bf16x2(acc[4], acc[5]); ov.w = pack_bf16x2(acc[6], acc[7]);
+        ov.x = pack_h16x2(acc[0], acc[1]); ov.y = pack_h16x2(acc[2], acc[3]);
+        ov.z = pack_h16x2(acc[4], acc[5]); ov.w = pack_h16x2(acc[6], acc[7]);
         *reinterpret_cast<u32x4*>(y + pix * Cout + v * 8) = ov;
     }
 }
 
 // Cout <= 4: one wave per output pixel, lanes split K = ks*ks*Cin (Cin % 8 == 0), shuffle reduce.
 // Output fp32 [B, H, W, Cout] (conv_out feeds the scheduler / image, keep full precision) or bf16.
-__global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                              const bf16_t* __restrict__ bias, float* __restrict__ y32,
-                                                              bf16_t* __restrict__ y16, int B, int H, int W, int Cin,
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
+                                                              const h16_t* __restrict__ bias, float* __restrict__ y32,
+                                                              h16_t* __restrict__ y16, int B, int H, int W, int Cin,
                                                               int Cout, int ks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* ws = reinterpret_cast<bf16_t*>(smem);  // [Cout][ks*ks*Cin]
+    h16_t* ws = reinterpret_cast<h16_t*>(smem);  // [Cout][ks*ks*Cin]
     const int kk = ks * ks * Cin;
     for (int i = threadIdx.x; i < Cout * kk / 8; i += 256)
         reinterpret_cast<u32x4*>(ws)[i] = reinterpret_cast<const u32x4*>(w)[i];
@@ -658,17 +658,17 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __re
                     const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[co] += bf16lo_to_f32(aw[j]) * bf16lo_to_f32(ww[j]) + bf16hi_to_f32(aw[j]) * bf16hi_to_f32(ww[j]);
+                        acc[co] += h16lo_to_f32(aw[j]) * h16lo_to_f32(ww[j]) + h16hi_to_f32(aw[j]) * h16hi_to_f32(ww[j]);
                 }
             }
         }
 #pragma unroll
         for (int co = 0; co < 8; ++co) {
             if (co < Cout) {
-                const float t = wave_sum(acc[co]) + (bias ? bf16_to_f32(bias[co]) : 0.f);
+                const float t = wave_sum(acc[co]) + (bias ? h16_to_f32(bias[co]) : 0.f);
                 if (lane == 0) {
                     if (y32) y32[pix * Cout + co] = t;
-                    else y16[pix * Cout + co] = f32_to_bf16(t);
+                    else y16[pix * Cout + co] = f32_to_h16(t);
                 }
             }
         }
@@ -681,14 +681,14 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __re
 // accumulate bf16 rounding) and are converted to bf16 NHWC only as UNet input.
 // ------------------------------------------------------------------------------------------
 // out[rep, b, y, x, c] = bf16(lat[b, c, y, x] * scale) for rep < reps   (torch.cat([latents]*2) + scale_model_input)
-__global__ __launch_bounds__(256) void latent_in_kernel(const float* __restrict__ lat, bf16_t* __restrict__ out, int B, int C,
+__global__ __launch_bounds__(256) void latent_in_kernel(const float* __restrict__ lat, h16_t* __restrict__ out, int B, int C,
                                                         int HW, int reps, float scale) {
     const size_t total = (size_t)B * C * HW;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int c = (int)(idx % C);
         const size_t px = (idx / C) % HW;
         const size_t b = idx / ((size_t)C * HW);
-        const bf16_t v = f32_to_bf16(lat[(b * C + c) * HW + px] * scale);
+        const h16_t v = f32_to_h16(lat[(b * C + c) * HW + px] * scale);
         for (int r = 0; r < reps; ++r) out[(size_t)r * total + idx] = v;
     }
 }
@@ -737,11 +737,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 // Row softmax: y[r, :] = bf16(softmax(scale * x[r, :])), x fp32 [rows, n] (scores of the VAE's single-head
 // d=512 attention, diffusers AttnProcessor on AutoencoderKL.mid_block.attentions.0). One block per row.
 // Columns n_valid..n-1 (row padding up to the 8-element granularity of the next GEMM) are written as zeros.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int ld, int n,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, h16_t* __restrict__ y, int ld, int n,
                                                            float scale) {
     __shared__ float red[4];
     const float* xr = x + (size_t)blockIdx.x * ld;
-    bf16_t* yr = y + (size_t)blockIdx.x * ld;
+    h16_t* yr = y + (size_t)blockIdx.x * ld;
     float m = -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, xr[i]);
     m = wave_max(m);
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += __expf(xr[i] * scale - m);
     const float inv = 1.f / block_sum<4>(s, red);
-    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_bf16(__expf(xr[i] * scale - m) * inv);
+    for (int i = threadIdx.x; i < n; i += 256) yr[i] = f32_to_h16(__expf(xr[i] * scale - m) * inv);
     for (int i = n + threadIdx.x; i < ld; i += 256) yr[i] = 0;
 }
 
@@ -762,6 +762,7 @@ inline int grid_for(size_t n) {
 
 }  // namespace
 
+#ifndef SPIDER_F16   // dtype-free: built once (bf16 translation unit)
 // StoryDiffusion keep vector -> bit words (cal_attn_mask_xl reduced to its information content, gradio_utils.py:241-287):
 // bit j of word w = (u[64 w + j] < thr) && (64 w + j < n_valid). One ballot per wave: no host round trip per UNet step.
 __global__ __launch_bounds__(256) void pack_keep_kernel(const float* __restrict__ u, unsigned long long* __restrict__ words, int n,
@@ -771,13 +772,18 @@ __global__ __launch_bounds__(256) void pack_keep_kernel(const float* __restrict_
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && idx < ((n + 63) / 64) * 64) words[idx >> 6] = m;
 }
+#endif
 
-extern "C" {
-
-int spider_groupnorm_nchunk(int HW) {
+static int gn_nchunk(int HW) {
     int n = HW / 32;
     return n < 1 ? 1 : (n > 128 ? 128 : n);
 }
+
+extern "C" {
+
+#ifndef SPIDER_F16
+int spider_groupnorm_nchunk(int HW) { return gn_nchunk(HW); }
+#endif
 
 // GroupNorm of the channel concatenation [x1 | x2] (UpBlock2D / UpBlock3D: cat([hidden, skip]) -> ResnetBlock.norm1) without a
 // concat launch: x1 [B, HW, C1], x2 [B, HW, C2] are read in place, y [B, HW, C1 + C2] is the normalised result and `cat`
@@ -790,137 +796,137 @@ static int groupnorm_impl(const void* x, const void* x2, const void* gamma, cons
     if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
         // (measured: a 40-pair variant for 20K-element groups is no faster than the stats + apply pair -- 64 blocks cannot
         // pull enough bandwidth)
-        if (silu) gn_small_kernel<20, true><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
-                                                                                        (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps,
-                                                                                        (const bf16_t*)x2, C1, (bf16_t*)cat);
-        else gn_small_kernel<20, false><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma,
-                                                                                     (const bf16_t*)beta, (bf16_t*)y, HW, C, G, eps,
-                                                                                     (const bf16_t*)x2, C1, (bf16_t*)cat);
+        if (silu) gn_small_kernel<20, true><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)gamma,
+                                                                                        (const h16_t*)beta, (h16_t*)y, HW, C, G, eps,
+                                                                                        (const h16_t*)x2, C1, (h16_t*)cat);
+        else gn_small_kernel<20, false><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)gamma,
+                                                                                     (const h16_t*)beta, (h16_t*)y, HW, C, G, eps,
+                                                                                     (const h16_t*)x2, C1, (h16_t*)cat);
         SPIDER_LAUNCH_OK();
         return 0;
     }
-    const int nchunk = spider_groupnorm_nchunk(HW);
+    const int nchunk = gn_nchunk(HW);
     const int cv = C / 8;
     int KP = 256 / cv;
     if (KP < 1) KP = 1;
     const int threads = cv * KP;
     SPIDER_CHECK(threads <= 1024, "groupnorm: C too large");
     dim3 g1(nchunk, B);
-    gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (float*)ws, HW, C,
-                                                                                       G, nchunk, KP, (const bf16_t*)x2, C1, (bf16_t*)cat);
+    gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const h16_t*)x, (float*)ws, HW, C,
+                                                                                       G, nchunk, KP, (const h16_t*)x2, C1, (h16_t*)cat);
     SPIDER_LAUNCH_OK();
     if (x2) x = cat;              // pass 2 reads the concatenated copy pass 1 has just written
     int ppb = 4 * KP;             // one round of 4 independent 16-byte loads per thread
     while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;   // keep the grid at <= ~4 blocks per CU
     SPIDER_CHECK(threads >= 128 || threads >= 2 * G, "groupnorm: too few channels for the block layout");
     dim3 g2((HW + ppb - 1) / ppb, B);
-    if (silu) gn_apply_kernel<true><<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
-                                                                       (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
-    else gn_apply_kernel<false><<<g2, threads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const float*)ws, (const bf16_t*)gamma,
-                                                                    (const bf16_t*)beta, (bf16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    if (silu) gn_apply_kernel<true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x, (const float*)ws, (const h16_t*)gamma,
+                                                                       (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    else gn_apply_kernel<false><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x, (const float*)ws, (const h16_t*)gamma,
+                                                                    (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
 // x, y [B, HW, C] bf16 (NHWC); ws >= B * nchunk * G * 2 floats, nchunk = spider_groupnorm_nchunk(HW)
-int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
+int SPIDER_FN(spider_groupnorm_nhwc)(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
                                int C, int G, float eps, int silu, void* stream) {
     return groupnorm_impl(x, nullptr, gamma, beta, y, nullptr, ws, B, HW, C, 0, G, eps, silu, stream);
 }
 
-int spider_groupnorm_cat_nhwc_bf16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
+int SPIDER_FN(spider_groupnorm_cat_nhwc)(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
                                    void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream) {
     SPIDER_CHECK(x2 && cat && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "groupnorm_cat: two sources with channels % 8 == 0");
     return groupnorm_impl(x1, x2, gamma, beta, y, cat, ws, B, HW, C1, C2, G, eps, silu, stream);
 }
 
-int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+int SPIDER_FN(spider_layernorm)(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                           void* stream) {
     SPIDER_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 8192, "layernorm: C must be a multiple of 8 and <= 8192");
     if (C <= 2048) {
         const int vpl = (C / 8 + 63) / 64, grid = (rows + 3) / 4;
-#define LNW(V_) layernorm_wave_kernel<V_><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, \
-                                                                                (const bf16_t*)beta, (bf16_t*)y, rows, C, eps)
+#define LNW(V_) layernorm_wave_kernel<V_><<<grid, 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)gamma, \
+                                                                                (const h16_t*)beta, (h16_t*)y, rows, C, eps)
         if (vpl == 1) LNW(1); else if (vpl == 2) LNW(2); else if (vpl == 3) LNW(3); else LNW(4);
 #undef LNW
         SPIDER_LAUNCH_OK();
         return 0;
     }
-    layernorm_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta,
-                                                           (bf16_t*)y, C, eps);
+    layernorm_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)gamma, (const h16_t*)beta,
+                                                           (h16_t*)y, C, eps);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_geglu_bf16(const void* x, void* y, int M, int inner, void* stream) {
+int SPIDER_FN(spider_geglu)(const void* x, void* y, int M, int inner, void* stream) {
     SPIDER_CHECK(M > 0 && inner > 0 && inner % 8 == 0, "geglu: inner must be a multiple of 8");
     const size_t nvec = (size_t)M * (inner / 8);
-    geglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, nvec, inner);
+    geglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (h16_t*)y, nvec, inner);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_swiglu_bf16(const void* x, void* y, int M, int inner, void* stream) {
+int SPIDER_FN(spider_swiglu)(const void* x, void* y, int M, int inner, void* stream) {
     SPIDER_CHECK(M > 0 && inner > 0 && inner % 8 == 0, "swiglu: inner must be a multiple of 8");
     const size_t nvec = (size_t)M * (inner / 8);
-    swiglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, nvec, inner);
+    swiglu_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (h16_t*)y, nvec, inner);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_concat_channels_bf16(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream) {
+int SPIDER_FN(spider_concat_channels)(const void* a, const void* b, void* y, long rows, int C1, int C2, void* stream) {
     SPIDER_CHECK(rows > 0 && C1 > 0 && C2 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "concat: channels must be multiples of 8");
     const size_t nvec = (size_t)rows * ((C1 + C2) / 8);
-    concat_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+    concat_kernel<<<grid_for(nvec), 256, 0, (hipStream_t)stream>>>((const h16_t*)a, (const h16_t*)b, (h16_t*)y,
                                                                   (size_t)rows, C1, C2);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_act_ex_bf16(const void* x, void* y, long n, int act, float param, void* stream) {
+int SPIDER_FN(spider_act_ex)(const void* x, void* y, long n, int act, float param, void* stream) {
     SPIDER_CHECK(n > 0 && n % 8 == 0, "act: n must be a multiple of 8");
     SPIDER_CHECK(act == 1 || act == 2 || act == 3 || act == 5 || act == 6 || act == 7, "act: unknown activation");
-    act_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, (size_t)n / 8, act, param);
+    act_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (h16_t*)y, (size_t)n / 8, act, param);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_act_bf16(const void* x, void* y, long n, int act, void* stream) {
+int SPIDER_FN(spider_act)(const void* x, void* y, long n, int act, void* stream) {
     SPIDER_CHECK(act >= 1 && act <= 3, "act: act in 1..3 (spider_act_ex_bf16 has the parameterised forms)");
-    return spider_act_ex_bf16(x, y, n, act, 0.f, stream);
+    return SPIDER_FN(spider_act_ex)(x, y, n, act, 0.f, stream);
 }
 
-int spider_add_scaled_bf16(const void* a, const void* b, void* y, long n, float scale, void* stream) {
+int SPIDER_FN(spider_add_scaled)(const void* a, const void* b, void* y, long n, float scale, void* stream) {
     SPIDER_CHECK(n > 0 && n % 8 == 0, "add_scaled: n must be a multiple of 8");
-    add_scaled_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+    add_scaled_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const h16_t*)a, (const h16_t*)b, (h16_t*)y,
                                                                                (size_t)n / 8, scale);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_axpby_bf16(const void* a, const void* b, void* y, long n, float alpha, float beta, void* stream) {
+int SPIDER_FN(spider_axpby)(const void* a, const void* b, void* y, long n, float alpha, float beta, void* stream) {
     SPIDER_CHECK(n > 0 && n % 8 == 0, "axpby: n must be a multiple of 8");
-    axpby_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+    axpby_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const h16_t*)a, (const h16_t*)b, (h16_t*)y,
                                                                           (size_t)n / 8, alpha, beta);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_mean_tokens_bf16(const void* x, void* y, int B, int T, int C, void* stream) {
+int SPIDER_FN(spider_mean_tokens)(const void* x, void* y, int B, int T, int C, void* stream) {
     SPIDER_CHECK(B > 0 && T > 0 && C > 0, "mean_tokens: bad shape");
-    mean_tokens_kernel<<<grid_for((size_t)B * C), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, T, C);
+    mean_tokens_kernel<<<grid_for((size_t)B * C), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (h16_t*)y, B, T, C);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
 // host_xs: HOST array of E device pointers, each [B, per_batch] bf16; logits [B, ld >= E] bf16 (router outputs before the sigmoid)
-int spider_moe_combine_bf16(const void* const* host_xs, int E, const void* logits, int ld, void* y, int B, long per_batch,
+int SPIDER_FN(spider_moe_combine)(const void* const* host_xs, int E, const void* logits, int ld, void* y, int B, long per_batch,
                             void* stream) {
     SPIDER_CHECK(E >= 1 && E <= 8 && ld >= E && B > 0 && per_batch > 0, "moe_combine: 1..8 experts, ld >= E");
     MoeCombine mc{};
     mc.E = E;
-    for (int e = 0; e < E; ++e) mc.x[e] = (const bf16_t*)host_xs[e];
-    moe_combine_kernel<<<grid_for((size_t)B * per_batch), 256, 0, (hipStream_t)stream>>>(mc, (const bf16_t*)logits, ld, (bf16_t*)y, B,
+    for (int e = 0; e < E; ++e) mc.x[e] = (const h16_t*)host_xs[e];
+    moe_combine_kernel<<<grid_for((size_t)B * per_batch), 256, 0, (hipStream_t)stream>>>(mc, (const h16_t*)logits, ld, (h16_t*)y, B,
                                                                                         (size_t)per_batch);
     SPIDER_LAUNCH_OK();
     return 0;
@@ -928,36 +934,36 @@ int spider_moe_combine_bf16(const void* const* host_xs, int E, const void* logit
 
 // ConvTranspose1d, second half: overlap-add of the per-tap GEMM output. cols [B, L_in, k, Cout] fp32 (cols[b,i,j,:] =
 // x[b,i,:] . w[:, :, j]); y[b, t, :] = bias + sum over (i, j) with i*stride - pad + j == t. L_out = (L_in-1)*stride - 2*pad + k.
-int spider_col2im1d_f32_bf16(const float* cols, const void* bias, void* y, int B, int L_in, int k, int stride, int pad,
+int SPIDER_FN(spider_col2im1d_f32)(const float* cols, const void* bias, void* y, int B, int L_in, int k, int stride, int pad,
                              int Cout, void* stream) {
     SPIDER_CHECK(B > 0 && L_in > 0 && k >= 1 && stride >= 1 && pad >= 0 && Cout > 0 && Cout % 4 == 0, "col2im1d: bad shape (Cout % 4 == 0)");
     const int L_out = (L_in - 1) * stride - 2 * pad + k;
     SPIDER_CHECK(L_out > 0, "col2im1d: empty output");
     const size_t total = (size_t)B * L_out * (Cout / 4);
-    col2im1d_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(cols, (const bf16_t*)bias, (bf16_t*)y, B, L_in, L_out, k,
+    col2im1d_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(cols, (const h16_t*)bias, (h16_t*)y, B, L_in, L_out, k,
                                                                       stride, pad, Cout);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
 // y[r, :] = x[r, :] / max(||x[r, :]||_2, eps)   (F.normalize of the CLAP text embedding, custom_ad.py:217-219)
-int spider_l2_normalize_rows_bf16(const void* x, void* y, int rows, int n, float eps, void* stream) {
+int SPIDER_FN(spider_l2_normalize_rows)(const void* x, void* y, int rows, int n, float eps, void* stream) {
     SPIDER_CHECK(rows > 0 && n > 0 && n <= 8192, "l2_normalize_rows: n must be 1..8192");
-    l2norm_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, n, eps);
+    l2norm_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (h16_t*)y, n, eps);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_add_bf16(const void* a, const void* b, void* y, long n, void* stream) {
+int SPIDER_FN(spider_add)(const void* a, const void* b, void* y, long n, void* stream) {
     SPIDER_CHECK(n > 0 && n % 8 == 0, "add: n must be a multiple of 8");
-    add_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+    add_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const h16_t*)a, (const h16_t*)b, (h16_t*)y,
                                                                         (size_t)n / 8);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
 // conv with Cin <= 8 (conv_in). x [B,H,W,Cin], w [Cout,ks,ks,Cin], y [B,H,W,Cout]; stride 1, same padding.
-int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
+int SPIDER_FN(spider_conv2d_small_cin)(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin,
                                  int Cout, int ks, void* stream) {
     SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 8 && Cout % 8 == 0, "conv_small_cin: Cin <= 8, Cout % 8 == 0");
     SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cin: kernel size must be 1 or 3");
@@ -967,39 +973,40 @@ int spider_conv2d_small_cin_bf16(const void* x, const void* w, const void* bias,
     // every block re-stages the whole weight tensor into LDS: keep the grid at ~2 blocks per CU and grid-stride
     int grid = grid_for(total);
     if (grid > 512) grid = 512;
-    conv_small_cin_kernel<<<grid, 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
-                                                                               (const bf16_t*)bias, (bf16_t*)y, B, H, W,
+    conv_small_cin_kernel<<<grid, 256, smem, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)w,
+                                                                               (const h16_t*)bias, (h16_t*)y, B, H, W,
                                                                                Cin, Cout, ks);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
 // conv with Cout <= 4 (conv_out). Exactly one of y32 (fp32) / y16 (bf16) is written, layout [B,H,W,Cout].
-int spider_conv2d_small_cout_bf16(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
+int SPIDER_FN(spider_conv2d_small_cout)(const void* x, const void* w, const void* bias, void* y32, void* y16, int B, int H,
                                   int W, int Cin, int Cout, int ks, void* stream) {
     SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "conv_small_cout: Cout <= 8, Cin % 8 == 0");
     SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cout: kernel size must be 1 or 3");
     SPIDER_CHECK((y32 != nullptr) != (y16 != nullptr), "conv_small_cout: give exactly one output");
     SPIDER_CHECK((Cout * ks * ks * Cin) % 8 == 0, "conv_small_cout: weight count must be a multiple of 8");
-    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(bf16_t);
+    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(h16_t);
     SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cout: weights exceed LDS");
     const size_t npix = (size_t)B * H * W;
     size_t grid = (npix + 3) / 4;
     if (grid > 2048) grid = 2048;   // each block stages all weights into LDS once, then grid-strides over pixels
-    conv_small_cout_kernel<<<(int)grid, 256, smem, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)w,
-                                                                         (const bf16_t*)bias, (float*)y32, (bf16_t*)y16, B,
+    conv_small_cout_kernel<<<(int)grid, 256, smem, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)w,
+                                                                         (const h16_t*)bias, (float*)y32, (h16_t*)y16, B,
                                                                          H, W, Cin, Cout, ks);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
-int spider_latent_to_nhwc_bf16(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream) {
+int SPIDER_FN(spider_latent_to_nhwc)(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0 && reps >= 1, "latent_to_nhwc: bad shape");
-    latent_in_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(lat, (bf16_t*)out, B, C, HW, reps, scale);
+    latent_in_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(lat, (h16_t*)out, B, C, HW, reps, scale);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
+#ifndef SPIDER_F16
 int spider_cfg_combine_f32(const float* eps2, float* out, int B, int C, int HW, float guidance, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "cfg_combine: bad shape");
     cfg_combine_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(eps2, out, B, C, HW, guidance);
@@ -1017,13 +1024,16 @@ int spider_lincomb_f32(const float* const* ins, const float* coefs, int n, float
     return 0;
 }
 
-int spider_softmax_rows_f32_bf16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream) {
+#endif
+
+int SPIDER_FN(spider_softmax_rows_f32)(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream) {
     SPIDER_CHECK(rows > 0 && n > 0 && n_valid > 0 && n_valid <= n && scale > 0.f, "softmax_rows: bad shape");
-    softmax_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n, n_valid, scale);
+    softmax_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, (h16_t*)y, n, n_valid, scale);
     SPIDER_LAUNCH_OK();
     return 0;
 }
 
+#ifndef SPIDER_F16
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad shape");
     nhwc_to_nchw_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(x, y, B, C, HW, mul, add, clamp01);
@@ -1038,5 +1048,7 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
     SPIDER_LAUNCH_OK();
     return 0;
 }
+
+#endif
 
 }  // extern "C"

@@ -30,13 +30,13 @@ constexpr int XLT = XLP / 16;    // key tiles per head
 constexpr int XPS = 1408;        // P image row stride in bytes
 
 struct XArgs {
-    const bf16_t* x;        // [rows, C] residual stream (un-normalised)
-    const bf16_t* mq;       // [B2][XHL/16][C/64][2][64][8]   fragment-major Mq (gamma and scale folded)
-    const bf16_t* mo;       // [B2][C/16][XHL/64][2][64][8]   fragment-major Mo
+    const h16_t* x;        // [rows, C] residual stream (un-normalised)
+    const h16_t* mq;       // [B2][XHL/16][C/64][2][64][8]   fragment-major Mq (gamma and scale folded)
+    const h16_t* mo;       // [B2][C/16][XHL/64][2][64][8]   fragment-major Mo
     const float* colsum;    // [B2, XHL]
     const float* colbias;   // [B2, XHL]
-    const bf16_t* bias_o;   // [C]
-    bf16_t* out;            // [rows, C]
+    const h16_t* bias_o;   // [C]
+    h16_t* out;            // [rows, C]
     int rows, C, n_tok, n_keys;
     float eps;
 };
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
     constexpr int ITEMS = BM * 8;
     const bool x_owner = tid < ITEMS;                          // BM = 64: every thread; 32 / 16: the first 256 / 128
     const int xr = tid >> 3, xc = tid & 7;
-    const bf16_t* xsrc = p.x + (size_t)(row0 + (x_owner ? xr : 0)) * C + xc * 8;
+    const h16_t* xsrc = p.x + (size_t)(row0 + (x_owner ? xr : 0)) * C + xc * 8;
     const int xdst = xr * 128 + ((xc ^ ((xr >> 1) & 7)) * 16);
     float sum = 0.f, sq = 0.f;
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
             *reinterpret_cast<u32x4*>(xs + buf * (BM * 128) + xdst) = xr_;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const float lo = bf16lo_to_f32(xr_[d]), hi = bf16hi_to_f32(xr_[d]);
+                const float lo = h16lo_to_f32(xr_[d]), hi = h16hi_to_f32(xr_[d]);
                 sum += lo + hi;
                 sq = fmaf(lo, lo, fmaf(hi, hi, sq));
             }
@@ -112,15 +112,15 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
                 const char* xb = xs + buf * (BM * 128);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 xf[MT];
+                    h16x8 xf[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        xf[mt] = *reinterpret_cast<const bf16x8*>(xb + (mt * 16 + r16) * 128 + (((ks * 4 + g) ^ fswz) * 16));
+                        xf[mt] = *reinterpret_cast<const h16x8*>(xb + (mt * 16 + r16) * 128 + (((ks * 4 + g) ^ fswz) * 16));
 #pragma unroll
                     for (int lt = 0; lt < XLT; ++lt)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[lt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[s][ks][lt]), xf[mt], acc[lt][mt], 0, 0, 0);
+                            acc[lt][mt] = mfma_16x16x32_h16(__builtin_bit_cast(h16x8, aq[s][ks][lt]), xf[mt], acc[lt][mt]);
                 }
                 issue1(kc + PD1, s);
             }
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
             for (int lt = 0; lt < XLT; ++lt) {
                 const int k = wave * XLP + lt * 16 + 4 * g;            // 4 consecutive keys: 8 bytes inside one 16-byte chunk
                 u32x2 o2;
-                o2.x = pack_bf16x2(acc[lt][mt][0] * inv, acc[lt][mt][1] * inv);
-                o2.y = pack_bf16x2(acc[lt][mt][2] * inv, acc[lt][mt][3] * inv);
+                o2.x = pack_h16x2(acc[lt][mt][0] * inv, acc[lt][mt][1] * inv);
+                o2.y = pack_h16x2(acc[lt][mt][2] * inv, acc[lt][mt][3] * inv);
                 *reinterpret_cast<u32x2*>(prow + (k >> 6) * 128 + ((((k & 63) >> 3) ^ pswz) * 16) + (k & 4) * 2) = o2;
             }
         }
@@ -218,17 +218,17 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
 #pragma unroll
         for (int s = 0; s < PD2; ++s) {
             const int k2 = k20 + s;                                  // NK2 = 20 is a multiple of PD2
-            bf16x8 pf[MT];
+            h16x8 pf[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = mt * 16 + r16;
-                pf[mt] = *reinterpret_cast<const bf16x8*>(ps + m * XPS + (k2 >> 1) * 128 + (((((k2 & 1) * 4) + g) ^ ((m >> 1) & 7)) * 16));
+                pf[mt] = *reinterpret_cast<const h16x8*>(ps + m * XPS + (k2 >> 1) * 128 + (((((k2 & 1) * 4) + g) ^ ((m >> 1) & 7)) * 16));
             }
 #pragma unroll
             for (int i = 0; i < CTW; ++i)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc2[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, mo_r[s][i]), pf[mt], acc2[i][mt], 0, 0, 0);
+                    acc2[i][mt] = mfma_16x16x32_h16(__builtin_bit_cast(h16x8, mo_r[s][i]), pf[mt], acc2[i][mt]);
             issue2(k2 + PD2, s);
         }
     }
@@ -244,13 +244,13 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
         for (int mt = 0; mt < MT; ++mt) {
             const size_t off = (size_t)(row0 + mt * 16 + r16) * C + c;
             const u32x2 rq = *reinterpret_cast<const u32x2*>(p.x + off);
-            float v0 = acc2[i][mt][0] + bf16lo_to_f32(bq.x), v1 = acc2[i][mt][1] + bf16hi_to_f32(bq.x);
-            float v2 = acc2[i][mt][2] + bf16lo_to_f32(bq.y), v3 = acc2[i][mt][3] + bf16hi_to_f32(bq.y);
-            v0 = bf16_to_f32(f32_to_bf16(v0)) + bf16lo_to_f32(rq.x); v1 = bf16_to_f32(f32_to_bf16(v1)) + bf16hi_to_f32(rq.x);
-            v2 = bf16_to_f32(f32_to_bf16(v2)) + bf16lo_to_f32(rq.y); v3 = bf16_to_f32(f32_to_bf16(v3)) + bf16hi_to_f32(rq.y);
+            float v0 = acc2[i][mt][0] + h16lo_to_f32(bq.x), v1 = acc2[i][mt][1] + h16hi_to_f32(bq.x);
+            float v2 = acc2[i][mt][2] + h16lo_to_f32(bq.y), v3 = acc2[i][mt][3] + h16hi_to_f32(bq.y);
+            v0 = h16_to_f32(f32_to_h16(v0)) + h16lo_to_f32(rq.x); v1 = h16_to_f32(f32_to_h16(v1)) + h16hi_to_f32(rq.x);
+            v2 = h16_to_f32(f32_to_h16(v2)) + h16lo_to_f32(rq.y); v3 = h16_to_f32(f32_to_h16(v3)) + h16hi_to_f32(rq.y);
             u32x2 o2;
-            o2.x = pack_bf16x2(v0, v1);
-            o2.y = pack_bf16x2(v2, v3);
+            o2.x = pack_h16x2(v0, v1);
+            o2.y = pack_h16x2(v2, v3);
             *reinterpret_cast<u32x2*>(p.out + off) = o2;
         }
     }
@@ -273,7 +273,7 @@ extern "C" {
 // x, out [rows, C] bf16 (rows = B2 * n_tok, sample-major); mq_fm / mo_fm: fragment-major folded projections (see the header);
 // colsum / colbias [B2, 8 * 80] fp32; bias_o [C]. 8 heads, n_keys <= 80 text tokens, C a multiple of 64, C <= 1280 (<= 10
 // output column tiles per wave), n_tok a multiple of the row tile (16; 32 / 64 are chosen when the grid still fills the chip).
-int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
+int SPIDER_FN(spider_xattn_fused)(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
                             const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
                             void* stream) {
     SPIDER_CHECK(heads == XH, "xattn_fused: built for 8 heads");
@@ -282,8 +282,8 @@ int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm,
     SPIDER_CHECK(n_keys >= 1 && n_keys <= XLP, "xattn_fused: at most 80 keys");
     SPIDER_CHECK((size_t)B2 * n_tok * C * 2 < ((size_t)1 << 31), "xattn_fused: activations must be < 2 GiB");
     XArgs a{};
-    a.x = (const bf16_t*)x; a.mq = (const bf16_t*)mq_fm; a.mo = (const bf16_t*)mo_fm; a.colsum = colsum; a.colbias = colbias;
-    a.bias_o = (const bf16_t*)bias_o; a.out = (bf16_t*)out; a.rows = B2 * n_tok; a.C = C; a.n_tok = n_tok; a.n_keys = n_keys; a.eps = eps;
+    a.x = (const h16_t*)x; a.mq = (const h16_t*)mq_fm; a.mo = (const h16_t*)mo_fm; a.colsum = colsum; a.colbias = colbias;
+    a.bias_o = (const h16_t*)bias_o; a.out = (h16_t*)out; a.rows = B2 * n_tok; a.C = C; a.n_tok = n_tok; a.n_keys = n_keys; a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     const int ctw = (C / 16 + 7) / 8;           // output column tiles per wave
     // row tile: the largest of 64 / 32 / 16 that divides n_tok and still gives >= ~192 blocks (or the smallest otherwise)

@@ -77,6 +77,18 @@ SIGNATURES = {
     "spider_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }
 
+# the diffusion-side operators (gemm / conv / attention / UNet ops / fused cross-attention translation units) also exist as
+# IEEE-half instantiations with the same signatures: spider_<op>_f16 (include/spider_hip.h, last section)
+F16_OPS = (
+    "spider_gemm", "spider_gemm_ln", "spider_xattn_fused", "spider_conv2d_nhwc", "spider_conv_nhwc_ex", "spider_attn",
+    "spider_attn_keylist", "spider_attn_varlen", "spider_groupnorm_nhwc", "spider_groupnorm_cat_nhwc", "spider_layernorm",
+    "spider_geglu", "spider_swiglu", "spider_concat_channels", "spider_act", "spider_add", "spider_act_ex", "spider_add_scaled",
+    "spider_axpby", "spider_mean_tokens", "spider_moe_combine", "spider_col2im1d_f32", "spider_l2_normalize_rows",
+    "spider_conv2d_small_cin", "spider_conv2d_small_cout", "spider_latent_to_nhwc", "spider_softmax_rows_f32",
+)
+for _n in F16_OPS:
+    SIGNATURES[_n + "_f16"] = SIGNATURES[_n + "_bf16"]
+
 
 class SpiderHipError(RuntimeError):
     pass

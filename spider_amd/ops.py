@@ -36,6 +36,19 @@ def _workspace(device) -> torch.Tensor:
     return _WS[key]
 
 
+F16 = torch.float16
+
+
+def _h16(t: torch.Tensor):
+    """(dtype, entry-point suffix) of a diffusion-side operand: the UNet / VAE / text-encoder operators exist as bf16 and as
+    IEEE-half (f16, the reference's torch_dtype) instantiations; every 16-bit operand of one call must share the dtype."""
+    if t.dtype == BF16:
+        return BF16, "bf16"
+    if t.dtype == F16:
+        return F16, "f16"
+    raise ValueError(f"expected a bfloat16 or float16 tensor, got {t.dtype}")
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -54,9 +67,11 @@ def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
 
 # --------------------------------------------------------------------------- LLM decode
 def embed(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    _chk(table, BF16, "table"); _chk(ids, torch.int32, "ids")
+    """Row gather of 16-bit rows (a copy of bit patterns: one kernel serves bf16 and f16 tables)."""
+    dt, _ = _h16(table)
+    _chk(table, dt, "table"); _chk(ids, torch.int32, "ids")
     V, H = table.shape
-    out = torch.empty(*ids.shape, H, dtype=BF16, device=table.device)
+    out = torch.empty(*ids.shape, H, dtype=dt, device=table.device)
     _lib.call("spider_embed_bf16", _p(table), _p(ids), _p(out), ids.numel(), H, V, _stream())
     return out
 
@@ -100,14 +115,15 @@ def repack_fm16(W: torch.Tensor, norm_w: Optional[torch.Tensor] = None) -> torch
     W -> fragment-major copy [ceil(N/16), K/64, 2, 64, 8] for the *_fm kernels: piece (rg, kb, sx)
     holds, at lane 16 g + r, W[16 rg + r, 64 kb + 32 sx + 8 g : + 8]. Pure data movement, done once when an engine loads its
     weights (like the OIHW -> OHWI conv repack); rows are zero-padded to a multiple of 16."""
-    _chk(W, BF16, "W")
+    dt, _ = _h16(W)
+    _chk(W, dt, "W")
     N, K = W.shape
     assert K % 64 == 0, "repack_fm16: K must be a multiple of 64"
     if norm_w is not None:
-        W = (W.float() * norm_w.float()[None, :]).to(BF16)
+        W = (W.float() * norm_w.float()[None, :]).to(dt)
     NG = (N + 15) // 16
     if NG * 16 != N:
-        W = torch.cat([W, torch.zeros(NG * 16 - N, K, dtype=BF16, device=W.device)], 0)
+        W = torch.cat([W, torch.zeros(NG * 16 - N, K, dtype=dt, device=W.device)], 0)
     # [rg, r, kb, sx, g, e] -> [rg, kb, sx, g, r, e]
     return W.view(NG, 16, K // 64, 2, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous().view(NG, K // 64, 2, 64, 8)
 
@@ -228,15 +244,16 @@ def attn_decode_fused(qkv, pos, cos_sin, k_cache, v_cache, kv_end, kv_beg, count
 # --------------------------------------------------------------------------- GEMM / conv / attention
 def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, out_scale=1.0, out=None, out_f32=False):
     """C = act(A @ W^T + bias + rowbias[row // rows_per_group]) (+ res) * out_scale.  A [..., K], W [N, K]."""
-    _chk(A, BF16, "A"); _chk(W, BF16, "W")
+    dt, sfx = _h16(A)
+    _chk(A, dt, "A"); _chk(W, dt, "W")
     N, K = W.shape
     assert A.shape[-1] == K, f"gemm: A[..., {A.shape[-1]}] vs W[{N},{K}]"
     M = A.numel() // K
     n_out = N // 2 if act == "geglu" else N    # GEGLU epilogue: W = [value rows | gate rows], output has N/2 columns
     if out is None:
-        out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else BF16, device=A.device)
+        out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else dt, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
-    _lib.call("spider_gemm_bf16", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
+    _lib.call(f"spider_gemm_{sfx}", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
               M, N, K, K, n_out, ACT[act], float(out_scale), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
@@ -247,7 +264,7 @@ def fold_layernorm(W, gamma, beta, bias=None):
     Wf = W * gamma (bf16), colsum = Wf.sum(1) (fp32, of the ROUNDED Wf so that the mean term cancels exactly),
     colbias = W @ beta + bias (fp32). Returns (Wf, colsum, colbias)."""
     W32 = W.float()
-    Wf = (W32 * gamma.float()[None, :]).to(BF16).contiguous()
+    Wf = (W32 * gamma.float()[None, :]).to(W.dtype).contiguous()
     colsum = Wf.float().sum(1).contiguous()
     colbias = (W32 @ beta.float())
     if bias is not None:
@@ -258,17 +275,18 @@ def fold_layernorm(W, gamma, beta, bias=None):
 def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
     """LayerNorm(A) @ W^T + bias (+ res) in one launch; (Wf, colsum, colbias) = fold_layernorm(W, gamma, beta, bias).
     act: None or "geglu". A [..., K] bf16 contiguous rows."""
-    _chk(A, BF16, "A"); _chk(Wf, BF16, "Wf"); _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
+    dt, sfx = _h16(A)
+    _chk(A, dt, "A"); _chk(Wf, dt, "Wf"); _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
     N, K = Wf.shape
     assert A.shape[-1] == K and colsum.numel() == N and colbias.numel() == N, "gemm_ln: shape mismatch"
     assert act in (None, "geglu"), "gemm_ln: only the plain and GEGLU epilogues exist"
     M = A.numel() // K
     n_out = N // 2 if act == "geglu" else N
     if out is None:
-        out = torch.empty(*A.shape[:-1], n_out, dtype=BF16, device=A.device)
+        out = torch.empty(*A.shape[:-1], n_out, dtype=dt, device=A.device)
     if res is not None:
-        _chk(res, BF16, "res")
-    _lib.call("spider_gemm_ln_bf16", _p(A), _p(Wf), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out, ACT[act], float(eps),
+        _chk(res, dt, "res")
+    _lib.call(f"spider_gemm_ln_{sfx}", _p(A), _p(Wf), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out, ACT[act], float(eps),
               _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
@@ -279,20 +297,22 @@ XATTN_LP = 80     # keys per head in the folded cross-attention operands (77 tex
 def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps=1e-5, out=None):
     """x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) with the prompt's K / V folded into mq_fm / mo_fm (see
     include/spider_hip.h, spider_xattn_fused_bf16, and UNetEngine.prepare). x [B2, n_tok, C] or [B2 * n_tok, C] bf16."""
-    _chk(x, BF16, "x"); _chk(mq_fm, BF16, "mq_fm"); _chk(mo_fm, BF16, "mo_fm")
-    _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias"); _chk(bias_o, BF16, "bias_o")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(mq_fm, dt, "mq_fm"); _chk(mo_fm, dt, "mo_fm")
+    _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias"); _chk(bias_o, dt, "bias_o")
     C = x.shape[-1]
     n_tok = x.numel() // (C * B2)
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("spider_xattn_fused_bf16", _p(x), _p(mq_fm), _p(mo_fm), _p(colsum), _p(colbias), _p(bias_o), _p(out), B2, n_tok, C,
+    _lib.call(f"spider_xattn_fused_{sfx}", _p(x), _p(mq_fm), _p(mo_fm), _p(colsum), _p(colbias), _p(bias_o), _p(out), B2, n_tok, C,
               heads, n_keys, float(eps), _stream())
     return out
 
 
 def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None):
     """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]."""
-    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
     Cout, ks = w.shape[0], w.shape[1]
     if pad is None:
@@ -300,8 +320,8 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     Hs, Ws = (H * 2, Wd * 2) if ups else (H, Wd)
     Ho, Wo = (Hs + 2 * pad - ks) // stride + 1, (Ws + 2 * pad - ks) // stride + 1
     if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
-    _lib.call("spider_conv2d_nhwc_bf16", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
+        out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
+    _lib.call(f"spider_conv2d_nhwc_{sfx}", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
               ks, stride, pad, int(ups), float(out_scale), _p(_workspace(x.device)), WS_BYTES, _stream())
     return out
 
@@ -310,7 +330,8 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
             out_scale=1.0, out=None):
     """General NHWC conv. x [B,H,W,Cin] bf16, w [Cout,kh,kw,Cin] bf16 -> [B,Ho,Wo,Cout]. up_size=(uh,uw): x is read through
     a nearest upsample to that size (each in (in, 2*in]) before the conv."""
-    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
     Cout, kh, kw = w.shape[0], w.shape[1], w.shape[2]
     assert w.shape[3] == Cin, f"conv: x has {Cin} channels, w expects {w.shape[3]}"
@@ -318,9 +339,9 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     Ho = (Hs + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1
     Wo = (Ws + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
     if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=BF16, device=x.device)
+        out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
     uh, uw = up_size if up_size is not None else (0, 0)
-    _lib.call("spider_conv_nhwc_ex_bf16", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout, kh, kw,
+    _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout, kh, kw,
               stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), _p(_workspace(x.device)),
               WS_BYTES, _stream())
     return out
@@ -341,15 +362,17 @@ def conv_transpose1d(x, w_taps, bias, k: int, stride: int, pad: int):
     B, L, Cin = x.shape
     Cout = w_taps.shape[0] // k
     cols = gemm(x, w_taps, out_f32=True)                      # [B, L, k*Cout] fp32
-    out = torch.empty(B, (L - 1) * stride - 2 * pad + k, Cout, dtype=BF16, device=x.device)
-    _lib.call("spider_col2im1d_f32_bf16", _p(cols), _p(bias), _p(out), B, L, k, stride, pad, Cout, _stream())
+    dt, sfx = _h16(x)
+    out = torch.empty(B, (L - 1) * stride - 2 * pad + k, Cout, dtype=dt, device=x.device)
+    _lib.call(f"spider_col2im1d_f32_{sfx}", _p(cols), _p(bias), _p(out), B, L, k, stride, pad, Cout, _stream())
     return out
 
 
 def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_off=None, kv_beg=None,
               keep_bits=None, blk=0, q_off=0, out=None):
     """q [B,Lq,Hq*d], k/v [B,Lk,Hkv*d] (last dim contiguous; batch/row strides free) -> [B,Lq,Hq*d]."""
-    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    dt, sfx = _h16(q)
+    _chk(q, dt, "q", False); _chk(k, dt, "k", False); _chk(v, dt, "v", False)
     B, Lq, Cq = q.shape
     Lk = k.shape[1]
     Hq = n_heads
@@ -361,8 +384,8 @@ def attention(q, k, v, n_heads, n_kv_heads=None, scale=None, causal=False, kv_of
     if kv_off is None:
         kv_off = Lk - Lq
     if out is None:
-        out = torch.empty(B, Lq, Cq, dtype=BF16, device=q.device)
-    _lib.call("spider_attn_bf16", _p(q), _p(k), _p(v), _p(out),
+        out = torch.empty(B, Lq, Cq, dtype=dt, device=q.device)
+    _lib.call(f"spider_attn_{sfx}", _p(q), _p(k), _p(v), _p(out),
               q.stride(0), d, q.stride(1), k.stride(0), d, k.stride(1), v.stride(0), d, v.stride(1),
               out.stride(0), d, out.stride(1),
               B, Hq, Hkv, Lq, Lk, d, float(scale), int(causal), int(kv_off), _p(kv_beg), _p(keep_bits), blk, q_off,
@@ -384,7 +407,8 @@ def story_key_lists(keep_bits, n_keys: int, N: int, img0: int, n_lists: int, q_i
 
 def attention_keylist(q, k, v, n_heads, key_idx, tiles, scale=None, out=None):
     """Consistent self-attention over visible-key lists (story_key_lists): q [B,Lq,H*64], k / v [B,Lk,H*64]."""
-    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    dt, sfx = _h16(q)
+    _chk(q, dt, "q", False); _chk(k, dt, "k", False); _chk(v, dt, "v", False)
     _chk(key_idx, torch.int32, "key_idx"); _chk(tiles, torch.int32, "tiles")
     B, Lq, Cq = q.shape
     Lk, d = k.shape[1], Cq // n_heads
@@ -392,8 +416,8 @@ def attention_keylist(q, k, v, n_heads, key_idx, tiles, scale=None, out=None):
     if scale is None:
         scale = 1.0 / math.sqrt(d)
     if out is None:
-        out = torch.empty(B, Lq, Cq, dtype=BF16, device=q.device)
-    _lib.call("spider_attn_keylist_bf16", _p(q), _p(k), _p(v), _p(out),
+        out = torch.empty(B, Lq, Cq, dtype=dt, device=q.device)
+    _lib.call(f"spider_attn_keylist_{sfx}", _p(q), _p(k), _p(v), _p(out),
               q.stride(0), d, q.stride(1), k.stride(0), d, k.stride(1), v.stride(0), d, v.stride(1),
               out.stride(0), d, out.stride(1), B, n_heads, n_heads, Lq, Lk, d, float(scale),
               _p(key_idx), key_idx.numel(), _p(tiles), tiles.shape[0], _stream())
@@ -417,7 +441,8 @@ def varlen_tiles(cu_seqlens, device) -> torch.Tensor:
 
 def attention_varlen(q, k, v, n_heads, tiles, n_kv_heads=None, scale=None, out=None):
     """Packed segments: q [T,Hq*d], k/v [T,Hkv*d] (last dim contiguous, row stride free); tiles from varlen_tiles()."""
-    _chk(q, BF16, "q", False); _chk(k, BF16, "k", False); _chk(v, BF16, "v", False)
+    dt, sfx = _h16(q)
+    _chk(q, dt, "q", False); _chk(k, dt, "k", False); _chk(v, dt, "v", False)
     T, Cq = q.shape
     Hq, Hkv = n_heads, (n_kv_heads or n_heads)
     d = Cq // Hq
@@ -426,8 +451,8 @@ def attention_varlen(q, k, v, n_heads, tiles, n_kv_heads=None, scale=None, out=N
     if scale is None:
         scale = 1.0 / math.sqrt(d)
     if out is None:
-        out = torch.empty(T, Cq, dtype=BF16, device=q.device)
-    _lib.call("spider_attn_varlen_bf16", _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+        out = torch.empty(T, Cq, dtype=dt, device=q.device)
+    _lib.call(f"spider_attn_varlen_{sfx}", _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
               T, Hq, Hkv, d, float(scale), _p(tiles), tiles.shape[0], _stream())
     return out
 
@@ -444,7 +469,8 @@ def rope_rows_(x, cos_sin, n_heads):
 
 def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=None, kv_beg=None, out=None):
     """Prefill attention against the KV cache. q [B,S,n_q,d]; caches [B,n_kv,T_max,d]; keys [0, Lk)."""
-    _chk(q, BF16, "q"); _chk(k_cache, BF16, "k_cache"); _chk(v_cache, BF16, "v_cache")
+    dt, sfx = _h16(q)
+    _chk(q, dt, "q"); _chk(k_cache, dt, "k_cache"); _chk(v_cache, dt, "v_cache")
     B, S, n_q, d = q.shape
     n_kv, T_max = k_cache.shape[1], k_cache.shape[2]
     if scale is None:
@@ -452,8 +478,8 @@ def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=Non
     if kv_off is None:
         kv_off = Lk - S
     if out is None:
-        out = torch.empty(B, S, n_q * d, dtype=BF16, device=q.device)
-    _lib.call("spider_attn_bf16", _p(q), _p(k_cache), _p(v_cache), _p(out),
+        out = torch.empty(B, S, n_q * d, dtype=dt, device=q.device)
+    _lib.call(f"spider_attn_{sfx}", _p(q), _p(k_cache), _p(v_cache), _p(out),
               S * n_q * d, d, n_q * d, n_kv * T_max * d, T_max * d, d, n_kv * T_max * d, T_max * d, d,
               S * n_q * d, d, n_q * d,
               B, n_q, n_kv, S, Lk, d, float(scale), int(causal), int(kv_off), _p(kv_beg), None, 0, 0, _stream())
@@ -467,107 +493,117 @@ def groupnorm_nchunk(HW: int) -> int:
 
 def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None):
     """x [B, ..., C] NHWC bf16."""
-    _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
     B, Cn = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cn)
     if out is None:
         out = torch.empty_like(x)
     if ws is None:
         ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x.device)
-    _lib.call("spider_groupnorm_nhwc_bf16", _p(x), _p(gamma), _p(beta), _p(out), _p(ws), B, HW, Cn, groups, float(eps),
+    _lib.call(f"spider_groupnorm_nhwc_{sfx}", _p(x), _p(gamma), _p(beta), _p(out), _p(ws), B, HW, Cn, groups, float(eps),
               int(silu), _stream())
     return out
 
 
 def groupnorm_cat(x1, x2, gamma, beta, groups=32, eps=1e-5, silu=False, ws=None):
     """GroupNorm(+SiLU) of cat([x1, x2], channel) without a concat launch; returns (normalised, concatenated input)."""
-    _chk(x1, BF16, "x1"); _chk(x2, BF16, "x2"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    dt, sfx = _h16(x1)
+    _chk(x1, dt, "x1"); _chk(x2, dt, "x2"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
     B, C1, C2 = x1.shape[0], x1.shape[-1], x2.shape[-1]
     HW = x1.numel() // (B * C1)
     assert x2.shape[:-1] == x1.shape[:-1] and gamma.numel() == C1 + C2, "groupnorm_cat: sources must share [B, ..., *]"
-    out = torch.empty(*x1.shape[:-1], C1 + C2, dtype=BF16, device=x1.device)
+    out = torch.empty(*x1.shape[:-1], C1 + C2, dtype=dt, device=x1.device)
     cat = torch.empty_like(out)
     if ws is None:
         ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x1.device)
-    _lib.call("spider_groupnorm_cat_nhwc_bf16", _p(x1), _p(x2), _p(gamma), _p(beta), _p(out), _p(cat), _p(ws), B, HW, C1, C2,
+    _lib.call(f"spider_groupnorm_cat_nhwc_{sfx}", _p(x1), _p(x2), _p(gamma), _p(beta), _p(out), _p(cat), _p(ws), B, HW, C1, C2,
               groups, float(eps), int(silu), _stream())
     return out, cat
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
-    _chk(x, BF16, "x"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
     Cn = x.shape[-1]
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("spider_layernorm_bf16", _p(x), _p(gamma), _p(beta), _p(out), x.numel() // Cn, Cn, float(eps), _stream())
+    _lib.call(f"spider_layernorm_{sfx}", _p(x), _p(gamma), _p(beta), _p(out), x.numel() // Cn, Cn, float(eps), _stream())
     return out
 
 
 def geglu(x, out=None):
-    _chk(x, BF16, "x")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
     inner = x.shape[-1] // 2
     M = x.numel() // (2 * inner)
     if out is None:
-        out = torch.empty(*x.shape[:-1], inner, dtype=BF16, device=x.device)
-    _lib.call("spider_geglu_bf16", _p(x), _p(out), M, inner, _stream())
+        out = torch.empty(*x.shape[:-1], inner, dtype=dt, device=x.device)
+    _lib.call(f"spider_geglu_{sfx}", _p(x), _p(out), M, inner, _stream())
     return out
 
 
 def swiglu(x, out=None):
-    _chk(x, BF16, "x")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
     inner = x.shape[-1] // 2
     M = x.numel() // (2 * inner)
     if out is None:
-        out = torch.empty(*x.shape[:-1], inner, dtype=BF16, device=x.device)
-    _lib.call("spider_swiglu_bf16", _p(x), _p(out), M, inner, _stream())
+        out = torch.empty(*x.shape[:-1], inner, dtype=dt, device=x.device)
+    _lib.call(f"spider_swiglu_{sfx}", _p(x), _p(out), M, inner, _stream())
     return out
 
 
 def concat_channels(a, b, out=None):
-    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    dt, sfx = _h16(a)
+    _chk(a, dt, "a"); _chk(b, dt, "b")
     C1, C2 = a.shape[-1], b.shape[-1]
     rows = a.numel() // C1
     assert b.numel() // C2 == rows
     if out is None:
-        out = torch.empty(*a.shape[:-1], C1 + C2, dtype=BF16, device=a.device)
-    _lib.call("spider_concat_channels_bf16", _p(a), _p(b), _p(out), rows, C1, C2, _stream())
+        out = torch.empty(*a.shape[:-1], C1 + C2, dtype=dt, device=a.device)
+    _lib.call(f"spider_concat_channels_{sfx}", _p(a), _p(b), _p(out), rows, C1, C2, _stream())
     return out
 
 
 def act(x, kind: str, param: float = 0.0, out=None):
-    _chk(x, BF16, "x")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
     if out is None:
         out = torch.empty_like(x)
-    _lib.call("spider_act_ex_bf16", _p(x), _p(out), x.numel(), ACT[kind], float(param), _stream())
+    _lib.call(f"spider_act_ex_{sfx}", _p(x), _p(out), x.numel(), ACT[kind], float(param), _stream())
     return out
 
 
 def add_scaled(a, b, scale: float, out=None):
     """bf16((a + b) * scale)"""
-    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    dt, sfx = _h16(a)
+    _chk(a, dt, "a"); _chk(b, dt, "b")
     if out is None:
         out = torch.empty_like(a)
-    _lib.call("spider_add_scaled_bf16", _p(a), _p(b), _p(out), a.numel(), float(scale), _stream())
+    _lib.call(f"spider_add_scaled_{sfx}", _p(a), _p(b), _p(out), a.numel(), float(scale), _stream())
     return out
 
 
 def axpby(a, b, alpha: float, beta: float, out=None):
     """bf16(alpha * a + beta * b)"""
-    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    dt, sfx = _h16(a)
+    _chk(a, dt, "a"); _chk(b, dt, "b")
     assert a.shape == b.shape, (a.shape, b.shape)
     if out is None:
         out = torch.empty_like(a)
-    _lib.call("spider_axpby_bf16", _p(a), _p(b), _p(out), a.numel(), float(alpha), float(beta), _stream())
+    _lib.call(f"spider_axpby_{sfx}", _p(a), _p(b), _p(out), a.numel(), float(alpha), float(beta), _stream())
     return out
 
 
 def mean_tokens(x, out=None):
     """x [B,T,C] bf16 -> [B,C] mean over T"""
-    _chk(x, BF16, "x")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
     B, T, Cn = x.shape
     if out is None:
-        out = torch.empty(B, Cn, dtype=BF16, device=x.device)
-    _lib.call("spider_mean_tokens_bf16", _p(x), _p(out), B, T, Cn, _stream())
+        out = torch.empty(B, Cn, dtype=dt, device=x.device)
+    _lib.call(f"spider_mean_tokens_{sfx}", _p(x), _p(out), B, T, Cn, _stream())
     return out
 
 
@@ -575,64 +611,70 @@ def moe_combine(xs, logits, out=None):
     """xs: list of E tensors [B, ...] bf16; logits [B, ld >= E] bf16 (first E columns used) -> sum_e r_e * xs[e] with
     r = sigmoid(logits) / sum(sigmoid(logits))."""
     for t in xs:
-        _chk(t, BF16, "expert output")
-    _chk(logits, BF16, "logits")
+        dt, sfx = _h16(t)
+        _chk(t, dt, "expert output")
+    _chk(logits, dt, "logits")
     B, ld = logits.shape
     E = len(xs)
     assert ld >= E and all(t.shape == xs[0].shape for t in xs) and xs[0].shape[0] == B
     if out is None:
         out = torch.empty_like(xs[0])
     ptrs = (C.c_void_p * E)(*[t.data_ptr() for t in xs])
-    _lib.call("spider_moe_combine_bf16", ptrs, E, _p(logits), ld, _p(out), B, xs[0].numel() // B, _stream())
+    _lib.call(f"spider_moe_combine_{sfx}", ptrs, E, _p(logits), ld, _p(out), B, xs[0].numel() // B, _stream())
     return out
 
 
 def l2_normalize(x, eps: float = 1e-12, out=None):
     """rows of x [..., n] divided by max(L2 norm, eps) (torch.nn.functional.normalize)."""
-    _chk(x, BF16, "x")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
     if out is None:
         out = torch.empty_like(x)
     n = x.shape[-1]
-    _lib.call("spider_l2_normalize_rows_bf16", _p(x), _p(out), x.numel() // n, n, float(eps), _stream())
+    _lib.call(f"spider_l2_normalize_rows_{sfx}", _p(x), _p(out), x.numel() // n, n, float(eps), _stream())
     return out
 
 
 def add(a, b, out=None):
-    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    dt, sfx = _h16(a)
+    _chk(a, dt, "a"); _chk(b, dt, "b")
     if out is None:
         out = torch.empty_like(a)
-    _lib.call("spider_add_bf16", _p(a), _p(b), _p(out), a.numel(), _stream())
+    _lib.call(f"spider_add_{sfx}", _p(a), _p(b), _p(out), a.numel(), _stream())
     return out
 
 
 def conv2d_small_cin(x, w, bias=None, out=None):
-    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
     Cout, ks = w.shape[0], w.shape[1]
     if out is None:
-        out = torch.empty(B, H, Wd, Cout, dtype=BF16, device=x.device)
-    _lib.call("spider_conv2d_small_cin_bf16", _p(x), _p(w), _p(bias), _p(out), B, H, Wd, Cin, Cout, ks, _stream())
+        out = torch.empty(B, H, Wd, Cout, dtype=dt, device=x.device)
+    _lib.call(f"spider_conv2d_small_cin_{sfx}", _p(x), _p(w), _p(bias), _p(out), B, H, Wd, Cin, Cout, ks, _stream())
     return out
 
 
 def conv2d_small_cout(x, w, bias=None, out_f32=True, out=None):
-    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
     Cout, ks = w.shape[0], w.shape[1]
     if out is None:
-        out = torch.empty(B, H, Wd, Cout, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        out = torch.empty(B, H, Wd, Cout, dtype=torch.float32 if out_f32 else dt, device=x.device)
     y32, y16 = (out, None) if out.dtype == torch.float32 else (None, out)
-    _lib.call("spider_conv2d_small_cout_bf16", _p(x), _p(w), _p(bias), _p(y32), _p(y16), B, H, Wd, Cin, Cout, ks, _stream())
+    _lib.call(f"spider_conv2d_small_cout_{sfx}", _p(x), _p(w), _p(bias), _p(y32), _p(y16), B, H, Wd, Cin, Cout, ks, _stream())
     return out
 
 
-def latent_to_nhwc(lat, reps=1, scale=1.0, out=None):
-    """fp32 NCHW [B,C,H,W] -> bf16 NHWC [reps*B,H,W,C]."""
+def latent_to_nhwc(lat, reps=1, scale=1.0, out=None, dtype=BF16):
+    """fp32 NCHW [B,C,H,W] -> 16-bit (dtype, or out's) NHWC [reps*B,H,W,C]."""
     _chk(lat, torch.float32, "lat")
     B, Cn, H, Wd = lat.shape
     if out is None:
-        out = torch.empty(reps * B, H, Wd, Cn, dtype=BF16, device=lat.device)
-    _lib.call("spider_latent_to_nhwc_bf16", _p(lat), _p(out), B, Cn, H * Wd, reps, float(scale), _stream())
+        out = torch.empty(reps * B, H, Wd, Cn, dtype=dtype, device=lat.device)
+    _, sfx = _h16(out)
+    _lib.call(f"spider_latent_to_nhwc_{sfx}", _p(lat), _p(out), B, Cn, H * Wd, reps, float(scale), _stream())
     return out
 
 
@@ -668,13 +710,14 @@ def nhwc_to_nchw(x, mul=1.0, add_=0.0, clamp01=False, out=None):
     return out
 
 
-def softmax_rows(x, scale=1.0, n_valid=None, out=None):
-    """fp32 [rows, n] -> bf16 softmax(scale * x) per row over the first n_valid (default n) columns; the rest -> 0."""
+def softmax_rows(x, scale=1.0, n_valid=None, out=None, dtype=BF16):
+    """fp32 [rows, n] -> 16-bit softmax(scale * x) per row over the first n_valid (default n) columns; the rest -> 0."""
     _chk(x, torch.float32, "x")
     n = x.shape[-1]
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    _lib.call("spider_softmax_rows_f32_bf16", _p(x), _p(out), x.numel() // n, n, n if n_valid is None else n_valid, float(scale),
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _, sfx = _h16(out)
+    _lib.call(f"spider_softmax_rows_f32_{sfx}", _p(x), _p(out), x.numel() // n, n, n if n_valid is None else n_valid, float(scale),
               _stream())
     return out
 

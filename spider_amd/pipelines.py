@@ -32,6 +32,13 @@ from .vae import VAEDecoderEngine
 from .vocoder import HifiGanEngine
 
 
+def engine_dtype(torch_dtype):
+    """The 16-bit engine format for a `from_pretrained(..., torch_dtype=...)` request. The reference always passes
+    torch.float16 (spider_decoder.py:109,114,130,136,153,159; base_model.py:211); bfloat16 is honoured; None / float32
+    (diffusers: keep the checkpoint precision) maps to float16, the closest format the MFMA engines have."""
+    return torch.bfloat16 if torch_dtype == torch.bfloat16 else torch.float16
+
+
 class PipelineOutput:
     def __init__(self, images, nsfw_content_detected=None):
         self.images = images
@@ -66,9 +73,10 @@ class StableDiffusionPipeline:
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
-        return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device),
-                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, scaling=0.18215),   # custom_sd.py:388
-                   CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
+        dt = engine_dtype(torch_dtype)
+        return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt),
+                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, scaling=0.18215, dtype=dt),   # custom_sd.py:388
+                   CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 64))
 
     def to(self, device=None, *a, **k):
@@ -89,7 +97,7 @@ class StableDiffusionPipeline:
         batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
         if prompt_embeds is None:
             prompt_embeds = self.text_encoder.encode(self._tokenize(prompt))
-        prompt_embeds = prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+        prompt_embeds = prompt_embeds.to(device=self.device, dtype=self.unet.dtype)
         bs, seq, _ = prompt_embeds.shape
         prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, seq, -1)
         if do_cfg and negative_prompt_embeds is None:
@@ -105,7 +113,7 @@ class StableDiffusionPipeline:
                                  return_tensors="pt").input_ids
             negative_prompt_embeds = self.text_encoder.encode(ids)
         if do_cfg:
-            n = negative_prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+            n = negative_prompt_embeds.to(device=self.device, dtype=self.unet.dtype)
             n = n.repeat(1, num_images_per_prompt, 1).view(batch_size * num_images_per_prompt, n.shape[1], -1)
             prompt_embeds = torch.cat([n, prompt_embeds])   # [uncond | cond], one UNet batch (custom_sd.py:372)
         return prompt_embeds.contiguous()
@@ -191,11 +199,12 @@ class AudioLDMPipeline:
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
-        return cls(VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),
-                   ClapTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
+        dt = engine_dtype(torch_dtype)
+        return cls(VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, dtype=dt),
+                   ClapTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    RobertaTokenizer.from_pretrained(os.path.join(path, "tokenizer")),
-                   UNetEngine.from_pretrained(os.path.join(path, "unet"), device), sched,
-                   HifiGanEngine.from_pretrained(os.path.join(path, "vocoder"), device), ucfg.get("sample_size", 128))
+                   UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt), sched,
+                   HifiGanEngine.from_pretrained(os.path.join(path, "vocoder"), device, dtype=dt), ucfg.get("sample_size", 128))
 
     def to(self, device=None, *a, **k):
         return self
@@ -213,7 +222,7 @@ class AudioLDMPipeline:
         batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
         if prompt_embeds is None:
             prompt_embeds = self._clap(prompt)
-        prompt_embeds = prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+        prompt_embeds = prompt_embeds.to(device=self.device, dtype=self.unet.dtype)
         bs, dim = prompt_embeds.shape
         prompt_embeds = prompt_embeds.repeat(1, num_waveforms_per_prompt).view(bs * num_waveforms_per_prompt, dim)
         if do_cfg and negative_prompt_embeds is None:
@@ -231,7 +240,7 @@ class AudioLDMPipeline:
             # padding length does not change a masked encoder's output, so only the truncation limit matters
             negative_prompt_embeds = self._clap(uncond, max_length=min(prompt_embeds.shape[1], self.tokenizer.model_max_length))
         if do_cfg:
-            n = negative_prompt_embeds.to(device=self.device, dtype=torch.bfloat16)
+            n = negative_prompt_embeds.to(device=self.device, dtype=self.unet.dtype)
             n = n.repeat(1, num_waveforms_per_prompt).view(batch_size * num_waveforms_per_prompt, n.shape[1])
             prompt_embeds = torch.cat([n, prompt_embeds])   # [uncond | cond] (custom_ad.py:283)
         return prompt_embeds.contiguous()
@@ -348,9 +357,10 @@ class TextToVideoSDPipeline(StableDiffusionPipeline):
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
-        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device),
-                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device),       # scaling_factor from the config (:382)
-                   CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device),
+        dt = engine_dtype(torch_dtype)
+        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt),
+                   VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, dtype=dt),       # scaling_factor from the config (:382)
+                   CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 32))
 
     def _tokenize(self, prompt: List[str]) -> torch.Tensor:

@@ -30,8 +30,9 @@ class SpiderDecoder:
                  diffusion_modules=None, system_prompt_image="", system_prompt_video="", system_prompt_audio="",
                  mask_decoder_modules=None, system_prompt_mask="", box_decoder_modules=None, system_prompt_box="",
                  story_generation=None, system_prompt_story="", max_context_len=4096, reload_per_call=False,
-                 device="cuda:0", pipelines: Optional[Dict[str, object]] = None):
+                 device="cuda:0", pipelines: Optional[Dict[str, object]] = None, diffusion_dtype=torch.float16):
         diffusion_modules = diffusion_modules or {}
+        self.diffusion_dtype = diffusion_dtype   # the reference hard-codes torch.float16 (spider_decoder.py:109,114,130,136,153,159)
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -61,7 +62,7 @@ class SpiderDecoder:
         cls = registry.get_model_class(self.diffusion_types.get(modality) or {"IMAGE": "sd", "VIDEO": "vd", "AUDIO": "ad"}[modality])
         if cls is None:
             return None
-        pipe = cls.from_pretrained(ckpt, torch_dtype=torch.bfloat16).to(self.device)   # base_model.py:207-219
+        pipe = cls.from_pretrained(ckpt, torch_dtype=self.diffusion_dtype).to(self.device)   # base_model.py:207-219 (torch.float16)
         self._pipes[modality] = pipe
         return pipe
 

@@ -113,8 +113,13 @@ def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos=True, shift=0.
 
 
 class UNetEngine:
-    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+        """dtype: torch.bfloat16 or torch.float16 -- the 16-bit storage / MFMA operand format of the whole engine (the reference
+        loads its diffusion decoders with torch_dtype=torch.float16, spider_decoder.py:109; both instantiations of every kernel
+        exist, see csrc/common.hpp)."""
+        assert dtype in (torch.bfloat16, torch.float16), "UNetEngine: dtype must be bfloat16 or float16"
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        BF16 = dtype      # every 16-bit tensor this engine creates is of the engine dtype
         self.w: Dict[str, torch.Tensor] = {}
         dv = self.device
         for n, t in weights.items():
@@ -195,7 +200,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0, dtype=BF16):
         from_shapes = _param_shapes(cfg)
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
@@ -206,11 +211,11 @@ class UNetEngine:
                 t = torch.ones(shp, device=device)
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
-            w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+            w[n] = t.to(torch.bfloat16)     # same values for either engine dtype (bf16-representable, exact in f16 too)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
         """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors."""
         import glob, json, os
         from safetensors import safe_open
@@ -220,7 +225,7 @@ class UNetEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     # ------------------------------------------------------------------ per-call preparation
     def prepare(self, timesteps: torch.Tensor, enc: Optional[torch.Tensor], added: Optional[dict] = None,
@@ -228,7 +233,7 @@ class UNetEngine:
         """timesteps [n] (host), enc [B2, 77, cross] bf16 on device, added: SDXL {'text_embeds','time_ids'}.
         Computes every step's per-resnet time projection and every cross-attention layer's K/V once.
         AudioLDM form: enc=None (attn2 attends to its own input) and class_labels [B2, class_in]."""
-        cfg, dv = self.cfg, self.device
+        cfg, dv, BF16 = self.cfg, self.device, self.dtype
         B2 = enc.shape[0] if enc is not None else class_labels.shape[0]
         frames = getattr(self, "frames", 1)      # UNet3D: every sample of the CFG batch is `frames` images
         rows = B2 * frames
@@ -314,7 +319,7 @@ class UNetEngine:
         scale = 1.0 / math.sqrt(d)
         ops.gemm(kexp, xw["wqt_g"], out_scale=scale, out=f["mq"])                                 # [B2*HL, C]
         if C not in self._ones4:
-            o4 = torch.zeros(4, C, dtype=BF16, device=kv.device); o4[0] = 1.0
+            o4 = torch.zeros(4, C, dtype=self.dtype, device=kv.device); o4[0] = 1.0
             self._ones4[C] = o4
         f["cs"].copy_(ops.gemm(f["mq"], self._ones4[C], out_f32=True)[:, 0])
         f["cb"].copy_(ops.gemm(kexp, xw["wqb4"], out_scale=scale, out_f32=True)[:, 0])
@@ -482,13 +487,13 @@ def _fourier_filter(x_nhwc: torch.Tensor, threshold: int, scale: float) -> torch
     cr, cc = H // 2, W // 2
     mask[..., cr - threshold:cr + threshold, cc - threshold:cc + threshold] = scale
     xf = torch.fft.ifftshift(xf * mask, dim=(-2, -1))
-    return torch.fft.ifftn(xf, dim=(-2, -1)).real.permute(0, 2, 3, 1).to(BF16).contiguous()
+    return torch.fft.ifftn(xf, dim=(-2, -1)).real.permute(0, 2, 3, 1).to(x_nhwc.dtype).contiguous()
 
 
 def _apply_freeu(res_idx, hidden, skip, s1, s2, b1, b2):
     n = hidden.shape[-1] // 2
     b, s = (b1, s1) if res_idx == 0 else (b2, s2)
-    hidden = torch.cat([(hidden[..., :n].float() * b).to(BF16), hidden[..., n:]], -1).contiguous()
+    hidden = torch.cat([(hidden[..., :n].float() * b).to(hidden.dtype), hidden[..., n:]], -1).contiguous()
     return hidden, _fourier_filter(skip, 1, s)
 
 
@@ -609,7 +614,7 @@ def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: Optional[
     latents = (latents * scheduler.init_noise_sigma).contiguous()
     do_cfg = guidance > 1.0
     for i, t in enumerate(ts):
-        x2 = ops.latent_to_nhwc(latents, reps=2 if do_cfg else 1)
+        x2 = ops.latent_to_nhwc(latents, reps=2 if do_cfg else 1, dtype=unet.dtype)
         e = unet.step(x2, i, use_graph=use_graph)
         eps = ops.cfg_combine(e, guidance) if do_cfg else ops.nhwc_to_nchw(e)
         latents = scheduler.step(eps, t, latents)

@@ -96,17 +96,17 @@ def _param_shapes3d(c: UNet3DConfig) -> dict:
 
 
 class UNet3DEngine(UNetEngine):
-    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
         self.cfg3 = cfg
         # Conv3d (3,1,1) weights [O,I,3,1,1] -> [O,I,3,1]; the base class turns 4-D conv weights into OHWI = [O,3,1,I]
         w = {n: (t[..., 0] if t.ndim == 5 else t) for n, t in weights.items()}
-        super().__init__(cfg.as2d(), w, device)
+        super().__init__(cfg.as2d(), w, device, dtype=dtype)
         is_temporal = lambda l: ".temp_attentions." in l or l.startswith("transformer_in")
         self.cross_layers = [l for l in self.cross_layers if not is_temporal(l)]
         self.frames = 1
 
     @classmethod
-    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0, dtype=BF16):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _param_shapes3d(cfg).items():
@@ -117,10 +117,10 @@ class UNet3DEngine(UNetEngine):
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
         import glob, json, os
         from safetensors import safe_open
         cfg = UNet3DConfig.from_diffusers_dict(json.load(open(os.path.join(path, "config.json"))))
@@ -129,7 +129,7 @@ class UNet3DEngine(UNetEngine):
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     def prepare(self, timesteps, enc, added=None, class_labels=None, frames: int = 1):
         """enc [B2, 77, cross]; the UNet input of step() is [B2*frames, h, w, C] (sample-major, frame-minor)."""
@@ -153,7 +153,7 @@ class UNet3DEngine(UNetEngine):
     def _frame_attention(self, qkv, inner, heads, B, HW):
         """qkv [B*F*HW, 3*inner] (rows ordered sample, frame, pixel) -> attention along the frame axis, same row order."""
         F_ = self.frames
-        o = torch.empty(qkv.shape[0], inner, dtype=BF16, device=qkv.device)
+        o = torch.empty(qkv.shape[0], inner, dtype=qkv.dtype, device=qkv.device)
         for b in range(B):
             qv = qkv[b * F_ * HW:(b + 1) * F_ * HW].view(F_, HW, 3 * inner).permute(1, 0, 2)     # [HW, F, 3*inner], no copy
             ov = o[b * F_ * HW:(b + 1) * F_ * HW].view(F_, HW, inner).permute(1, 0, 2)
@@ -246,7 +246,7 @@ def video_denoise(unet: UNet3DEngine, scheduler, latents: torch.Tensor, enc: tor
     lat = (latents.permute(0, 2, 1, 3, 4).reshape(B * F_, C, h, w) * scheduler.init_noise_sigma).contiguous()
     do_cfg = guidance > 1.0
     for i, t in enumerate(ts):
-        x2 = ops.latent_to_nhwc(lat, reps=2 if do_cfg else 1)
+        x2 = ops.latent_to_nhwc(lat, reps=2 if do_cfg else 1, dtype=unet.dtype)
         e = unet.step(x2, i, use_graph=use_graph)
         eps = ops.cfg_combine(e, guidance) if do_cfg else ops.nhwc_to_nchw(e)
         lat = scheduler.step(eps, t, lat)

@@ -68,8 +68,12 @@ def _shapes(c: VAEConfig) -> dict:
 
 
 class VAEDecoderEngine:
-    def __init__(self, cfg: VAEConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: VAEConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+        """dtype: torch.bfloat16 or torch.float16 (the reference decodes in torch.float16, spider_decoder.py:109). bf16 is the
+        choice for checkpoints whose config sets force_upcast (the SDXL VAE overflows IEEE half: diffusers upcasts it to fp32)."""
+        assert dtype in (torch.bfloat16, torch.float16), "VAEDecoderEngine: dtype must be bfloat16 or float16"
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        BF16 = dtype
         self.w = {}
         for n, t in weights.items():
             if not (n.startswith("decoder.") or n.startswith("post_quant_conv")):
@@ -82,7 +86,7 @@ class VAEDecoderEngine:
         self.w["post_quant_conv.weight_scaled"] = (self.w["post_quant_conv.weight"].float() / cfg.scaling).to(BF16).contiguous()
 
     @classmethod
-    def random_init(cls, cfg: VAEConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: VAEConfig, device="cuda:0", seed=0, dtype=BF16):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _shapes(cfg).items():
@@ -93,17 +97,20 @@ class VAEDecoderEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) / math.sqrt(math.prod(shp[1:]))
             w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", scaling=None):
+    def from_pretrained(cls, path: str, device="cuda:0", scaling=None, dtype=BF16):
         """diffusers layout: <path>/config.json + *.safetensors. `scaling` overrides the checkpoint's scaling_factor (the
         reference's SD pipeline hard-codes 0.18215, custom_sd.py:388; its AudioLDM pipeline reads the config,
         custom_ad.py:289)."""
         import glob, json, os
         from safetensors import safe_open
         cj = os.path.join(path, "config.json")
-        cfg = VAEConfig.from_diffusers_dict(json.load(open(cj))) if os.path.exists(cj) else VAEConfig.sd15()
+        cj_d = json.load(open(cj)) if os.path.exists(cj) else {}
+        cfg = VAEConfig.from_diffusers_dict(cj_d) if cj_d else VAEConfig.sd15()
+        if cj_d.get("force_upcast", False) and dtype == torch.float16:
+            dtype = torch.bfloat16      # diffusers runs such a VAE in fp32 (it overflows IEEE half): take the wide-range 16-bit format
         if scaling is not None:
             cfg.scaling = scaling
         w = {}
@@ -111,7 +118,7 @@ class VAEDecoderEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     def _gn(self, n, x, silu):
         return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, 1e-6, silu)
@@ -135,13 +142,13 @@ class VAEDecoderEngine:
             xb = x[b]
             xk = xb
             if N8 != N:
-                xk = torch.zeros(N8, C, dtype=BF16, device=x.device)
+                xk = torch.zeros(N8, C, dtype=x.dtype, device=x.device)
                 xk[:N] = xb
             q = ops.gemm(xb, w[a + ".to_q.weight"], bias=w[a + ".to_q.bias"])
             k = ops.gemm(xk, w[a + ".to_k.weight"], bias=w[a + ".to_k.bias"])
             vT = ops.gemm(w[a + ".to_v.weight"], xk)                        # [C, N8] = Wv . x^T (bias folded below)
             s = ops.gemm(q, k, out_f32=True)                                # [N, N8] fp32 scores
-            p = ops.softmax_rows(s, scale=C ** -0.5, n_valid=N)             # padded columns -> 0
+            p = ops.softmax_rows(s, scale=C ** -0.5, n_valid=N, dtype=x.dtype)   # padded columns -> 0
             o = ops.gemm(p, vT, bias=w[a + ".to_v.bias"])                   # P.V + b_v (rows of P sum to 1)
             ops.gemm(o, w[a + ".to_out.0.weight"], bias=w[a + ".to_out.0.bias"], res=h.view(B, N, C)[b], out=out[b])
         return out.view(B, H, W_, C)
@@ -160,7 +167,7 @@ class VAEDecoderEngine:
 
     def _decode(self, latents: torch.Tensor, to_image: bool) -> torch.Tensor:
         c, w = self.cfg, self.w
-        z = ops.latent_to_nhwc(latents.contiguous())
+        z = ops.latent_to_nhwc(latents.contiguous(), dtype=self.dtype)
         z = ops.conv2d_small_cin(z, w["post_quant_conv.weight_scaled"], w["post_quant_conv.bias"]) if c.latent % 8 == 0 else \
             self._post_quant(z)
         h = ops.conv2d_small_cin(z, w["decoder.conv_in.weight"], w["decoder.conv_in.bias"])
@@ -180,6 +187,6 @@ class VAEDecoderEngine:
         """4 -> 4 channel 1x1 conv: Cout = 4 fits the small-Cout kernel only when Cin % 8 == 0, so pad Cin to 8."""
         w = self.w
         B, H, W_, C = z.shape
-        zp = torch.zeros(B, H, W_, 8, dtype=BF16, device=z.device); zp[..., :C] = z
-        wp = torch.zeros(C, 1, 1, 8, dtype=BF16, device=z.device); wp[..., :C] = w["post_quant_conv.weight_scaled"]
+        zp = torch.zeros(B, H, W_, 8, dtype=z.dtype, device=z.device); zp[..., :C] = z
+        wp = torch.zeros(C, 1, 1, 8, dtype=z.dtype, device=z.device); wp[..., :C] = w["post_quant_conv.weight_scaled"]
         return ops.conv2d_small_cout(zp, wp, w["post_quant_conv.bias"], out_f32=False)

@@ -60,8 +60,10 @@ def _shapes(c: HifiGanConfig) -> dict:
 
 
 class HifiGanEngine:
-    def __init__(self, cfg: HifiGanConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: HifiGanConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+        assert dtype in (torch.bfloat16, torch.float16), "HifiGanEngine: dtype must be bfloat16 or float16"
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        BF16 = dtype
         dv = self.device
         self.w: Dict[str, torch.Tensor] = {}
         for n, t in weights.items():
@@ -80,7 +82,7 @@ class HifiGanEngine:
         self.w["conv_post.weight4"], self.w["conv_post.bias4"] = wp.contiguous(), bp
 
     @classmethod
-    def random_init(cls, cfg: HifiGanConfig, device="cuda:0", seed=0):
+    def random_init(cls, cfg: HifiGanConfig, device="cuda:0", seed=0, dtype=BF16):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _shapes(cfg).items():
@@ -91,10 +93,10 @@ class HifiGanEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) / math.sqrt(math.prod(shp[1:]))
             w[n] = t.to(BF16)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0"):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
         import glob, json, os
         from safetensors import safe_open
         cfg = HifiGanConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
@@ -103,7 +105,7 @@ class HifiGanEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device)
+        return cls(cfg, w, device, dtype=dtype)
 
     @property
     def config(self):   # the pipeline reads vocoder.config.{upsample_rates, sampling_rate, model_in_dim} (custom_ad.py:490-500)
@@ -117,7 +119,7 @@ class HifiGanEngine:
         if c.normalize_before:
             mel = (mel - w["mean"]) / w["scale"]
         slope = c.leaky_relu_slope
-        x = mel.to(BF16).contiguous()
+        x = mel.to(self.dtype).contiguous()
         # conv_pre; its output is only ever read through the first leaky-ReLU, so that is fused here
         h = ops.conv1d(x, w["conv_pre.weight"], bias=w["conv_pre.bias"], pad=3, act="leaky_relu", act_param=slope)
         nk = len(c.resblock_kernel_sizes)
