@@ -38,6 +38,34 @@ def test_llama_forward_and_greedy_match_reference(golden_dir, seed):
     assert torch.allclose(step_logits, torch.from_numpy(z["step_logits"]), atol=5e-4, rtol=1e-4)
 
 
+def load_llama_d128(golden_dir, k):
+    """Reference-generated head_dim-128 fixture k: weights are regenerated from the recorded seed (checksum-guarded)."""
+    z = np.load(os.path.join(golden_dir, f"llama_ref_d128_{k}.npz"))
+    cfg = LlamaCfg(**json.loads(str(z["cfg"])))
+    w = LlamaOracle.random_weights(cfg, seed=int(z["seed"]), std=float(z["std"]))
+    wsum = sum(float(v.double().abs().sum()) for v in w.values())
+    assert abs(wsum - float(z["wsum"])) <= 1e-9 * float(z["wsum"]), "random_weights no longer reproduces the fixture's weights"
+    return z, cfg, w
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_llama_d128_forward_and_greedy_match_reference(golden_dir, k):
+    """The oracle against the reference's own LlamaForCausalLM at head_dim 128 (the HIP decode kernels' size)."""
+    z, cfg, w = load_llama_d128(golden_dir, k)
+    assert float(z["margins"].min()) >= 0.1
+    m = LlamaOracle(cfg, w)
+    ids = torch.from_numpy(z["ids"])
+    pos = torch.arange(ids.shape[1])[None].expand(ids.shape[0], -1)
+    logits, _, hid = m.forward(ids, pos, None, None, all_hidden=True)
+    assert torch.allclose(logits, torch.from_numpy(z["logits0"]), atol=5e-4, rtol=1e-4)
+    ref_h = torch.from_numpy(z["hiddens"])
+    for l in range(cfg.layers + 1):
+        assert torch.allclose(hid[l], ref_h[l], atol=5e-4, rtol=1e-4), f"hidden state {l}"
+    gen, step_logits = m.greedy(ids, 16, return_logits=True)
+    assert torch.equal(gen, torch.from_numpy(z["tokens"]))
+    assert torch.allclose(step_logits, torch.from_numpy(z["step_logits"]), atol=2e-3, rtol=1e-4)
+
+
 def test_llama_ops_match_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "llama_ops_ref.npz"))
     t = lambda k: torch.from_numpy(z[k])

@@ -7,8 +7,10 @@ value measured on MI355X + 20 % (round 2; the tests print their measured value a
     (test_unet_blocks_match_oracle)
   * a whole evaluation chains ~25 blocks -> sqrt(25) * 3e-3 ~ 1.5e-2: measured 1.44 - 1.58e-2, bound 1.9e-2 (FreeU 1.96e-2 -> 2.4e-2)
   * latents after a coarse 6-8 step loop: measured 2.4 - 2.7e-2 (each coarse step weighs eps heavily), bound 3.2e-2.
-north_star asks for 1e-3 relative on the latents; a bf16 tensor alone is only exact to 2e-3, so that target needs
-an fp32 residual stream -- tracked in DESIGN.md ("numerics"), not asserted here.
+Every comparison runs in both engine dtypes: bf16 and f16 (IEEE half: the reference's own torch_dtype, spider_decoder.py:109;
+half-ulp 2^-12 = 2.4e-4, i.e. 8x finer than bf16). north_star asks for 1e-3 relative on the latents: the f16 engine measures
+1.5e-3 .. 2e-3 per evaluation (the reference's own graph run in torch.float16 is at 1.6 - 1.9e-3 from fp32), bf16 1.5e-2;
+DESIGN.md section 4 holds the table.
 """
 import pytest
 import torch
@@ -16,23 +18,29 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-# measured on MI355X (printed by the tests as MEASURED ...) + 20 %: one UNet evaluation 1.44 - 1.58e-2, FreeU 1.96e-2, loops 2.4 - 2.7e-2
-UNET_STEP_BOUND = 1.9e-2
-FREEU_BOUND = 2.4e-2
-LOOP_BOUND = 3.2e-2
+# measured on MI355X (printed by the tests as MEASURED ...) + 20 %.
+# bf16: one UNet evaluation 1.44 - 1.58e-2, FreeU 1.96e-2, loops 2.4 - 2.7e-2, single blocks 1.7 - 6.0e-3
+# f16 : one UNet evaluation, FreeU, loops and blocks 8x below that (round 3 measurements in DESIGN.md section 4)
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+UNET_STEP_BOUND_DT = {"bf16": 1.9e-2, "f16": 2.5e-3}
+FREEU_BOUND_DT = {"bf16": 2.4e-2, "f16": 3.2e-3}
+LOOP_BOUND_DT = {"bf16": 3.2e-2, "f16": 4.2e-3}
+BLOCK_BOUND_DT = {"bf16": 8e-3, "f16": 1.1e-3}
+UNET_STEP_BOUND = UNET_STEP_BOUND_DT["bf16"]
 
 
 def _rel(a, b):
     return float((a.float().cpu() - b).norm() / b.norm())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("sdxl_like", [False, True])
-def test_unet_step_matches_oracle(dev, sdxl_like):
+def test_unet_step_matches_oracle(dev, sdxl_like, dtype):
     from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
     from spider_amd.unet import UNetConfig, UNetEngine
     ocfg = UNetCfg.tiny(sdxl_like)
     w = random_unet_weights(ocfg, seed=1)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype])
     g = torch.Generator().manual_seed(2)
     B2, hh, ww = 2, 16, 24
     x = torch.randn(B2, 4, hh, ww, generator=g).bfloat16().float()
@@ -44,18 +52,19 @@ def test_unet_step_matches_oracle(dev, sdxl_like):
     oracle = UNetOracle(ocfg, w)
     ts = torch.tensor([981, 500, 21])
     eng.prepare(ts, enc.to(dev), added)
-    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(DT[dtype])
     for i, t in enumerate(ts):
         ref = oracle.forward(x, t, enc, added)
         eager = eng.step(xn, i, use_graph=False).permute(0, 3, 1, 2)
         graph = eng.step(xn, i, use_graph=True).permute(0, 3, 1, 2)
         assert torch.equal(eager.cpu(), graph.cpu()), "hipGraph replay must be bit-identical to eager launches"
         r = _rel(eager, ref)
-        print(f"MEASURED unet_step sdxl_like={sdxl_like} t={int(t)} rel={r:.5f}")
-        assert r < UNET_STEP_BOUND, f"t={int(t)}: rel L2 {r:.4f}"
+        print(f"MEASURED unet_step dtype={dtype} sdxl_like={sdxl_like} t={int(t)} rel={r:.5f}")
+        assert r < UNET_STEP_BOUND_DT[dtype], f"t={int(t)}: rel L2 {r:.4f}"
 
 
-def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch, dtype):
     """8-head config (SD-v1.5's head count): every cross-attention sub-block runs as the ONE-launch fused kernel with the prompt's
     K / V folded into the projections (spider_xattn_fused_bf16). Against the fp32 oracle, and against the unfused HIP path."""
     from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
@@ -66,21 +75,22 @@ def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
     x = torch.randn(2, 4, 16, 24, generator=g).bfloat16().float()
     enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
     ref = UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc)
-    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(DT[dtype])
+    UNET_STEP_BOUND = UNET_STEP_BOUND_DT[dtype]
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype])
     eng.prepare(torch.tensor([500]), enc.to(dev))
     assert len(eng.xf) == len(eng.cross_layers) > 0, "the 8-head config must take the fused cross-attention path"
     fused = eng.step(xn, 0, use_graph=False).permute(0, 3, 1, 2).clone()
     graph = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
     assert torch.equal(fused, graph)
     monkeypatch.setenv("SPIDER_XATTN_FUSE", "0")
-    eng2 = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng2 = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype])
     eng2.prepare(torch.tensor([500]), enc.to(dev))
     assert len(eng2.xf) == 0
     unfused = eng2.step(xn, 0, use_graph=False).permute(0, 3, 1, 2)
     r_f, r_u, d = _rel(fused, ref), _rel(unfused, ref), _rel(fused, unfused.float().cpu())
     print(f"rel L2 vs fp32 oracle: fused {r_f:.4f}  unfused {r_u:.4f}  fused-vs-unfused {d:.4f}")
-    assert r_f < UNET_STEP_BOUND and r_f < 1.3 * r_u + 2e-3
+    assert r_f < UNET_STEP_BOUND and r_f < 1.3 * r_u + 0.1 * UNET_STEP_BOUND
     # a second prompt re-folds in place: same buffers (a captured graph stays valid), new result
     ptrs = {l: f["mq_fm"].data_ptr() for l, f in eng.xf.items()}
     enc2 = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
@@ -90,18 +100,19 @@ def test_unet_step_with_fused_cross_attention_matches_oracle(dev, monkeypatch):
     assert _rel(again, UNetOracle(ocfg, w).forward(x, torch.tensor(500), enc2)) < UNET_STEP_BOUND
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("sdxl_like", [False, True])
-def test_unet_blocks_match_oracle(dev, sdxl_like):
+def test_unet_blocks_match_oracle(dev, sdxl_like, dtype):
     """Every block class in isolation (inputs rounded to bf16, taken from the oracle): one bf16 rounding of the block
     output is 2e-3 .. 4e-3 relative; the bound for a single block is 8e-3 (per-block assertions)."""
     from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
     from spider_amd import ops
     from spider_amd.unet import UNetConfig, UNetEngine
-    BF = torch.bfloat16
+    BF = DT[dtype]
     ocfg = UNetCfg.tiny(sdxl_like)
     w = random_unet_weights(ocfg, seed=1)
     orc = UNetOracle(ocfg, w)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=BF)
     g = torch.Generator().manual_seed(2)
     B2 = 2
     x = torch.randn(B2, 4, 16, 24, generator=g).bfloat16().float()
@@ -148,9 +159,9 @@ def test_unet_blocks_match_oracle(dev, sdxl_like):
     o = eng._cross_attn(b, y.to(dev).to(BF), ocfg.heads[ti])
     errs["cross_attn"] = _rel(ops.gemm(o, eng.w[b + ".attn2.to_out.0.weight"], bias=eng.w[b + ".attn2.to_out.0.bias"]),
                               orc.attention(b + ".attn2", y, enc, ocfg.heads[ti]))
-    print("per-block rel L2:", {k: round(v, 5) for k, v in errs.items()})
+    print(f"MEASURED per-block rel L2 dtype={dtype}:", {k: round(v, 5) for k, v in errs.items()})
     for k, v in errs.items():
-        assert v < 8e-3, (k, v)
+        assert v < BLOCK_BOUND_DT[dtype], (k, v)
 
 
 def test_unet_step_vs_bf16_reference_emulation(dev):
@@ -176,8 +187,9 @@ def test_unet_step_vs_bf16_reference_emulation(dev):
     assert e_hip < 1.5 * e_emul + 2e-3, (e_hip, e_emul)   # not worse than a bf16 run of the reference graph itself
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("sched_name,steps", [("pndm", 8), ("ddim", 6)])
-def test_denoise_loop_matches_oracle(dev, sched_name, steps):
+def test_denoise_loop_matches_oracle(dev, sched_name, steps, dtype):
     from oracle.unet import DDIMOracle, PNDMOracle, UNetCfg, UNetOracle, denoise_loop, random_unet_weights
     from spider_amd.schedulers import DDIMScheduler, PNDMScheduler
     from spider_amd.unet import UNetConfig, UNetEngine, denoise
@@ -187,16 +199,17 @@ def test_denoise_loop_matches_oracle(dev, sched_name, steps):
     lat = torch.randn(1, 4, 16, 16, generator=g)
     enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
     ref = denoise_loop(UNetOracle(ocfg, w), PNDMOracle() if sched_name == "pndm" else DDIMOracle(), lat, enc, 7.5, steps)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype])
     sched = PNDMScheduler() if sched_name == "pndm" else DDIMScheduler()
     got = denoise(eng, sched, lat.to(dev), enc.to(dev), 7.5, steps)
     assert got.shape == lat.shape
     r = _rel(got, ref)
-    print(f"MEASURED denoise_loop {sched_name} rel={r:.5f}")
-    assert r < LOOP_BOUND, f"latents rel L2 {r:.5f}"
+    print(f"MEASURED denoise_loop dtype={dtype} {sched_name} rel={r:.5f}")
+    assert r < LOOP_BOUND_DT[dtype], f"latents rel L2 {r:.5f}"
 
 
-def test_freeu_matches_oracle(dev):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_freeu_matches_oracle(dev, dtype):
     from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
     from spider_amd.unet import UNetConfig, UNetEngine
     ocfg = UNetCfg.tiny(True)
@@ -207,13 +220,13 @@ def test_freeu_matches_oracle(dev):
     added = dict(text_embeds=torch.randn(2, 64, generator=g).bfloat16().float(),
                  time_ids=torch.tensor([[128, 128, 0, 0, 128, 128]] * 2, dtype=torch.float32))
     oracle = UNetOracle(ocfg, w); oracle.freeu = (0.6, 0.4, 1.1, 1.2)
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev); eng.freeu = (0.6, 0.4, 1.1, 1.2)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype]); eng.freeu = (0.6, 0.4, 1.1, 1.2)
     eng.prepare(torch.tensor([300]), enc.to(dev), added)
-    got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), 0, use_graph=False).permute(0, 3, 1, 2)
+    got = eng.step(x.permute(0, 2, 3, 1).contiguous().to(dev).to(DT[dtype]), 0, use_graph=False).permute(0, 3, 1, 2)
     ref = oracle.forward(x, torch.tensor(300), enc, added)
     r_on = _rel(got, ref)
-    print(f"MEASURED freeu rel={r_on:.5f}")
-    assert r_on < FREEU_BOUND
+    print(f"MEASURED freeu dtype={dtype} rel={r_on:.5f}")
+    assert r_on < FREEU_BOUND_DT[dtype]
     oracle.freeu = None
     r_off = _rel(got, oracle.forward(x, torch.tensor(300), enc, added))
     assert r_off > 3 * r_on, (r_on, r_off)  # FreeU really changes the result
