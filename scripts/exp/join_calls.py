@@ -20,9 +20,11 @@ def pop():
     return k
 for c in reversed(calls):
     name = c[0]
-    k = pop(); t = k[1]; names = [k[0].split("(")[0]]
+    k = pop(); t = k[1]; names = [k[0].split("(")[0].replace("void ", "")]
     if "splitk_reduce" in k[0] or "gn_apply" in k[0]:
         k2 = pop(); t += k2[1]; names.insert(0, k2[0].split("(")[0])
+    if "gemm_ln" in name and i >= 0 and "ln_row_stats" in ks[i][0]:      # the 256^2 LN form: row statistics launched first
+        k3 = pop(); t += k3[1]; names.insert(0, k3[0].split("(")[0])
     out.append((name, [a for a in c[1:] if a is not None], t, names))
 out.reverse()
 agg = defaultdict(lambda: [0, 0.0, None])

@@ -10,7 +10,7 @@ Produces
                              manual KV-cache loop, per-step logits, top-2 margins
   llama_ref_d128_{0,1,2}.npz the same reference class at head_dim 128 (the HIP decode kernels' size): ids, logits, hidden states,
                              16 greedy tokens, margins; weights are regenerated from the recorded seed (checksum inside);
-                             the 3 seeds of 400 with the largest minimum top-2 margin (>= 0.1)
+                             the 3 seeds of 3000 with the largest minimum top-2 margin (>= 0.1)
   llama_ops_ref.npz          per-op vectors: LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, LlamaAttention
   routing_ref.json           SpiderDecoder.get_llm_text_res / get_llm_text_modality / generate (stub decoders)
                              and clean_prompt_array / extract_story_elements / extract_answer on 40+ strings
@@ -138,11 +138,11 @@ def gen_llama():
 # Seeds are chosen so that every one of the 2 x 16 greedy decisions has a top-2 margin >= 0.1 of the reference's fp32 logits:
 # the bf16 engine must then reproduce ALL token ids (north_star: routing bit-exact).
 D128_CFG = dict(hidden=256, layers=2, n_q=2, n_kv=2, head_dim=128, inter=512, vocab=331, rope_theta=10000.0, eps=1e-6, max_pos=128)
-D128_STD = 0.2
+D128_STD = 0.08
 D128_PROMPT = 12
 
 
-def gen_llama_d128(n_keep=3, seed_range=range(0, 400)):
+def gen_llama_d128(n_keep=3, seed_range=range(0, 3000)):
     ml = load_by_path("ref_modeling_llama", f"{REF}/spider/models/modeling_llama.py")
     from transformers import LlamaConfig
     cfg = LlamaCfg(**D128_CFG)
