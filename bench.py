@@ -35,6 +35,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+MFMA_PEAK_TF = 2500.0  # dense bf16 / f16 MFMA peak
+# 16-bit format of the diffusion engines (UNet / CLIP / VAE): f16 = the reference's torch_dtype (spider_decoder.py:109,114);
+# bf16 on request. Same MFMA rate, same bytes: the two run at the same speed. The LLM is bf16.
+DIFF_DT = torch.float16
 
 
 def parse():
@@ -50,10 +54,16 @@ def parse():
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--serial-decoders", action="store_true",
+                   help="any2many: one SpiderDecoder.generate call per response (the reference's contract) instead of generate_batch")
     p.add_argument("--throughput-batch", type=int, default=8,
                    help="also report (outside the timed region, as an extra field) the rate with this many prompts per GPU; 0 = skip")
     p.add_argument("--llm", default="qwen25_7b", choices=["qwen25_7b", "llama3_8b"])
+    p.add_argument("--diffusion-dtype", default="f16", choices=["f16", "bf16"],
+                   help="16-bit format of the UNet / text-encoder / VAE engines (f16 = the reference's torch_dtype)")
     a = p.parse_args()
+    global DIFF_DT
+    DIFF_DT = torch.float16 if a.diffusion_dtype == "f16" else torch.bfloat16
     if a.batch is None:
         a.batch = 8 if a.workload == "any2many" else 1
     return a
@@ -101,14 +111,14 @@ class Responder:
         cfg = getattr(LLMConfig, args.llm)()
         self.max_batch = max(args.batch, min(args.throughput_batch, 8))
         self.llm = LlamaEngine.random_init(cfg, device, max_batch=self.max_batch, max_len=args.prompt_len + args.new_tokens + 8, seed=0)
-        self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1)
+        self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1, dtype=DIFF_DT)
         self.sched = PNDMScheduler()
         self.text_enc = self.vae = None
         try:
             from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
             from spider_amd.vae import VAEConfig, VAEDecoderEngine
-            self.text_enc = CLIPTextEngine.random_init(CLIPTextConfig.sd15(), device, seed=2)
-            self.vae = VAEDecoderEngine.random_init(VAEConfig.sd15(), device, seed=3)
+            self.text_enc = CLIPTextEngine.random_init(CLIPTextConfig.sd15(), device, seed=2, dtype=DIFF_DT)
+            self.vae = VAEDecoderEngine.random_init(VAEConfig.sd15(), device, seed=3, dtype=DIFF_DT)
         except ImportError:
             pass
         g = torch.Generator(device=device).manual_seed(2047)  # seed echoes Comic_Generation.py:387
@@ -117,7 +127,7 @@ class Responder:
         self.latents0 = torch.randn(mb, 4, 64, 64, generator=g, device=device)
         self.clip_ids_u = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
         self.clip_ids_c = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
-        self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(torch.bfloat16)
+        self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(DIFF_DT)
 
     def includes(self):
         inc = ["llm_prefill", "llm_decode", "routing", "unet_denoise_loop"]
@@ -177,13 +187,14 @@ class AnyToManyResponder:
         dev = device
         cfg = getattr(LLMConfig, args.llm)()
         self.llm = LlamaEngine.random_init(cfg, dev, max_batch=min(args.batch, 8), max_len=args.prompt_len + args.new_tokens + 8, seed=0)
-        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2),
-                                     CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 3), FakeTokenizer(40000))
-        ad = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), dev, 4), ClapTextEngine.random_init(ClapTextConfig(), dev, 5),
-                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6),
-                              DDIMScheduler(beta_start=0.0015, beta_end=0.0195), HifiGanEngine.random_init(HifiGanConfig.audioldm(), dev, 7))
-        vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9),
-                                   CLIPTextEngine.random_init(CLIPTextConfig(49408, 1024, 23, 16, 4096, 77, 1e-5, "gelu"), dev, 10),
+        D = DIFF_DT
+        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1, dtype=D), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2, dtype=D),
+                                     CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 3, dtype=D), FakeTokenizer(40000))
+        ad = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), dev, 4, dtype=D), ClapTextEngine.random_init(ClapTextConfig(), dev, 5, dtype=D),
+                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6, dtype=D),
+                              DDIMScheduler(beta_start=0.0015, beta_end=0.0195), HifiGanEngine.random_init(HifiGanConfig.audioldm(), dev, 7, dtype=D))
+        vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8, dtype=D), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9, dtype=D),
+                                   CLIPTextEngine.random_init(CLIPTextConfig(49408, 1024, 23, 16, 4096, 77, 1e-5, "gelu"), dev, 10, dtype=D),
                                    FakeTokenizer(40000))
         self.decoder = SpiderDecoder(pipelines={"IMAGE": sd, "AUDIO": ad, "VIDEO": vd}, device=str(dev))
         g = torch.Generator(device=dev).manual_seed(2047 + rank)
@@ -204,12 +215,18 @@ class AnyToManyResponder:
         host = toks.cpu()
         t1 = time.perf_counter()
         imgs, auds, vids = [], [], []
+        samples = []
         for b in range(B):
             head = " ".join(str(int(t)) for t in host[b, :6])
             # random-init weights emit no tags: the synthetic response carries exactly one caption per modality
-            text = f"Sure. <IMAGE>scene {head}</IMAGE> <AUDIO>sound {head}</AUDIO> <VIDEO>clip {head}</VIDEO>"
-            answers, preds, ptext = routing.new_outputs()
-            answers, preds, ptext = self.decoder.generate({"llm_text_all": [text]}, answers, preds, ptext)
+            samples.append({"llm_text_all": [f"Sure. <IMAGE>scene {head}</IMAGE> <AUDIO>sound {head}</AUDIO> <VIDEO>clip {head}</VIDEO>"]})
+        # Decoders-Controller, batched entry point: the rank's B responses are routed together and every diffusion decoder runs
+        # ONCE at CFG batch 2 x B (SpiderDecoder.generate_batch; per-sample containers as in the reference's generate)
+        if a.serial_decoders:
+            outs = [self.decoder.generate(s, *routing.new_outputs()) for s in samples]
+        else:
+            outs = self.decoder.generate_batch(samples)
+        for answers, preds, ptext in outs:
             assert len(preds["IMAGE"]) == 1 and len(preds["AUDIO"]) == 1 and len(preds["VIDEO"]) == 1
             imgs.append(torch.from_numpy(np.asarray(preds["IMAGE"][0], dtype=np.uint8)))                         # [512, 512, 3]
             auds.append(torch.from_numpy(np.asarray(preds["AUDIO"][0], dtype=np.float32).reshape(-1)))           # [80000]
@@ -282,8 +299,8 @@ def measure_mfma_roofline(device):
     320 -> 320 channels, CFG batch 2: M = 8192 output pixels, N = 320, K = 2880; the LDS-DMA kernel on 64-row tiles, no split-K).
     Algorithmic flops per call = 2*M*N*K; timed live with HIP events over back-to-back calls on torch's current stream."""
     from spider_amd import ops
-    x = torch.randn(2, 64, 64, 320, device=device).to(torch.bfloat16)
-    w = (torch.randn(320, 3, 3, 320, device=device) * 0.02).to(torch.bfloat16)
+    x = torch.randn(2, 64, 64, 320, device=device).to(DIFF_DT)
+    w = (torch.randn(320, 3, 3, 320, device=device) * 0.02).to(DIFF_DT)
     for _ in range(5):
         ops.conv2d(x, w)
     torch.cuda.synchronize(device)
@@ -347,7 +364,7 @@ def measure_attention_roofline(device):
     from spider_amd import ops
     N, heads, d, B = 4096, 8, 40, 2
     C = heads * d
-    qkv = torch.randn(B, N, 3 * C, device=device).to(torch.bfloat16)
+    qkv = torch.randn(B, N, 3 * C, device=device).to(DIFF_DT)
     f = lambda: ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
     for _ in range(3):
         f()
@@ -421,7 +438,7 @@ def cpu_baseline(args):
     L = full.layers
     n_unet = args.denoise_steps + 1
     t_resp = L * t_prefill_layer + t_head1 + args.new_tokens * (L * t_dec_layer + t_head1) + n_unet * t_unet
-    return {"value": round(1.0 / t_resp, 6), "unit": "responses/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / t_resp, 6), "unit": "responses/s", "cores": cores, "kind": "port", "extrapolated": True,
             "sample": (f"oracle fp32 on {cores} host threads: 1 of {L} decoder layers over the {S}-token prompt "
                        f"({t_prefill_layer:.2f}s) + {nd} decode tokens through 1 layer at context {S} ({t_dec_layer * 1e3:.1f} ms/layer-token) "
                        f"+ lm_head ({t_head1 * 1e3:.0f} ms) + 1 SD-v1.5 UNet step at [2,4,64,64] ({t_unet:.2f}s); extrapolated "
@@ -440,7 +457,7 @@ def measure_story_attention_roofline(device):
     from spider_amd.story import pack_keep_bits
     N, img, heads, C = 2304, 4, 10, 640
     L = img * N
-    qkv = torch.randn(2, L, 3 * C, device=device).to(torch.bfloat16)
+    qkv = torch.randn(2, L, 3 * C, device=device).to(DIFF_DT)
     keep = torch.rand(L, generator=torch.Generator().manual_seed(0)) < 0.5
     bits = pack_keep_bits(keep).to(device)
     ki, tl = ops.story_key_lists(bits, L, N, 0, img, 0)
@@ -496,12 +513,12 @@ def other_decoders(device):
     g = torch.Generator(device=device).manual_seed(7)
     # ---- SDXL story step: 768^2, CFG batch 8 (4 panels), FreeU, all 36 up-block processors on the consistent path
     from spider_amd.story import ConsistentSelfAttention, StoryState
-    sdxl = UNetEngine.random_init(UNetConfig.sdxl(), device, seed=11)
+    sdxl = UNetEngine.random_init(UNetConfig.sdxl(), device, seed=11, dtype=DIFF_DT)
     sdxl.freeu = (0.6, 0.4, 1.1, 1.2)
     hw = 96
-    x = torch.randn(8, hw, hw, 4, generator=g, device=device).to(torch.bfloat16)
-    enc = torch.randn(8, 77, 2048, generator=g, device=device).to(torch.bfloat16)
-    added = dict(text_embeds=torch.randn(8, 1280, generator=g, device=device).to(torch.bfloat16),
+    x = torch.randn(8, hw, hw, 4, generator=g, device=device).to(DIFF_DT)
+    enc = torch.randn(8, 77, 2048, generator=g, device=device).to(DIFF_DT)
+    added = dict(text_embeds=torch.randn(8, 1280, generator=g, device=device).to(DIFF_DT),
                  time_ids=torch.tensor([[768, 768, 0, 0, 768, 768]] * 8, dtype=torch.float32))
     ts = DDIMScheduler().set_timesteps(50)
     sdxl.prepare(ts, enc, added)
@@ -529,11 +546,11 @@ def other_decoders(device):
     torch.cuda.empty_cache()
     # ---- zeroscope UNet3D step: CFG batch 2 x 16 frames at 40x72
     from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
-    u3 = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), device, seed=12)
-    enc = torch.randn(2, 77, 1024, generator=g, device=device).to(torch.bfloat16)
+    u3 = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), device, seed=12, dtype=DIFF_DT)
+    enc = torch.randn(2, 77, 1024, generator=g, device=device).to(DIFF_DT)
     ts = DDIMScheduler().set_timesteps(40)
     u3.prepare(ts, enc, frames=16)
-    x2 = ops.latent_to_nhwc(torch.randn(16, 4, 40, 72, generator=g, device=device), reps=2)
+    x2 = ops.latent_to_nhwc(torch.randn(16, 4, 40, 72, generator=g, device=device), reps=2, dtype=DIFF_DT)
     u3.step(x2, 0)
     out["unet3d_step_ms"] = round(_ev_ms(lambda i: u3.step(x2, i), 5, device), 2)
     del u3
@@ -543,9 +560,10 @@ def other_decoders(device):
     from spider_amd.pipelines import AudioLDMPipeline
     from spider_amd.vae import VAEConfig, VAEDecoderEngine
     from spider_amd.vocoder import HifiGanConfig, HifiGanEngine
-    pipe = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), device, 1), ClapTextEngine.random_init(ClapTextConfig(), device, 2),
-                            None, UNetEngine.random_init(UNetConfig.audioldm_l(), device, 3), DDIMScheduler(beta_start=0.0015, beta_end=0.0195),
-                            HifiGanEngine.random_init(HifiGanConfig.audioldm(), device, 4))
+    pipe = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), device, 1, dtype=DIFF_DT),
+                            ClapTextEngine.random_init(ClapTextConfig(), device, 2, dtype=DIFF_DT),
+                            None, UNetEngine.random_init(UNetConfig.audioldm_l(), device, 3, dtype=DIFF_DT), DDIMScheduler(beta_start=0.0015, beta_end=0.0195),
+                            HifiGanEngine.random_init(HifiGanConfig.audioldm(), device, 4, dtype=DIFF_DT))
     ids = torch.randint(3, 50000, (1, 12)); ids[0, 0] = 0; ids[0, -1] = 2
     emb = pipe.text_encoder.text_embeds(torch.cat([ids, ids]), normalize=True)
     call = lambda: pipe(prompt_embeds=emb[1:], negative_prompt_embeds=emb[:1], audio_length_in_s=5.0, num_inference_steps=40,
@@ -556,7 +574,7 @@ def other_decoders(device):
     call()
     torch.cuda.synchronize(device)
     out["audio_clip_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
-    x = torch.randn(2, 125, 16, 8, generator=g, device=device).to(torch.bfloat16)
+    x = torch.randn(2, 125, 16, 8, generator=g, device=device).to(DIFF_DT)
     pipe.unet.step(x, 0)
     out["audio_unet_step_ms"] = round(_ev_ms(lambda i: pipe.unet.step(x, i), 10, device), 3)
     out["audio_clip"] = "AudioLDM-L shapes, 5.0 s, 40 DDIM steps, CFG, mel VAE + HiFi-GAN; CLAP text (2 prompts) outside"
@@ -591,6 +609,54 @@ def llama8b_numbers(device):
             "decode_hbm_frac": round((wbytes + kv) * tok_s / 1e9 / HBM_PEAK_GBS, 4), "weight_bytes_per_token": wbytes}
 
 
+def run_timed(resp, args, rank, world, device):
+    """The contract's timed region, shared by every workload (and driven on gloo with a stand-in responder by
+    tests/test_dp_gloo.py): W untimed warm-up steps, then EXACTLY K steps between barrier + device synchronize on both sides;
+    a step = this rank's responses + the ONE gather of their padded outputs to rank 0; time = MAX over ranks. Afterwards every
+    rank leaves the process group, BEFORE rank 0's secondary timings and CPU baseline (tens of seconds), so that no rank waits in a
+    collective on a slow host. Returns (seconds, rank 0's last gathered payload | None, {"world_size", "backend"})."""
+    a2m = args.workload == "any2many"
+    is_cuda = getattr(device, "type", "cpu") == "cuda"
+
+    def sync():
+        if is_cuda:
+            torch.cuda.synchronize(device)
+
+    def one_step():
+        if a2m:
+            return dp_mod().gather_padded(resp.respond(), args.batch, rank, world, dst=0)
+        toks, out = resp.respond()
+        return dp_mod().gather_padded({"tokens": toks, "out": out}, args.batch, rank, world, dst=0)
+
+    g = None
+    for _ in range(args.warmup):
+        g = one_step()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = one_step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dist_info = {"world_size": 1, "backend": None}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
+        dist.barrier()
+        dist.destroy_process_group()
+    return dt, g, dist_info
+
+
+def dp_mod():
+    from spider_amd import dp
+    return dp
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # self-launch, decided before any GPU call
@@ -605,36 +671,14 @@ def main():
     a2m = args.workload == "any2many"
     resp = AnyToManyResponder(args, device, rank) if a2m else Responder(args, device)
 
-    def one_step():
-        if a2m:
-            return dp.gather_padded(resp.respond(), args.batch, rank, world, dst=0)
-        toks, out = resp.respond()
-        return dp.gather_padded({"tokens": toks, "out": out}, args.batch, rank, world, dst=0)
-
-    g = None
-    for _ in range(args.warmup):
-        g = one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g = one_step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, g, dist_info = run_timed(resp, args, rank, world, device)
 
     if rank == 0:
         a = args
         total = world * args.batch * args.steps
         base = {"value": round(total / dt, 4), "unit": "responses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "data": "synthetic"}
+                "dtype": "bf16", "diffusion_dtype": args.diffusion_dtype, "data": "synthetic", "dist": dist_info}
         if g is not None:
             base["gathered"] = {k: list(v.shape) for k, v in g.items()}
             base["gather_bytes_per_rank"] = int(sum(v[0].numel() * v[0].element_size() for v in g.values()))
@@ -657,6 +701,7 @@ def main():
                 extra.update(other_decoders(device))
                 extra["llama3_8b"] = llama8b_numbers(device)
             cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # reported at N=1 only
+            extra["roofline_response"] = response_roofline(args, extra, base["ms_per_step"])
             line = {"metric": "multimodal responses/sec (text->text+image)", **base,
                     "config": {"workload": f"SpiderFree text->text+1x512^2 image: {args.llm} text-decoder shapes, prompt {a.prompt_len} + "
                                            f"{a.new_tokens} greedy tokens, routing, SD-v1.5 UNet 64x64 latent, PNDM {a.denoise_steps} steps "
@@ -665,9 +710,28 @@ def main():
                                "weights": "random-init of the true shapes"},
                     "roofline": roof, "cpu_baseline": cpu, **extra}
             print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def response_roofline(args, extra, ms_per_step):
+    """Composite roofline of ONE response: the sum of every stage's algorithmic floor -- decode bytes / HBM peak,
+    prefill / UNet / VAE flops / MFMA peak -- over the measured time of the step. The per-kernel objects (`roofline`,
+    `roofline_unet_*`, `roofline_prefill_gemm`) say how close the best kernels are; this one says how close the RESPONSE is."""
+    from spider_amd.llm import LLMConfig
+    c = getattr(LLMConfig, args.llm)()
+    params = c.layers * (c.hidden * (c.n_q + 2 * c.n_kv) * c.head_dim + c.n_q * c.head_dim * c.hidden + 3 * c.hidden * c.inter) + c.vocab * c.hidden
+    S, T, B = args.prompt_len, args.new_tokens, args.batch
+    kv_per_tok = 2 * c.layers * c.n_kv * c.head_dim * 2
+    decode_bytes = T * 2 * params + B * sum(kv_per_tok * (S + t) for t in range(T))            # weights once per step, KV per row
+    prefill_flops = B * (2 * params * S + 4 * c.layers * c.n_q * c.head_dim * S * S / 2)
+    unet_flops_total = B * (args.denoise_steps + 1) * 2 * extra["unet_flops_per_sample"]["total"] * 1e9
+    vae_flops = B * 1.27e12                                                                    # AutoencoderKL decode at 512^2 (DESIGN.md section 3)
+    floors = {"decode_ms": decode_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "prefill_ms": prefill_flops / (MFMA_PEAK_TF * 1e12) * 1e3,
+              "unet_ms": unet_flops_total / (MFMA_PEAK_TF * 1e12) * 1e3, "vae_ms": vae_flops / (MFMA_PEAK_TF * 1e12) * 1e3}
+    floor = sum(floors.values())
+    return {"floor_ms": round(floor, 1), "measured_ms": ms_per_step, "frac": round(floor / ms_per_step, 4),
+            "floors_ms": {k: round(v, 1) for k, v in floors.items()},
+            "algorithmic": {"decode_hbm_bytes": int(decode_bytes), "prefill_flops": prefill_flops, "unet_flops": unet_flops_total, "vae_flops": vae_flops},
+            "peaks": {"hbm_GBps": HBM_PEAK_GBS, "mfma_TFLOPs": MFMA_PEAK_TF}}
 
 
 def text_image_extras(args, resp, device):
@@ -679,7 +743,7 @@ def text_image_extras(args, resp, device):
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # UNet step ms (BASELINE.json's second metric): graph replay of one CFG-batch-2 evaluation
-    x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2)
+    x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2, dtype=DIFF_DT)
     ts = resp.sched.set_timesteps(a.denoise_steps)
     resp.unet.prepare(ts, resp.enc_synth[:2].contiguous())
     resp.unet.step(x2, 0)

@@ -15,6 +15,7 @@
  */
 #ifndef SPIDER_HIP_H
 #define SPIDER_HIP_H
+#define SPIDER_ABI_VERSION 2   /* 2: w_tiled argument of the GEMM / conv entry points; *_f16 instantiations */
 
 #ifdef __cplusplus
 extern "C" {
@@ -109,7 +110,7 @@ int spider_lm_head_argmax_fm_bf16(const void* Wfm, const void* x, int* out_ids, 
  * Prefill projections (modeling_llama3.py:186-313), diffusers Attention/FeedForward/proj linears. */
 int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, void* ws, long ws_bytes, void* stream);
+                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 
 /* C = LayerNorm(A; gamma, beta, eps) . W^T + bias (+res) in ONE launch (act 0), or its GEGLU form (act 4, as above).
  * Replaces BasicTransformerBlock.norm1 / norm2 / norm3 + the projection that consumes it (attn1 to_q/k/v, attn2 to_q,
@@ -120,7 +121,7 @@ int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const voi
  * ws (optional, >= ceil(M/256)*256*8 bytes): lets large problems run on the 256x256 LDS-DMA kernel, whose row statistics
  * come from a preceding one-wave-per-row pass instead of the staging loop. */
 int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
-                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream);
+                        int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream);
 
 /* Fused cross-attention sub-block of BasicTransformerBlock (diffusers-0.25 attention.py, reached from custom_sd.py:634-639):
  *   out = x + to_out( softmax( to_q(LayerNorm(x)) K^T / sqrt(d) ) V )      for 8 heads and <= 80 text keys, ONE launch.
@@ -138,7 +139,7 @@ int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm,
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream);
+                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 
 /* General NHWC conv as implicit GEMM: rectangular / dilated kernels (w OHWI [Cout,kh,kw,Cin], Cin % 8 == 0), a fused
  * nearest upsample to an explicit size up_h x up_w in (in, 2*in] (diffusers Upsample2D with `upsample_size`, reached when
@@ -149,7 +150,7 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
 int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, void* ws, long ws_bytes, void* stream);
+                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 
 /* fused attention (prefill causal GQA: modeling_llama3.py:202-237; UNet self/cross attention:
  * StoryDiffusion/utils/gradio_utils.py:400-472; consistent self-attention with the column keep vector of
@@ -257,19 +258,19 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  * exist in bf16 only (the reference's LLM dtype). */
 int spider_gemm_f16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, void* ws, long ws_bytes, void* stream);
+                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_gemm_ln_f16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
-                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream);
+                        int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_xattn_fused_f16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
                             const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
                             void* stream);
 int spider_conv2d_nhwc_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream);
+                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_conv_nhwc_ex_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, void* ws, long ws_bytes, void* stream);
+                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_attn_f16(const void* q, const void* k, const void* v, void* o,
                      long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
                      long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,

@@ -54,6 +54,12 @@ struct GemmArgs {
     // the UNet's 8192-row activations against 320..2560 output columns -- with m fastest every column tile re-streamed all of A
     // through its XCD's 4 MiB L2: FETCH_SIZE 58 MB per GEGLU projection whose operands are 7 MB)
     int n_fast;
+    // W layout: 0 = row-major [N, K] (nn.Linear / OHWI conv weights as stored); 1 = TILE-MAJOR copy [ceil(N/64)][ceil(K/64)][64 rows][64 k]
+    // (8 KiB per tile, zero-padded): a K tile of 64 weight rows is ONE contiguous 8 KiB read instead of 64 pieces of 128 B at a
+    // row stride of 2 K bytes. The weight-streaming problems of the UNet (16^2 / 8^2 maps: M = 512 / 128 rows against 3 - 59 MB of
+    // weights, every byte used once per step and cold in HBM) ran at ~2 TB/s on the strided form -- the same DRAM-granularity
+    // limit the decode path's fragment-major weights removed.
+    int w_tiled;
     // LayerNorm folded into the GEMM (LN instantiations): C = rstd[m] * (A.W'^T - mean[m] * colsum[n]) + colbias[n], with
     // W' = W * diag(gamma) (folded by the caller), colsum[n] = sum_k W'[n,k], colbias[n] = sum_k beta[k] W[n,k] + bias[n];
     // the row statistics of A (K = the whole normalised row) are accumulated by the block itself while it stages A.
@@ -74,6 +80,13 @@ __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
     if (p.act == 7) return tanhf(v);
     return v;
 }
+
+// byte offset of row n's first K tile in W, and the byte step from one K tile to the next (see GemmArgs::w_tiled)
+__device__ __forceinline__ uint32_t w_row_byte(const GemmArgs& p, int n) {
+    const uint32_t nk = (uint32_t)((p.K + BK - 1) / BK);
+    return p.w_tiled ? ((uint32_t)(n >> 6) * nk * 8192u + (uint32_t)(n & 63) * 128u) : (uint32_t)n * (uint32_t)p.K * 2u;
+}
+__device__ __forceinline__ uint32_t w_tile_step(const GemmArgs& p) { return p.w_tiled ? 8192u : (uint32_t)(BK * 2); }
 
 // bias / rowbias / activation / residual / scale on 4 consecutive columns of one row, then store
 // EPI selects what is compiled in: 0 = bias / rowbias / residual / scale only, 1 = + activation, 2 = GEGLU (kernel-level).
@@ -373,8 +386,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             ok = n < p.N;
         }
         w_inv[i] = ok ? 0u : 0xFFFFFFFFu;
-        w_base[i] = ok ? (uint32_t)n * (uint32_t)p.K * 2u + chunk * 16u : 0u;
+        w_base[i] = ok ? w_row_byte(p, n) + chunk * 16u : 0u;
     }
+    const uint32_t w_step = w_tile_step(p);
 
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WC; ++i) {
-            const uint32_t off = (w_base[i] + kbyte) | w_inv[i] | k_inv;
+            const uint32_t off = (w_base[i] + (uint32_t)kt * w_step) | w_inv[i] | k_inv;
             rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
         }
     };
@@ -654,8 +668,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         const bool ok = n < p.N && R < BN;
         w_gch[j] = (uint32_t)(slot ^ ((R >> 1) & 7));   // BM = 128 rows precede the W tile: (128 + R) >> 1 & 7 == R >> 1 & 7
         w_inv[j] = ok ? 0u : 0xFFFFFFFFu;
-        w_base[j] = ok ? (uint32_t)n * (uint32_t)p.K * 2u + w_gch[j] * 16u : 0u;
+        w_base[j] = ok ? w_row_byte(p, n) + w_gch[j] * 16u : 0u;
     }
+    const uint32_t w_step = w_tile_step(p);
 
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         for (int j = 0; j < WJ; ++j) {
             if (W_RAGGED && j == WJ - 1 && wave >= WP % 8) break;
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)w_gch[j] * 8)) >> 31) | t_inv;
-            const uint32_t off = (w_base[j] + kbyte) | w_inv[j] | k_inv;
+            const uint32_t off = (w_base[j] + (uint32_t)kt * w_step) | w_inv[j] | k_inv;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (BM / 8 + j * 8 + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -842,9 +857,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 n = (within >= 32 ? p.N : 0) + oc;
             }
             w_inv[h][j] = okn ? 0u : 0xFFFFFFFFu;
-            w_base[h][j] = okn ? (uint32_t)n * (uint32_t)p.K * 2u + gch[j] * 16u : 0u;
+            w_base[h][j] = okn ? w_row_byte(p, n) + gch[j] * 16u : 0u;
         }
     }
+    const uint32_t w_step = w_tile_step(p);
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
@@ -897,7 +913,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             } else {
-                off = (w_base[h][j] + kbyte) | w_inv[h][j] | k_inv;
+                off = (w_base[h][j] + (uint32_t)kt * w_step) | w_inv[h][j] | k_inv;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             }
         }
@@ -1090,8 +1106,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
         const int n = n0 + R;
         const bool okn = n < p.N;
         w_inv[j] = okn ? 0u : 0xFFFFFFFFu;
-        w_base[j] = okn ? (uint32_t)n * (uint32_t)p.K * 2u + gch[j] * 16u : 0u;
+        w_base[j] = okn ? w_row_byte(p, n) + gch[j] * 16u : 0u;
     }
+    const uint32_t w_step = w_tile_step(p);
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
@@ -1145,7 +1162,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             } else {
-                off = (w_base[j] + kbyte) | w_inv[j] | k_inv;
+                off = (w_base[j] + (uint32_t)kt * w_step) | w_inv[j] | k_inv;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             }
         }
@@ -1409,6 +1426,10 @@ void set_epilogue_ranges(GemmArgs& a) {
     a.rb_bytes = ok ? (uint32_t)rb : 0;
 }
 
+uint32_t tiled_bytes(int N, int K) {
+    return (uint32_t)((size_t)((N + 63) / 64) * ((K + BK - 1) / BK) * 8192);
+}
+
 int launch(GemmArgs a, long ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     static const int force_tile = env_int("SPIDER_GEMM_TILE"), force_splits = env_int("SPIDER_GEMM_SPLITS");  // tuning aid
@@ -1563,9 +1584,11 @@ extern "C" {
 
 // C = act(A[M,K] . W[N,K]^T + bias + rowbias[row / rows_per_group]) (+ res) , * out_scale
 // ldc applies to C, C32 and res. ws/ws_bytes: optional fp32 split-K workspace (NULL disables split-K).
+// w_tiled != 0: W is the tile-major copy [ceil(N/64)][ceil(K/64)][64][64] of the [N, K] weight (GemmArgs::w_tiled; built by the
+// caller once per weight: pure data movement, like the OIHW -> OHWI conv repack).
 int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, void* ws, long ws_bytes, void* stream) {
+                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
     SPIDER_CHECK(ldc % 4 == 0 && ldc >= (act == 4 ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
@@ -1584,7 +1607,8 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
     a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;
     SPIDER_CHECK((size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), "gemm: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)(M - 1) * lda * 2 + (size_t)K * 2);
-    a.w_bytes = (uint32_t)((size_t)N * K * 2);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
     set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
@@ -1595,7 +1619,7 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
 // C = rstd * (A.Wf^T - mean * colsum) + colbias in its epilogue. Replaces BasicTransformerBlock.norm1/2/3 + the projection
 // that consumes it (diffusers-0.25 attention.py; call site custom_sd.py:634-639). lda must equal K (whole rows are normalised).
 int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
-                        int M, int N, int K, int ldc, int act, float eps, void* ws, long ws_bytes, void* stream) {
+                        int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm_ln: empty problem");
     SPIDER_CHECK(K % 8 == 0, "gemm_ln: K must be a multiple of 8 (16-byte rows)");
     SPIDER_CHECK(act == 0 || act == 4, "gemm_ln: only the plain and the GEGLU epilogue are built");
@@ -1613,7 +1637,8 @@ int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const floa
     SPIDER_CHECK((size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 2 < ((size_t)1 << 31),
                  "gemm_ln: operands must be < 2 GiB");
     a.a_bytes = (uint32_t)((size_t)M * K * 2);
-    a.w_bytes = (uint32_t)((size_t)N * K * 2);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
     set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
@@ -1626,7 +1651,7 @@ int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const floa
 int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, void* ws, long ws_bytes, void* stream) {
+                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv: empty problem");
     SPIDER_CHECK(kh >= 1 && kw >= 1 && kh * kw <= 64 && dil >= 1, "conv: kernel taps must be 1..64, dilation >= 1");
     SPIDER_CHECK(stride == 1 || stride == 2, "conv: stride must be 1 or 2");
@@ -1654,7 +1679,8 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
     a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil; a.ups = ups; a.lim_h = Hs; a.lim_w = Ws; a.cin64 = Cin % 64 == 0;
     SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
-    a.w_bytes = (uint32_t)((size_t)Cout * a.K * 2);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(Cout, a.K) : (uint32_t)((size_t)Cout * a.K * 2);
     set_epilogue_ranges(a);
     return launch(a, ws ? ws_bytes : 0, stream);
 }
@@ -1663,11 +1689,11 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
 // ups=1 fuses the exact nearest-2x upsample.
 int SPIDER_FN(spider_conv2d_nhwc)(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, void* ws, long ws_bytes, void* stream) {
+                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
     SPIDER_CHECK(Cin % 64 == 0, "conv2d: Cin must be a multiple of 64 for the MFMA path (use conv2d_small)");
     return SPIDER_FN(spider_conv_nhwc_ex)(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, ks, ks, stride, pad, pad, 1,
-                                    ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, ws, ws_bytes, stream);
+                                    ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, w_tiled, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

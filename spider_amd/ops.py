@@ -49,6 +49,46 @@ def _h16(t: torch.Tensor):
     raise ValueError(f"expected a bfloat16 or float16 tensor, got {t.dtype}")
 
 
+# ---- tile-major weight copies for the weight-streaming GEMMs / convs (include/spider_hip.h: w_tiled) ----
+# An engine marks its long-lived weight tensors with mark_weight(); a GEMM / conv call with at most WTILED_MAX_M output rows then
+# runs on the tile-major copy [ceil(N/64)][ceil(K/64)][64][64] of that weight (one contiguous 8 KiB read per K tile of 64 rows
+# instead of 64 strided 128-byte pieces), built on first use -- outside graph capture: engines run one eager warm-up pass before
+# they capture -- and kept for the life of the tensor object. Unmarked tensors (activations passed as the W operand, slices)
+# always take the row-major path, so a recycled allocation can never meet a stale copy.
+import os as _os
+
+WTILED_MAX_M = int(_os.environ.get("SPIDER_WTILED_MAX_M", "512"))
+
+
+def mark_weight(t: torch.Tensor) -> torch.Tensor:
+    t._spider_weight = True
+    return t
+
+
+def tile_weight64(W2: torch.Tensor) -> torch.Tensor:
+    """[N, K] 16-bit -> tile-major [ceil(N/64), ceil(K/64), 64, 64], zero-padded (pure data movement)."""
+    N, K = W2.shape
+    Np, Kp = (N + 63) // 64 * 64, (K + 63) // 64 * 64
+    if (Np, Kp) != (N, K):
+        Wp = torch.zeros(Np, Kp, dtype=W2.dtype, device=W2.device)
+        Wp[:N, :K] = W2
+        W2 = Wp
+    return W2.view(Np // 64, 64, Kp // 64, 64).permute(0, 2, 1, 3).contiguous()
+
+
+def _tiled(W: torch.Tensor, M: int):
+    """the tile-major copy of a marked weight when the problem is weight-streaming (M <= WTILED_MAX_M), else None"""
+    if M > WTILED_MAX_M or not getattr(W, "_spider_weight", False):
+        return None
+    t = getattr(W, "_spider_tiled", None)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = tile_weight64(W.reshape(W.shape[0], -1))
+        W._spider_tiled = t
+    return t
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -253,8 +293,9 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     if out is None:
         out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else dt, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
-    _lib.call(f"spider_gemm_{sfx}", _p(A), _p(W), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
-              M, N, K, K, n_out, ACT[act], float(out_scale), _p(_workspace(A.device)), WS_BYTES, _stream())
+    wt = _tiled(W, M)
+    _lib.call(f"spider_gemm_{sfx}", _p(A), _p(W if wt is None else wt), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
+              M, N, K, K, n_out, ACT[act], float(out_scale), int(wt is not None), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
 
@@ -286,8 +327,9 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
         out = torch.empty(*A.shape[:-1], n_out, dtype=dt, device=A.device)
     if res is not None:
         _chk(res, dt, "res")
-    _lib.call(f"spider_gemm_ln_{sfx}", _p(A), _p(Wf), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out, ACT[act], float(eps),
-              _p(_workspace(A.device)), WS_BYTES, _stream())
+    wt = _tiled(Wf, M)
+    _lib.call(f"spider_gemm_ln_{sfx}", _p(A), _p(Wf if wt is None else wt), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out,
+              ACT[act], float(eps), int(wt is not None), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
 
 
@@ -321,8 +363,9 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     Ho, Wo = (Hs + 2 * pad - ks) // stride + 1, (Ws + 2 * pad - ks) // stride + 1
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
-    _lib.call(f"spider_conv2d_nhwc_{sfx}", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
-              ks, stride, pad, int(ups), float(out_scale), _p(_workspace(x.device)), WS_BYTES, _stream())
+    wt = _tiled(w, B * Ho * Wo)
+    _lib.call(f"spider_conv2d_nhwc_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
+              ks, stride, pad, int(ups), float(out_scale), int(wt is not None), _p(_workspace(x.device)), WS_BYTES, _stream())
     return out
 
 
@@ -341,9 +384,10 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
     uh, uw = up_size if up_size is not None else (0, 0)
-    _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout, kh, kw,
-              stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), _p(_workspace(x.device)),
-              WS_BYTES, _stream())
+    wt = _tiled(w, B * Ho * Wo)
+    _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
+              Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
+              _p(_workspace(x.device)), WS_BYTES, _stream())
     return out
 
 

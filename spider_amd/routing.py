@@ -59,6 +59,46 @@ def route(samples: dict, answers: list, predictions: dict, predictions_text: dic
     return answers, predictions, predictions_text
 
 
+def route_batch(samples_list: List[dict], outputs: List[tuple], decode_modality: Dict[str, Optional[Callable]],
+                batch_decoders: Dict[str, Callable]):
+    """The routing loop of SpiderDecoder.generate for SEVERAL independent samples at once (the batched
+    entry point offered next to the reference's one-sample contract). Result = calling `route` once per sample with that sample's
+    own containers -- same captions in the same order, same None-skip rule -- except that every caption of a diffusion modality
+    (IMAGE / VIDEO / AUDIO), over all samples, goes to ONE call of `batch_decoders[modality](captions) -> list | None` (one
+    entry per caption, shaped like the single call's `preds[0]` (IMAGE, AUDIO) or `preds` (VIDEO)). MASK / BOX keep their
+    per-sample calls (they read the sample's own image)."""
+    jobs: Dict[str, list] = {}
+    for i, (samples, (answers, predictions, predictions_text)) in enumerate(zip(samples_list, outputs)):
+        output_texts = samples["llm_text_all"][0]
+        for modality in get_llm_text_modality(output_texts, decode_modality.keys()):
+            for llm_text_res in get_llm_text_res(output_texts, modality):
+                predictions_text[modality].append(llm_text_res)
+                if modality in batch_decoders:
+                    jobs.setdefault(modality, []).append((i, llm_text_res))
+                    continue
+                samples["llm_text_res"] = [llm_text_res]
+                if modality == "MASK":
+                    preds = decode_modality[modality](samples)
+                    if preds is not None:
+                        predictions[modality].append(preds[0])
+                elif modality == "BOX":
+                    det = decode_modality[modality](samples)
+                    if det is not None:
+                        predictions[modality]["bboxes"].append(det["outputs_bboxes"][0])
+                        predictions[modality]["label_names"].append(det["outputs_label_names"][0])
+                        predictions[modality]["scores"].append(det["outputs_scores"][0])
+        answers.append(output_texts)
+    for modality in [m for m in decode_modality.keys() if m in jobs]:       # dict-key order, as the single-sample loop visits them
+        res = batch_decoders[modality]([c for _, c in jobs[modality]])
+        if res is None:
+            continue
+        assert len(res) == len(jobs[modality]), f"{modality}: the batched decoder must return one entry per caption"
+        for (i, caption), r in zip(jobs[modality], res):
+            outputs[i][1][modality].append(r)
+            samples_list[i]["llm_text_res"] = [caption]
+    return outputs
+
+
 def route_text(text: str):
     """Routing without decoders: (answers, predictions_text, [(modality, caption), ...] in dispatch order)."""
     calls = []

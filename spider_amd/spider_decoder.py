@@ -121,6 +121,53 @@ class SpiderDecoder:
         return routing.route(samples, answers, predictions, predictions_text, self.decode_modality)
 
 
+    # ------------------------------------------------------------------ batched entry point
+    def _decode_batch(self, modality, ckpt, captions, what, **call_kwargs):
+        pipe = self._pipe(modality, ckpt)
+        if pipe is None:
+            print(f"no input text prompt for {what} generation. or no {what} generation model.")
+            return None
+        if self.get_prompt_embed_for_diffusion:
+            embeds = pipe(list(captions), return_prompts_only=True).detach()
+            return pipe(prompt_embeds=embeds, **call_kwargs)
+        return pipe(prompt=list(captions), **call_kwargs)
+
+    def decode_image_batch(self, captions, guidance_scale=7.5, num_inference_steps=40):
+        out = self._decode_batch("IMAGE", self.sd_ckpt_path, captions, "image", guidance_scale=guidance_scale,
+                                 num_inference_steps=num_inference_steps)
+        return None if out is None else list(out.images)
+
+    def decode_audio_batch(self, captions, guidance_scale=7.5, num_inference_steps=40, audio_length_in_s=5.0):
+        out = self._decode_batch("AUDIO", self.ad_ckpt_path, captions, "audio", guidance_scale=guidance_scale,
+                                 num_inference_steps=num_inference_steps, audio_length_in_s=audio_length_in_s)
+        return None if out is None else [a for a in out.audios]
+
+    def decode_video_batch(self, captions, guidance_scale=7.5, num_inference_steps=40, height=320, width=576, num_frames=16):
+        """tensor2vid (custom_vd.py:59-74) tiles the batch horizontally inside every frame: cut each frame back into the per-caption
+        videos, so entry j is what the one-caption call returns (a list of `num_frames` [H, W, 3] uint8 frames)."""
+        out = self._decode_batch("VIDEO", self.vd_ckpt_path, captions, "video", guidance_scale=guidance_scale,
+                                 num_inference_steps=num_inference_steps, height=height, width=width, num_frames=num_frames)
+        if out is None:
+            return None
+        n = len(captions)
+        frames = out.frames
+        w = frames[0].shape[1] // n
+        return [[f[:, j * w:(j + 1) * w] for f in frames] for j in range(n)]
+
+    @torch.no_grad()
+    def generate_batch(self, samples_list, outputs=None):
+        """`generate` for several independent samples (BASELINE configs[4]: 8 prompts per GPU): every sample keeps the reference's
+        one-sample contract (its own answers / predictions / predictions_text containers, mutated and returned; index 0 of
+        `llm_text_all` is read, spider_decoder.py:311), but all IMAGE captions of the batch run through ONE pipeline call (CFG batch
+        2 x captions), likewise AUDIO and VIDEO -- the decoders are batched like the LLM is. `outputs`: optional list of
+        (answers, predictions, predictions_text) triples, one per sample (created when omitted). Returns that list."""
+        if outputs is None:
+            outputs = [routing.new_outputs() for _ in samples_list]
+        assert len(outputs) == len(samples_list)
+        batch = dict(IMAGE=self.decode_image_batch, VIDEO=self.decode_video_batch, AUDIO=self.decode_audio_batch)
+        return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch)
+
+
 class SpiderDecoderInfer:
     """spider_decoder_infer.py:35-84. `cfg.model` may be an mmengine Config node or a plain dict."""
 

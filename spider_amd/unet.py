@@ -170,6 +170,16 @@ class UNetEngine:
             wqb4[0] = (Wq.float() @ b2).to(BF16)
             self.xw[l] = dict(wqt_g=(Wq.float() * g2[None, :]).t().contiguous().to(BF16), wqb4=wqb4)
         self._ones4 = {}
+        # 1x1-conv proj_in / proj_out weights are used as plain [C, C] linears: keep the 2-D form (one tensor object per weight,
+        # so that ops.mark_weight's tile-major copy is found again on every call)
+        for n in [k for k in self.w if (k.endswith(".proj_in.weight") or k.endswith(".proj_out.weight")) and self.w[k].ndim == 4]:
+            self.w[n] = self.w[n].reshape(self.w[n].shape[0], -1).contiguous()
+        # weight-streaming problems (16^2 / 8^2 maps: M <= 512 rows) run on tile-major weight copies built on first use
+        for t in self.w.values():
+            if t.ndim >= 2:
+                ops.mark_weight(t)
+        for tup in self.ln.values():
+            ops.mark_weight(tup[0])
         self.xf: Dict[str, dict] = {}
         # resnet table: order of time_emb_proj consumers
         self.resnets = [k[:-len(".time_emb_proj.weight")] for k in self.w if k.endswith(".time_emb_proj.weight")]
@@ -381,8 +391,7 @@ class UNetEngine:
         w = self.w
         B, H, W_, C = x.shape
         a = self._gn(n + ".norm", x, False, eps=1e-6)
-        pw = w[n + ".proj_in.weight"].view(C, C)
-        h = ops.gemm(a.view(B, H * W_, C), pw, bias=w[n + ".proj_in.bias"])
+        h = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
             fuse = self.fuse_ln
@@ -413,7 +422,7 @@ class UNetEngine:
                 y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
                 g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
             h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
-        out = ops.gemm(h, w[n + ".proj_out.weight"].view(C, C), bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
+        out = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
         return out.view(B, H, W_, C)
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -99,3 +99,58 @@ def test_bench_self_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
     assert bench.launch_ranks(argparse.Namespace(gpus=2), script=str(script), argv=[str(tmp_path), "fail"]) == 3   # a failing rank is reported
     with pytest.raises(SystemExit, match="only 2 GPU"):
         bench.launch_ranks(argparse.Namespace(gpus=4), script=str(script), argv=[str(tmp_path)])
+
+
+def _bench_worker(rank, world, port, workload, q):
+    """Two ranks drive bench.run_timed (the contract's timed region) with a stand-in responder over gloo."""
+    import argparse
+    import importlib.util
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from spider_amd import dp
+    dp.init_from_env(backend="gloo")
+    B = 3
+
+    class Stub:
+        calls = 0
+
+        def respond(self):
+            Stub.calls += 1
+            base = 10 * rank
+            toks = torch.stack([torch.full((5,), base + b, dtype=torch.int32) for b in range(B)])
+            if workload == "any2many":      # the payload keys and shapes of AnyToManyResponder.respond (smaller tensors)
+                return {"tokens": toks, "image": torch.full((B, 4, 4, 3), rank, dtype=torch.uint8),
+                        "audio": torch.full((B, 7), rank + 0.25, dtype=torch.float32), "video": torch.full((B, 2, 3, 3, 3), rank, dtype=torch.uint8)}
+            return toks, torch.full((B, 3, 4, 4), rank, dtype=torch.uint8)      # Responder.respond: (tokens, images)
+
+    args = argparse.Namespace(workload=workload, batch=B, warmup=1, steps=2)
+    dt, g, info = bench.run_timed(Stub(), args, rank, world, torch.device("cpu"))
+    assert Stub.calls == 3 and dt > 0 and info == {"world_size": 2, "backend": "gloo"}
+    import torch.distributed as dist
+    assert not dist.is_initialized(), "run_timed leaves the process group before the rank-0 extras"
+    if rank == 0:
+        keys = sorted(k for k in g if k != "count")
+        full = dp.unshard(g, world * B, world)           # item i came from rank i % world, slot i // world
+        q.put((keys, g["count"].tolist(), full["tokens"][:, 0].tolist()))
+    else:
+        assert g is None
+
+
+def test_bench_timed_region_two_ranks_both_workloads():
+    import pytest  # noqa: F401
+    for workload, want in (("text_image", ["out", "tokens"]), ("any2many", ["audio", "image", "tokens", "video"])):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, workload, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        keys, counts, first = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+        assert keys == want and counts == [3, 3]
+        assert first == [0, 10, 1, 11, 2, 12]            # strided un-sharding: rank 0 slot 0, rank 1 slot 0, rank 0 slot 1, ...

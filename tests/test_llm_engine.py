@@ -27,7 +27,7 @@ def _load_d128(golden_dir, k):
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_engine_matches_reference_generated_fixture(dev, golden_dir, k):
     """The HIP engine DIRECTLY against reference-generated vectors (no oracle in between): every one of the 2 x 16 greedy token
-    ids equal (the fixtures' minimum top-2 margin is >= 0.18, far above bf16 resolution: north_star's bit-exact routing),
+    ids equal (the fixtures' minimum top-2 margin is >= 0.1, i.e. >= 5x the engine's logit error: north_star's bit-exact routing),
     prompt logits and all hidden states within the bf16 bounds, both the hipGraph and the eager decode loops."""
     from spider_amd.llm import LlamaEngine
     z, cfg, w = _load_d128(golden_dir, k)
@@ -43,16 +43,14 @@ def test_engine_matches_reference_generated_fixture(dev, golden_dir, k):
     got_steps = out.logits.float().cpu()
     rel = float((got_steps - ref_steps).norm() / ref_steps.norm())
     print(f"MEASURED llm d128 fixture {k}: step-logits rel-L2 {rel:.5f}, min margin {float(z['margins'].min()):.3f}")
-    # std-0.2 weights make q.k scores of magnitude ~100 (a near-argmax softmax that amplifies every bf16 rounding of the scores):
-    # measured 3.0 - 3.7e-2 on MI355X, bound = + 20 %; the token ids above are the criterion north_star names
-    assert rel < 4.5e-2
+    assert rel < 1.8e-2        # measured 1.48 - 1.50e-2 on MI355X (+ 20 %)
     ref_h = torch.from_numpy(z["hiddens"])                              # [L+1, B, S, H]
     hrel = []
     for l in range(cfg.layers + 1):
         got = out.hidden_states[0][l].float().cpu()
         hrel.append(float((got - ref_h[l]).norm() / ref_h[l].norm()))
     print(f"MEASURED llm d128 fixture {k}: prompt hidden-state rel-L2 per layer {[round(r, 5) for r in hrel]}")
-    assert hrel[0] < 1e-6 and max(hrel) < 3e-2, hrel
+    assert hrel[0] < 1e-6 and max(hrel) < 1.7e-2, hrel     # measured 0.86 - 1.41e-2 (+ 20 %)
 
 
 def _check_tokens(gen, ref_tokens, ref_step_logits, margin_tol):

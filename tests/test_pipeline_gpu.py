@@ -95,3 +95,32 @@ def test_spider_decoder_audio_and_video_paths(dev):
     dec2 = SpiderDecoder(diffusion_modules={}, pipelines=dict(AUDIO=tiny_audio_pipe(dev)), get_prompt_embed_for_diffusion=True)
     _, p2, _ = dec2.generate({"llm_text_all": ["<AUDIO>rain on a tin roof</AUDIO>"]}, *routing.new_outputs())
     assert p2["AUDIO"][0].shape == (80000,)
+
+
+def test_spider_decoder_generate_batch_runs_each_decoder_once(dev):
+    """SpiderDecoder.generate_batch on the real HIP pipelines (tiny engines): three responses, each with IMAGE + AUDIO + VIDEO
+    captions, decoded by ONE pipeline call per modality (CFG batch 2 x 3); every sample gets its own containers with entries shaped
+    exactly like the one-sample `generate` call's."""
+    from helpers import tiny_audio_pipe, tiny_video_pipe
+    from spider_amd.spider_decoder import SpiderDecoder
+    pipe, _ = _pipe(dev)
+    pipes = dict(IMAGE=pipe, AUDIO=tiny_audio_pipe(dev), VIDEO=tiny_video_pipe(dev))
+    calls = {m: 0 for m in pipes}
+    for m, p in pipes.items():
+        orig = p.__class__.__call__
+        def counted(self, *a, _m=m, _o=orig, **k):
+            calls[_m] += 1
+            return _o(self, *a, **k)
+        p.__class__ = type(p.__class__.__name__ + "Counted", (p.__class__,), {"__call__": counted})
+    dec = SpiderDecoder(diffusion_modules={}, pipelines=pipes)
+    texts = [f"ok <IMAGE>car {i}</IMAGE> <AUDIO>rain {i}</AUDIO> <VIDEO>sea {i}</VIDEO>" for i in range(3)]
+    outs = dec.generate_batch([{"llm_text_all": [t]} for t in texts])
+    assert calls == dict(IMAGE=1, AUDIO=1, VIDEO=1)
+    assert len(outs) == 3
+    for i, (a, p, pt) in enumerate(outs):
+        assert a == [texts[i]] and pt["IMAGE"] == [f"car {i}"] and pt["AUDIO"] == [f"rain {i}"] and pt["VIDEO"] == [f"sea {i}"]
+        assert len(p["IMAGE"]) == 1 and p["IMAGE"][0].size == (64, 64)
+        assert len(p["AUDIO"]) == 1 and p["AUDIO"][0].shape == (80000,) and np.isfinite(p["AUDIO"][0]).all()
+        assert len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
+    # different captions -> different samples (the batch rows are not copies of one another)
+    assert not np.array_equal(np.asarray(outs[0][1]["IMAGE"][0]), np.asarray(outs[1][1]["IMAGE"][0]))

@@ -59,3 +59,51 @@ def test_story_handoff(monkeypatch):
     a, p, pt = infer({"llm_text_all": [text]})
     assert seen == dict(pipe="PIPE", g="'a man with a black suit'", a=["wake up in the bed", "have breakfast"], s="'Comic book'")
     assert p["IMAGESTORY"] == [["img0", "img1"]] and pt["IMAGESTORY_prompts"] == [["wake up in the bed", "have breakfast"]]
+
+
+class FakeBatchPipe:
+    """Stand-in pipeline that accepts a list of prompts (one pipeline call for the whole batch)."""
+    def __init__(self, field):
+        self.field, self.calls = field, []
+
+    def __call__(self, prompt=None, prompt_embeds=None, return_prompts_only=False, **kw):
+        import numpy as np
+        self.calls.append((list(prompt), kw))
+        class O:
+            pass
+        o = O()
+        if self.field == "frames":   # tensor2vid layout: F frames of [H, B*W, 3], the batch tiled along the width
+            n = len(prompt)
+            setattr(o, self.field, [np.concatenate([np.full((2, 3, 3), 10 * j + f, dtype=np.uint8) for j in range(n)], 1) for f in range(4)])
+        else:
+            setattr(o, self.field, [f"{self.field}:{p}" for p in prompt])
+        return o
+
+
+def test_generate_batch_equals_per_sample_generate(golden_dir):
+    """SpiderDecoder.generate_batch (the batched entry point): per-sample containers identical to one
+    `generate` call per sample -- on the reference-generated routing cases -- while every diffusion modality runs ONE pipeline
+    call over all captions of the batch, and the tiled video frames are cut back per caption."""
+    import json, os
+    cases = json.load(open(os.path.join(golden_dir, "routing_ref.json")))["cases"]
+    texts = [c["text"] for c in cases]
+    mk = lambda cls: dict(IMAGE=cls("images"), VIDEO=cls("frames"), AUDIO=cls("audios"))
+    single_pipes, batch_pipes = mk(FakePipe), mk(FakeBatchPipe)
+    d1 = SpiderDecoder(diffusion_modules={}, pipelines=single_pipes)
+    d2 = SpiderDecoder(diffusion_modules={}, pipelines=batch_pipes)
+    ref = [d1.generate({"llm_text_all": [t]}, *routing.new_outputs()) for t in texts]
+    got = d2.generate_batch([{"llm_text_all": [t]} for t in texts])
+    assert len(got) == len(ref)
+    for (a1, p1, t1), (a2, p2, t2), c in zip(ref, got, cases):
+        assert a1 == a2 and t1 == t2                                   # answers and predictions_text: identical
+        assert t2 == c["predictions_text"] and a2 == c["answers"]      # ... and equal to what the reference's generate produced
+        assert p1["IMAGE"] == p2["IMAGE"] and p1["AUDIO"] == p2["AUDIO"]
+        assert len(p1["VIDEO"]) == len(p2["VIDEO"])
+        for v in p2["VIDEO"]:
+            assert len(v) == 4 and v[0].shape == (2, 3, 3)             # one caption's own frames, not the tiled batch
+    n_img = sum(len(c["predictions_text"]["IMAGE"]) for c in cases)
+    assert len(batch_pipes["IMAGE"].calls) == 1 and len(batch_pipes["IMAGE"].calls[0][0]) == n_img
+    assert len(batch_pipes["VIDEO"].calls) == 1 and len(batch_pipes["AUDIO"].calls) == 1
+    # the j-th caption of the VIDEO call gets the j-th width slice of every frame
+    vids = [v for _, p, _ in got for v in p["VIDEO"]]
+    assert [int(v[0][0, 0, 0]) for v in vids] == [10 * j for j in range(len(vids))]
