@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--schedule", default="overlap", choices=["overlap", "serial"],
+                   help="text_image: overlap = response k's diffusion decoder on one stream beside response k+1's LLM pass on another "
+                        "(one LLM pass + one decoder pass per step either way); serial = one stream")
     p.add_argument("--serial-decoders", action="store_true",
                    help="any2many: one SpiderDecoder.generate call per response (the reference's contract) instead of generate_batch")
     p.add_argument("--throughput-batch", type=int, default=8,
@@ -128,6 +131,7 @@ class Responder:
         self.clip_ids_u = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
         self.clip_ids_c = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
         self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(DIFF_DT)
+        self._streams, self._pending = None, None
 
     def includes(self):
         inc = ["llm_prefill", "llm_decode", "routing", "unet_denoise_loop"]
@@ -137,30 +141,70 @@ class Responder:
             inc.append("vae_decode")
         return inc
 
-    def respond(self, batch=None):
-        from spider_amd import routing
+    # ---- the two passes of one response -------------------------------------------------------------------------------------
+    def _llm_pass(self, B):
+        """LLM generate for B prompts on the CURRENT stream; ends with the one device->host copy of the generated ids."""
+        from spider_amd import ops
+        a = self.args
+        with ops.workspace_scope("llm"):
+            toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
+        gen = toks[:, a.prompt_len:]
+        return gen, gen.cpu()                      # the one device->host sync of the LLM phase
+
+    def _decoder_pass(self, B, gen_host):
+        """routing of the generated text + the image decoder (text encoder, UNet loop, VAE) on the CURRENT stream, no host sync"""
+        from spider_amd import ops, routing
         from spider_amd.unet import denoise
         a = self.args
-        B = batch or a.batch
-        toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
-        gen = toks[:, a.prompt_len:]
-        gen_host = gen.cpu()                       # the one device->host sync of the LLM phase
-        images = []
         for b in range(B):
             # synthetic text forced to carry exactly one <IMAGE> tag (random-init weights emit no real tags)
             text = "Here you go: <IMAGE>tokens " + " ".join(str(int(t)) for t in gen_host[b, :8]) + "</IMAGE>"
             answers, ptext, calls = routing.route_text(text)
             assert len(calls) == 1 and calls[0][0] == "IMAGE"
-        if self.text_enc is not None:   # CFG layout of _encode_prompt (custom_sd.py:372): [uncond(B) | cond(B)]
-            enc = self.text_enc.encode(torch.cat([self.clip_ids_u[:B], self.clip_ids_c[:B]]))
-        else:
-            enc = torch.cat([self.enc_synth[:B], self.enc_synth[self.max_batch:self.max_batch + B]]).contiguous()
-        lat = denoise(self.unet, self.sched, self.latents0[:B].contiguous(), enc, 7.5, a.denoise_steps)
-        if self.vae is not None:
-            img = self.vae.decode(lat)                          # [B, 3, 512, 512] fp32 in [0,1]
-            out = (img * 255.0).round().to(torch.uint8)
-        else:
-            out = lat
+        with ops.workspace_scope("diffusion"):
+            if self.text_enc is not None:   # CFG layout of _encode_prompt (custom_sd.py:372): [uncond(B) | cond(B)]
+                enc = self.text_enc.encode(torch.cat([self.clip_ids_u[:B], self.clip_ids_c[:B]]))
+            else:
+                enc = torch.cat([self.enc_synth[:B], self.enc_synth[self.max_batch:self.max_batch + B]]).contiguous()
+            lat = denoise(self.unet, self.sched, self.latents0[:B].contiguous(), enc, 7.5, a.denoise_steps)
+            if self.vae is not None:
+                img = self.vae.decode(lat)                          # [B, 3, 512, 512] fp32 in [0,1]
+                return (img * 255.0).round().to(torch.uint8)
+            return lat
+
+    def respond_serial(self, batch=None):
+        """One response start to finish on one stream: LLM pass, then its decoder pass (the latency of ONE request)."""
+        B = batch or self.args.batch
+        gen, gen_host = self._llm_pass(B)
+        return gen.to(torch.int32), self._decoder_pass(B, gen_host)
+
+    def respond(self, batch=None):
+        """One step = one LLM pass + one decoder pass. Default schedule (`--schedule overlap`): the decoder pass of response k
+        (MFMA / latency-bound UNet loop) runs on one HIP stream while the LLM pass of response k+1 (HBM-bound weight streaming)
+        runs on another -- the two halves of the hot path load different parts of the chip, and consecutive requests are
+        independent (spider_decoder.py:311 reads one sample per call). Every step still performs exactly one LLM pass and one
+        decoder pass and returns the finished response k; the LLM output that response k+1 needs was produced one step earlier.
+        `--schedule serial` runs the two passes of the same response back to back on one stream."""
+        B = batch or self.args.batch
+        if self.args.schedule == "serial" or B != self.args.batch:
+            return self.respond_serial(B)
+        dev = self.dev
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        sL, sU = self._streams
+        cur = torch.cuda.current_stream(dev)
+        if self._pending is None:                   # pipeline empty (first step): this response's own LLM pass comes first
+            sL.wait_stream(cur)
+            with torch.cuda.stream(sL):
+                self._pending = self._llm_pass(B)
+        gen, gen_host = self._pending
+        sU.wait_stream(cur)
+        sL.wait_stream(cur)
+        with torch.cuda.stream(sU):                 # decoder pass of THIS response: enqueued first (asynchronous on the host)
+            out = self._decoder_pass(B, gen_host)
+        with torch.cuda.stream(sL):                 # LLM pass of the NEXT response, concurrently (blocks the host at its end)
+            self._pending = self._llm_pass(B)
+        sU.synchronize()
         return gen.to(torch.int32), out
 
 
@@ -707,6 +751,10 @@ def main():
                                            f"{a.new_tokens} greedy tokens, routing, SD-v1.5 UNet 64x64 latent, PNDM {a.denoise_steps} steps "
                                            f"({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5",
                                "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": extra.pop("_includes"),
+                               "schedule": ("overlap: every step = ONE LLM pass + ONE decoder pass; the decoder pass of response k runs on one HIP "
+                                            "stream beside the LLM pass of response k+1 on another (independent consecutive requests); "
+                                            "serial_ms_per_response is the one-stream latency of a single request"
+                                            if a.schedule == "overlap" else "serial: the two passes of a response back to back on one stream"),
                                "weights": "random-init of the true shapes"},
                     "roofline": roof, "cpu_baseline": cpu, **extra}
             print(json.dumps(line), flush=True)
@@ -728,7 +776,12 @@ def response_roofline(args, extra, ms_per_step):
     floors = {"decode_ms": decode_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "prefill_ms": prefill_flops / (MFMA_PEAK_TF * 1e12) * 1e3,
               "unet_ms": unet_flops_total / (MFMA_PEAK_TF * 1e12) * 1e3, "vae_ms": vae_flops / (MFMA_PEAK_TF * 1e12) * 1e3}
     floor = sum(floors.values())
+    # with the LLM pass and the decoder pass on different streams the two halves could hide each other completely: the floor of a
+    # step of the overlapped schedule is the larger half, not the sum (both are reported; `frac` uses the conservative sum)
+    overlap_floor = max(floors["decode_ms"] + floors["prefill_ms"], floors["unet_ms"] + floors["vae_ms"])
     return {"floor_ms": round(floor, 1), "measured_ms": ms_per_step, "frac": round(floor / ms_per_step, 4),
+            "overlap_floor_ms": round(overlap_floor, 1), "serial_measured_ms": extra.get("serial_ms_per_response"),
+            "serial_frac": round(floor / extra["serial_ms_per_response"], 4) if extra.get("serial_ms_per_response") else None,
             "floors_ms": {k: round(v, 1) for k, v in floors.items()},
             "algorithmic": {"decode_hbm_bytes": int(decode_bytes), "prefill_flops": prefill_flops, "unet_flops": unet_flops_total, "vae_flops": vae_flops},
             "peaks": {"hbm_GBps": HBM_PEAK_GBS, "mfma_TFLOPs": MFMA_PEAK_TF}}
@@ -778,6 +831,16 @@ def text_image_extras(args, resp, device):
         frac = (wbytes + B * kvb) * (tok_s / B) / 1e9 / HBM_PEAK_GBS
         return t_prefill, tok_s, frac
 
+    # one response start to finish on ONE stream (the latency of a single request; `value` counts a step of the overlapped
+    # schedule when --schedule overlap)
+    resp.respond_serial()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for _ in range(2):
+        resp.respond_serial()
+    torch.cuda.synchronize(device)
+    extra["serial_ms_per_response"] = round((time.perf_counter() - t1) / 2 * 1e3, 2)
+    extra["serial_responses_per_s"] = round(a.batch / (extra["serial_ms_per_response"] * 1e-3), 4)
     tp, tok_s, frac = llm_phase(a.batch)
     extra["llm_prefill_ms"] = round(tp * 1e3, 1)
     extra["llm_decode_tokens_per_s"] = round(tok_s, 1)

@@ -421,7 +421,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_kernel(Att
 // K is consumed one iteration ahead of V, so the two LDS images hold {K(t+1), V(t)} while {K(t+2), V(t+1)} are in registers;
 // one barrier per tile as before.
 // ------------------------------------------------------------------------------------------------------------------
-template <int DP, bool ONES>
+// KQ = 16-wide k-steps of the QK^T product = ceil(head_dim / 16) <= DP / 16: the UNet's d = 40 heads ride in 64-wide tiles (the
+// padded Q / K columns are zeros) but need only 3 of the tile's 4 k-steps -- 6 instead of 8 QK^T MFMAs per 64-key tile.
+template <int DP, bool ONES, int KQ = DP / 16>
 __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kernel(AttnArgs p) {
     using C = Cfg<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,9 +452,9 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     const h16_t* kb = p.k + b * p.k_bs + hk * p.k_hs;
     const h16_t* vb = p.v + b * p.v_bs + hk * p.v_hs;
 
-    h16x8 qf[DP / 16];
+    h16x8 qf[KQ];
 #pragma unroll
-    for (int ks = 0; ks < DP / 16; ++ks) {
+    for (int ks = 0; ks < KQ; ++ks) {
         const int dd = ks * 16 + h32 * 8;
         u32x4 t = {0u, 0u, 0u, 0u};
         if (q_ok && dd < p.d) t = *reinterpret_cast<const u32x4*>(qb + (long)qi * p.q_rs + dd);
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
             const h16_t* krow = Ks + (kt * 32 + l32) * C::KS + h32 * 8;
 #pragma unroll
-            for (int ks = 0; ks < DP / 16; ++ks) {
+            for (int ks = 0; ks < KQ; ++ks) {
                 const h16x8 kf = *reinterpret_cast<const h16x8*>(krow + ks * 16);
                 s[kt] = mfma_32x32x16_h16(kf, qf[ks], s[kt]);
             }
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256, (DP <= 96 ? 2 : 1)) void attn_flash_pipe_kerne
     load_k(1);
     store_k(1);
 #pragma unroll
-    for (int ks = 0; ks < DP / 16; ++ks) asm volatile("" ::"v"(qf[ks]));      // retire the Q loads before the loop (see above)
+    for (int ks = 0; ks < KQ; ++ks) asm volatile("" ::"v"(qf[ks]));      // retire the Q loads before the loop (see above)
     __syncthreads();
     f32x16 sc[2], sn[2];
     qk(0, sc);
@@ -711,6 +713,13 @@ int launch(const AttnArgs& a, void* stream) {
     const bool plain = !a.causal && !a.keep_bits && !a.kv_beg && !a.tiles;
     static const int pipe_env = [] { const char* e = getenv("SPIDER_ATTN_PIPE"); return e ? atoi(e) : 1; }();
     if (plain && pipe_env && a.Lk % 64 == 0 && a.Lk >= 128 && DP <= 96) {      // software-pipelined dense form (whole 64-key tiles)
+        if constexpr (DP == 64) {
+            if (a.d <= 48) {       // 3 k-steps cover the head (d = 40: the SD-v1.5 64^2 level)
+                attn_flash_pipe_kernel<DP, true, 3><<<grid, 256, smem, (hipStream_t)stream>>>(a);
+                SPIDER_LAUNCH_OK();
+                return 0;
+            }
+        }
         if (a.d < DP) attn_flash_pipe_kernel<DP, true><<<grid, 256, smem, (hipStream_t)stream>>>(a);
         else attn_flash_pipe_kernel<DP, false><<<grid, 256, smem, (hipStream_t)stream>>>(a);
         SPIDER_LAUNCH_OK();

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const h16_t* __restrict__
     h16_t* catb = cat ? cat + (size_t)b * HW * C + g * cpg : nullptr;
     // the group's data is read ONCE into registers (all loads independent and in flight together)
     uint32_t v[MAXP];
-    int off[MAXP];          // element offset of the pair inside the batch image; the pair's channel offset 2*cp rides in bits 24..31
+    int off[MAXP];          // element offset of the pair inside the batch image; the pair index cp rides in bits 25..31 (cp < 128: C / G <= 256, and HW * C < 2^25: host-checked)
     // element i = threadIdx.x + 256 u lives at pixel i / hp, pair i % hp: one division for u = 0, then a carry-step per u (the 20
     // runtime divisions + 20 modulos per thread of the first version were most of the kernel's instructions, in front of its loads)
     int px = (int)threadIdx.x / hp, cp = (int)threadIdx.x - px * hp;
@@ -793,7 +793,8 @@ static int groupnorm_impl(const void* x, const void* x2, const void* gamma, cons
     const int C = C1 + C2;
     SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm: G must divide 256 and be <= 64");
     SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm: C must be a multiple of 8 and of G");
-    if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0) {   // small feature map: single launch, data held in registers
+    // small feature map: single launch, data held in registers (its packed offsets need C / G <= 256 and HW * C < 2^25)
+    if ((long)HW * (C / G) <= 10240 && (C / G) % 2 == 0 && C / G <= 256 && (long)HW * C < (1L << 25)) {
         // (measured: a 40-pair variant for 20K-element groups is no faster than the stats + apply pair -- 64 blocks cannot
         // pull enough bandwidth)
         if (silu) gn_small_kernel<20, true><<<dim3(G, B), 256, 0, (hipStream_t)stream>>>((const h16_t*)x, (const h16_t*)gamma,

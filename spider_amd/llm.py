@@ -531,7 +531,8 @@ class LlamaEngine:
 
     def _generate_grouped(self, input_ids, inputs_embeds, attention_mask, position_ids, B_all: int, kw: dict, as_dict: bool):
         """More rows than one decode graph holds: groups of DECODE_ROWS, results joined the way one HF call would return
-        them (every row padded to the longest group with pad_token_id; a group that ended early repeats its last state)."""
+        them (every row padded to the longest group with pad_token_id; a group that ended early repeats the LAST POSITION of its
+        last state, [rows, 1, H], for the steps it did not run -- its first entry is the prompt state [rows, S, H])."""
         if kw.get("stopping_criteria"):
             raise NotImplementedError("stopping_criteria look at sequence 0 and end the whole batch (spider.py:55-73); "
                                       f"use them with at most {self.DECODE_ROWS} rows per call")
@@ -554,7 +555,8 @@ class LlamaEngine:
             n_steps = max(len(o.hidden_states) for o in outs)
             hs = []
             for stp in range(n_steps):
-                per = [o.hidden_states[min(stp, len(o.hidden_states) - 1)] for o in outs]
+                per = [o.hidden_states[stp] if stp < len(o.hidden_states) else tuple(h[:, -1:, :] for h in o.hidden_states[-1])
+                       for o in outs]
                 hs.append(tuple(torch.cat([p[l] for p in per], 0) for l in range(len(per[0]))))
             out.hidden_states = tuple(hs)
         if kw.get("return_logits"):

@@ -28,9 +28,31 @@ _WS = {}
 WS_BYTES = 64 << 20
 
 
+_WS_SCOPE = ["default"]
+
+
+class workspace_scope:
+    """`with ops.workspace_scope("llm"): ...` -- calls (and graph captures) inside the block use a split-K workspace of their own.
+    Reuse of a workspace is stream-ordered, so work that runs on two streams AT ONCE must not share one: bench.py's two-stream
+    schedule puts the LLM pass and the diffusion decoder in different scopes. A captured graph keeps the
+    workspace of the scope it was captured in."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        _WS_SCOPE.append(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _WS_SCOPE.pop()
+        return False
+
+
 def _workspace(device) -> torch.Tensor:
-    """Per-device fp32 split-K workspace (stream-ordered reuse; allocated once, outside any graph capture)."""
-    key = (device.type, device.index)
+    """Per-(device, scope) fp32 split-K workspace (stream-ordered reuse; allocated on first use, outside any graph capture:
+    engines run an eager warm-up pass before they capture)."""
+    key = (device.type, device.index, _WS_SCOPE[-1])
     if key not in _WS:
         _WS[key] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
     return _WS[key]

@@ -26,7 +26,7 @@ def _alphas_cumprod(beta_start=0.00085, beta_end=0.012, n=1000, beta_schedule="s
 
 
 def _check_config(name: str, prediction_type="epsilon", timestep_spacing="leading", clip_sample=False, thresholding=False,
-                  trained_betas=None, skip_prk_steps=True, **ignored):
+                  trained_betas=None, skip_prk_steps=True, rescale_betas_zero_snr=False, **ignored):
     """The fields of scheduler_config.json whose non-default values change the update rule: refuse them instead of
     silently denoising with the wrong coefficients (the checkpoints on the reference path -- SD-v1.5 PNDM, SDXL /
     zeroscope / AudioLDM DDIM -- all carry the values accepted here)."""
@@ -41,6 +41,8 @@ def _check_config(name: str, prediction_type="epsilon", timestep_spacing="leadin
         bad.append("thresholding=True")
     if trained_betas is not None:
         bad.append("trained_betas")
+    if rescale_betas_zero_snr:
+        bad.append("rescale_betas_zero_snr=True")
     if name == "PNDMScheduler" and not skip_prk_steps:
         bad.append("skip_prk_steps=False")
     if bad:
@@ -137,6 +139,15 @@ class DDIMScheduler:
 
 SCHEDULERS = {"PNDMScheduler": PNDMScheduler, "DDIMScheduler": DDIMScheduler}
 
+# diffusers==0.25.0 constructor defaults: what a scheduler_config.json that OMITS a key means (the Python constructors above default
+# to the values of the checkpoints on the reference path instead, for direct construction in tests / bench)
+_DIFFUSERS_DEFAULTS = {
+    "DDIMScheduler": dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", steps_offset=0,
+                          set_alpha_to_one=True, clip_sample=True),
+    "PNDMScheduler": dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", steps_offset=0,
+                          set_alpha_to_one=False, skip_prk_steps=False),
+}
+
 
 def scheduler_from_config(sc: dict):
     """scheduler/scheduler_config.json -> scheduler object. Unknown classes and update-rule options that are not
@@ -144,4 +155,6 @@ def scheduler_from_config(sc: dict):
     name = sc.get("_class_name")
     if name not in SCHEDULERS:
         raise NotImplementedError(f"scheduler class {name!r} (implemented: {sorted(SCHEDULERS)})")
-    return SCHEDULERS[name](**{k: v for k, v in sc.items() if not k.startswith("_")})
+    cfg = dict(_DIFFUSERS_DEFAULTS[name])
+    cfg.update({k: v for k, v in sc.items() if not k.startswith("_")})
+    return SCHEDULERS[name](**cfg)

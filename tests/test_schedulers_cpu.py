@@ -47,3 +47,14 @@ def test_scheduler_config_is_honoured_or_refused():
             S.scheduler_from_config({**sd15, **bad})
     with pytest.raises(NotImplementedError):
         S.scheduler_from_config({**sd15, "_class_name": "DDIMScheduler", "clip_sample": True})
+    # a key the JSON omits takes the diffusers-0.25 constructor default, not this module's: DDIM set_alpha_to_one=True and
+    # clip_sample=True (refused), PNDM skip_prk_steps=False (refused); rescale_betas_zero_snr changes the betas (refused)
+    ddim_min = {"_class_name": "DDIMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear", "clip_sample": False}
+    d = S.scheduler_from_config(ddim_min)
+    assert float(d.final_alpha) == 1.0 and d.offset == 0
+    with pytest.raises(NotImplementedError, match="clip_sample"):
+        S.scheduler_from_config({k: v for k, v in ddim_min.items() if k != "clip_sample"})
+    with pytest.raises(NotImplementedError, match="skip_prk_steps"):
+        S.scheduler_from_config({"_class_name": "PNDMScheduler"})
+    with pytest.raises(NotImplementedError, match="rescale_betas_zero_snr"):
+        S.scheduler_from_config({**ddim_min, "rescale_betas_zero_snr": True})
