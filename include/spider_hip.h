@@ -110,7 +110,7 @@ int spider_lm_head_argmax_fm_bf16(const void* Wfm, const void* x, int* out_ids, 
  * Prefill projections (modeling_llama3.py:186-313), diffusers Attention/FeedForward/proj linears. */
 int spider_gemm_bf16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                     float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 
 /* C = LayerNorm(A; gamma, beta, eps) . W^T + bias (+res) in ONE launch (act 0), or its GEGLU form (act 4, as above).
  * Replaces BasicTransformerBlock.norm1 / norm2 / norm3 + the projection that consumes it (attn1 to_q/k/v, attn2 to_q,
@@ -139,7 +139,7 @@ int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm,
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
 int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                            int pad, int ups, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 
 /* General NHWC conv as implicit GEMM: rectangular / dilated kernels (w OHWI [Cout,kh,kw,Cin], Cin % 8 == 0), a fused
  * nearest upsample to an explicit size up_h x up_w in (in, 2*in] (diffusers Upsample2D with `upsample_size`, reached when
@@ -150,7 +150,7 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
 int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 
 /* fused attention (prefill causal GQA: modeling_llama3.py:202-237; UNet self/cross attention:
  * StoryDiffusion/utils/gradio_utils.py:400-472; consistent self-attention with the column keep vector of
@@ -258,7 +258,7 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  * exist in bf16 only (the reference's LLM dtype). */
 int spider_gemm_f16(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                     float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 int spider_gemm_ln_f16(const void* A, const void* Wf, void* C, const float* colsum, const float* colbias, const void* res,
                         int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_xattn_fused_f16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
@@ -266,11 +266,11 @@ int spider_xattn_fused_f16(const void* x, const void* mq_fm, const void* mo_fm, 
                             void* stream);
 int spider_conv2d_nhwc_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                            int pad, int ups, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 int spider_conv_nhwc_ex_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream);
+                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
 int spider_attn_f16(const void* q, const void* k, const void* v, void* o,
                      long q_bs, long q_hs, long q_rs, long k_bs, long k_hs, long k_rs,
                      long v_bs, long v_hs, long v_rs, long o_bs, long o_hs, long o_rs,

@@ -35,6 +35,12 @@ struct GemmArgs {
     const h16_t* res;      // [M, ldc] or null (added after rounding the GEMM result to bf16)
     const h16_t* rowbias;  // [M / rows_per_group, N] or null (time-embedding add)
     float* C32;             // optional fp32 output instead of bf16
+    // fp32 residual stream: res32 [M, ldc] fp32 is added to the UNROUNDED fp32 GEMM result (instead of `res`,
+    // which is added after rounding the result to 16 bits as the reference's separate ops do), and c32d [M, ldc] fp32 receives
+    // the fp32 value that C gets rounded: the residual chain x <- x + f(x) is then carried in fp32 (one rounding per READ of the
+    // 16-bit shadow C instead of one accumulating rounding per add). Either may be null.
+    const float* res32;
+    float* c32d;
     float* ws;              // split-K workspace [splits, M, N] fp32
     int M, N, K, lda, ldc;
     uint32_t a_bytes, w_bytes;   // buffer-descriptor ranges of A and W (< 4 GiB each)
@@ -111,7 +117,11 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(p, v[e]);
         }
-        if (p.res) {
+        if (p.res32) {
+            const f32x4 rq = *reinterpret_cast<const f32x4*>(p.res32 + (size_t)m * p.ldc + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rq[e];
+        } else if (p.res) {
             const u32x2 rq = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldc + n);
             v[0] = h16_to_f32(f32_to_h16(v[0])) + h16lo_to_f32(rq.x);
             v[1] = h16_to_f32(f32_to_h16(v[1])) + h16hi_to_f32(rq.x);
@@ -120,6 +130,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        if (p.c32d) *reinterpret_cast<f32x4*>(p.c32d + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
         if (p.C32) {
             *reinterpret_cast<f32x4*>(p.C32 + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
@@ -134,8 +145,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             if (p.bias) t += h16_to_f32(p.bias[n + e]);
             if (p.rowbias) t += h16_to_f32(p.rowbias[(size_t)grp * p.N + n + e]);
             if (ACT) t = apply_act(p, t);
-            if (p.res) t = h16_to_f32(f32_to_h16(t)) + h16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
+            if (p.res32) t += p.res32[(size_t)m * p.ldc + n + e];
+            else if (p.res) t = h16_to_f32(f32_to_h16(t)) + h16_to_f32(p.res[(size_t)m * p.ldc + n + e]);
             t *= p.out_scale;
+            if (p.c32d) p.c32d[(size_t)m * p.ldc + n + e] = t;
             if (p.C32) p.C32[(size_t)m * p.ldc + n + e] = t;
             else p.C[(size_t)m * p.ldc + n + e] = f32_to_h16(t);
         }
@@ -148,7 +161,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
 // "is this operand present" branches. (Reading absent operands through zero-range descriptors instead was measured
 // slower: 48 useless memory instructions per thread.)
 struct EpiRsrc {
-    __amdgpu_buffer_rsrc_t bias, rowbias, res, c;
+    __amdgpu_buffer_rsrc_t bias, rowbias, res, c, res32, c32d;
 };
 
 __device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemmArgs& p) {
@@ -157,6 +170,9 @@ __device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemmArgs& p) {
     r.rowbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.rowbias), 0, p.rowbias ? (int)p.rb_bytes : 0, 0x00020000);
     r.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.res), 0, p.res ? (int)p.c_bytes : 0, 0x00020000);
     r.c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+    // fp32 stream operands: twice the byte range of C (host-checked to stay below 2 GiB when they are given)
+    r.res32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res32), 0, p.res32 ? (int)(2 * p.c_bytes) : 0, 0x00020000);
+    r.c32d = __builtin_amdgcn_make_buffer_rsrc(p.c32d, 0, p.c32d ? (int)(2 * p.c_bytes) : 0, 0x00020000);
     return r;
 }
 
@@ -178,13 +194,20 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const EpiRsrc& 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(p, v[e]);
     }
-    if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
+    const uint32_t off32 = (off << 1) | inv;      // byte offset of the same element in an fp32 [M, ldc] array
+    if (p.res32) {   // fp32 residual stream: added to the unrounded result
+        const f32x4 rq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res32, off32, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rq[e];
+    } else if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
         const u32x2 rq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r.res, off, 0, 0));
         v[0] = h16_to_f32(f32_to_h16(v[0])) + h16lo_to_f32(rq.x); v[1] = h16_to_f32(f32_to_h16(v[1])) + h16hi_to_f32(rq.x);
         v[2] = h16_to_f32(f32_to_h16(v[2])) + h16lo_to_f32(rq.y); v[3] = h16_to_f32(f32_to_h16(v[3])) + h16hi_to_f32(rq.y);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+    if (p.c32d)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r.c32d, 0, 0, 0)), f32x4{v[0], v[1], v[2], v[3]}), r.c32d, off32, 0, 0);
     u32x2 o;
     o.x = pack_h16x2(v[0], v[1]);
     o.y = pack_h16x2(v[2], v[3]);
@@ -207,7 +230,13 @@ __device__ __forceinline__ void epilogue_fast8(const GemmArgs& p, const EpiRsrc&
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = apply_act(p, v[e]);
     }
-    if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
+    const uint32_t off32 = (off << 1) | inv;      // byte offset of the same 8 elements in an fp32 [M, ldc] array (two 16-byte halves)
+    if (p.res32) {   // fp32 residual stream: added to the unrounded result
+        const f32x4 r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res32, off32, 0, 0));
+        const f32x4 r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res32, (off32 + 16u) | inv, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+    } else if (p.res) {   // the GEMM result is rounded to bf16 before the residual add, as the reference's separate ops do
         const u32x4 rq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.res, off, 0, 0));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = h16_to_f32(f32_to_h16(v[e]));
@@ -215,6 +244,11 @@ __device__ __forceinline__ void epilogue_fast8(const GemmArgs& p, const EpiRsrc&
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    if (p.c32d) {
+        typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r.c32d, 0, 0, 0)) vec_t;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vec_t, f32x4{v[0], v[1], v[2], v[3]}), r.c32d, off32, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vec_t, f32x4{v[4], v[5], v[6], v[7]}), r.c32d, (off32 + 16u) | inv, 0, 0);
+    }
     u32x4 o;
     o.x = pack_h16x2(v[0], v[1]); o.y = pack_h16x2(v[2], v[3]); o.z = pack_h16x2(v[4], v[5]); o.w = pack_h16x2(v[6], v[7]);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r.c, 0, 0, 0)), o), r.c, off, 0, 0);
@@ -1586,9 +1620,11 @@ extern "C" {
 // ldc applies to C, C32 and res. ws/ws_bytes: optional fp32 split-K workspace (NULL disables split-K).
 // w_tiled != 0: W is the tile-major copy [ceil(N/64)][ceil(K/64)][64][64] of the [N, K] weight (GemmArgs::w_tiled; built by the
 // caller once per weight: pure data movement, like the OIHW -> OHWI conv repack).
+// res32 / c32d (either may be NULL): the fp32 residual stream -- res32 [M, ldc] fp32 replaces `res` and is added to the unrounded
+// result; c32d [M, ldc] fp32 receives the fp32 value that C rounds (GemmArgs::res32). Need the 16-bit output C.
 int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, const void* bias, const void* res,
                      const void* rowbias, int rows_per_group, int M, int N, int K, int lda, int ldc, int act,
-                     float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
+                     float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
     SPIDER_CHECK(ldc % 4 == 0 && ldc >= (act == 4 ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
@@ -1596,7 +1632,10 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
     SPIDER_CHECK(!rowbias || rows_per_group > 0, "gemm: rowbias needs rows_per_group > 0");
     SPIDER_CHECK(act >= 0 && act <= 7, "gemm: unknown activation");
     SPIDER_CHECK(act != 4 || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU epilogue needs bf16 output, even N, no res/rowbias");
+    SPIDER_CHECK((!res32 && !c32d) || (C && act != 4 && !(res && res32) && (size_t)M * ldc * 4 < ((size_t)1 << 31)),
+                 "gemm: the fp32 residual stream needs the 16-bit output, no GEGLU, at most one residual, and < 2 GiB of fp32 rows");
     GemmArgs a{};
+    a.res32 = res32; a.c32d = c32d;
     a.A = (const h16_t*)A; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.C32 = (float*)C32;
     a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = rows_per_group; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc;
@@ -1651,7 +1690,7 @@ int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const floa
 int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
+                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv: empty problem");
     SPIDER_CHECK(kh >= 1 && kw >= 1 && kh * kw <= 64 && dil >= 1, "conv: kernel taps must be 1..64, dilation >= 1");
     SPIDER_CHECK(stride == 1 || stride == 2, "conv: stride must be 1 or 2");
@@ -1670,7 +1709,10 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
     const int Hs = ups ? up_h : Hin, Ws = ups ? up_w : Win;
     const int Hout = (Hs + 2 * pad_h - dil * (kh - 1) - 1) / stride + 1, Wout = (Ws + 2 * pad_w - dil * (kw - 1) - 1) / stride + 1;
     SPIDER_CHECK(Hout > 0 && Wout > 0, "conv: kernel larger than the padded input");
+    SPIDER_CHECK((!res32 && !c32d) || (!(res && res32) && (size_t)B * Hout * Wout * Cout * 4 < ((size_t)1 << 31)),
+                 "conv: the fp32 residual stream takes at most one residual and < 2 GiB of fp32 output");
     GemmArgs a{};
+    a.res32 = res32; a.c32d = c32d;
     a.A = (const h16_t*)x; a.W = (const h16_t*)w; a.C = (h16_t*)y; a.C32 = nullptr;
     a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = Hout * Wout; a.M = B * Hout * Wout; a.N = Cout; a.K = kh * kw * Cin; a.lda = Cin; a.ldc = Cout;
@@ -1689,11 +1731,12 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
 // ups=1 fuses the exact nearest-2x upsample.
 int SPIDER_FN(spider_conv2d_nhwc)(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
-                            int pad, int ups, float out_scale, int w_tiled, void* ws, long ws_bytes, void* stream) {
+                            int pad, int ups, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes,
+                            void* stream) {
     SPIDER_CHECK(ks == 1 || ks == 3, "conv2d: kernel size must be 1 or 3");
     SPIDER_CHECK(Cin % 64 == 0, "conv2d: Cin must be a multiple of 64 for the MFMA path (use conv2d_small)");
     return SPIDER_FN(spider_conv_nhwc_ex)(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, ks, ks, stride, pad, pad, 1,
-                                    ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, w_tiled, ws, ws_bytes, stream);
+                                    ups ? 2 * Hin : 0, ups ? 2 * Win : 0, 0, 0.f, out_scale, w_tiled, res32, c32d, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -41,11 +41,11 @@ SIGNATURES = {
     "spider_rope_kv_append_mrope_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "spider_attn_decode_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_attn_decode_fused_bf16": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
-    "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _l, _vp]),
+    "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _l, _vp]),
     "spider_xattn_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _l, _vp]),
-    "spider_conv_nhwc_ex_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _i, _vp, _l, _vp]),
+    "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _l, _vp]),
+    "spider_conv_nhwc_ex_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_attn_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _i, _i, _vp, _vp, _i, _i, _vp]),
     "spider_story_key_lists_i32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "spider_attn_keylist_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _vp, _i, _vp, _i, _vp]),

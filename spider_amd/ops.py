@@ -304,8 +304,11 @@ def attn_decode_fused(qkv, pos, cos_sin, k_cache, v_cache, kv_end, kv_beg, count
 
 
 # --------------------------------------------------------------------------- GEMM / conv / attention
-def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, out_scale=1.0, out=None, out_f32=False):
-    """C = act(A @ W^T + bias + rowbias[row // rows_per_group]) (+ res) * out_scale.  A [..., K], W [N, K]."""
+def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, out_scale=1.0, out=None, out_f32=False,
+         res32=None, want32=False):
+    """C = act(A @ W^T + bias + rowbias[row // rows_per_group]) (+ res) * out_scale.  A [..., K], W [N, K].
+    fp32 residual stream: res32 (fp32, shape of C) replaces `res` and is added to the unrounded result; want32=True returns
+    (C, C32) with C32 the fp32 value that C rounds."""
     dt, sfx = _h16(A)
     _chk(A, dt, "A"); _chk(W, dt, "W")
     N, K = W.shape
@@ -316,9 +319,13 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
         out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else dt, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
     wt = _tiled(W, M)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=A.device) if want32 else None
+    if res32 is not None:
+        _chk(res32, torch.float32, "res32")
     _lib.call(f"spider_gemm_{sfx}", _p(A), _p(W if wt is None else wt), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
-              M, N, K, K, n_out, ACT[act], float(out_scale), int(wt is not None), _p(_workspace(A.device)), WS_BYTES, _stream())
-    return out
+              M, N, K, K, n_out, ACT[act], float(out_scale), int(wt is not None), _p(res32), _p(o32), _p(_workspace(A.device)), WS_BYTES,
+              _stream())
+    return (out, o32) if want32 else out
 
 
 def fold_layernorm(W, gamma, beta, bias=None):
@@ -373,8 +380,8 @@ def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps
     return out
 
 
-def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None):
-    """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]."""
+def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None, res32=None, want32=False):
+    """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]. res32 / want32: fp32 residual stream as in gemm()."""
     dt, sfx = _h16(x)
     _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
@@ -386,9 +393,13 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
     wt = _tiled(w, B * Ho * Wo)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
+    if res32 is not None:
+        _chk(res32, torch.float32, "res32")
     _lib.call(f"spider_conv2d_nhwc_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin, Cout,
-              ks, stride, pad, int(ups), float(out_scale), int(wt is not None), _p(_workspace(x.device)), WS_BYTES, _stream())
-    return out
+              ks, stride, pad, int(ups), float(out_scale), int(wt is not None), _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES,
+              _stream())
+    return (out, o32) if want32 else out
 
 
 def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1, up_size=None, act=None, act_param=0.0,
@@ -409,7 +420,7 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     wt = _tiled(w, B * Ho * Wo)
     _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
               Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
-              _p(_workspace(x.device)), WS_BYTES, _stream())
+              None, None, _p(_workspace(x.device)), WS_BYTES, _stream())
     return out
 
 

@@ -113,12 +113,16 @@ def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos=True, shift=0.
 
 
 class UNetEngine:
-    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False):
         """dtype: torch.bfloat16 or torch.float16 -- the 16-bit storage / MFMA operand format of the whole engine (the reference
         loads its diffusion decoders with torch_dtype=torch.float16, spider_decoder.py:109; both instantiations of every kernel
-        exist, see csrc/common.hpp)."""
+        exist, see csrc/common.hpp).
+        stream32: carry the residual stream (resnet outputs, the token stream of the transformer blocks) as an fp32 master beside
+        its 16-bit shadow: every `x + f(x)` adds in fp32 (GEMM / conv epilogue operands res32 / c32d), every consumer (GroupNorm,
+        folded LayerNorm, MFMA operands) reads the shadow. Removes the accumulating rounding of ~70 residual adds per evaluation
+        (the second precision lever next to dtype); the fused cross-attention kernel is not used in this mode."""
         assert dtype in (torch.bfloat16, torch.float16), "UNetEngine: dtype must be bfloat16 or float16"
-        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.cfg, self.device, self.dtype, self.stream32 = cfg, torch.device(device), dtype, bool(stream32)
         BF16 = dtype      # every 16-bit tensor this engine creates is of the engine dtype
         self.w: Dict[str, torch.Tensor] = {}
         dv = self.device
@@ -152,7 +156,7 @@ class UNetEngine:
                                                     W[b + ".ff.net.0.proj.bias"])
         # Fused cross-attention sub-block (ops.xattn_fused): weight-only halves of the per-prompt fold (prepare() finishes it
         # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
-        self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
+        self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0" and not self.stream32
         self.gn_cat = os.environ.get("SPIDER_GN_CAT", "1") != "0"     # up-block norm1 reads (hidden, skip) in place (tuning aid)
         self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
         self.xw: Dict[str, dict] = {}
@@ -210,7 +214,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0, dtype=BF16):
+    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False):
         from_shapes = _param_shapes(cfg)
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
@@ -222,10 +226,10 @@ class UNetEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(torch.bfloat16)     # same values for either engine dtype (bf16-representable, exact in f16 too)
-        return cls(cfg, w, device, dtype=dtype)
+        return cls(cfg, w, device, dtype=dtype, stream32=stream32) if stream32 else cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
         """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors."""
         import glob, json, os
         from safetensors import safe_open
@@ -235,7 +239,7 @@ class UNetEngine:
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype)
+        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
 
     # ------------------------------------------------------------------ per-call preparation
     def prepare(self, timesteps: torch.Tensor, enc: Optional[torch.Tensor], added: Optional[dict] = None,
@@ -355,9 +359,18 @@ class UNetEngine:
         h = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n])
         a = self._gn(n + ".norm2", h, True)
         sc = x
+        if not self.stream32:
+            if n + ".conv_shortcut.weight" in w:
+                sc = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0)
+            return ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=sc)
+        # fp32 residual stream: the shortcut (identity: the block input's master; 1x1 conv: its unrounded output) is added in fp32
+        sc32 = getattr(x, "_s32", None)
         if n + ".conv_shortcut.weight" in w:
-            sc = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0)
-        return ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=sc)
+            sc, sc32 = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0, want32=True)
+        out, out32 = ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=None if sc32 is not None else sc,
+                                res32=sc32, want32=True)
+        out._s32 = out32
+        return out
 
     def _self_attn(self, b, y, heads):
         """y [B, N, C] (LayerNorm output) -> attention output before the to_out projection's residual."""
@@ -391,7 +404,15 @@ class UNetEngine:
         w = self.w
         B, H, W_, C = x.shape
         a = self._gn(n + ".norm", x, False, eps=1e-6)
-        h = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
+        s32 = self.stream32
+        h32 = None
+        # stream32: every residual GEMM below takes the stream's fp32 master (res32) and returns the new master beside the shadow
+        rg = (lambda A_, W_w, bias, h_, h32_: ops.gemm(A_, W_w, bias=bias, res32=h32_, want32=True)) if s32 else \
+             (lambda A_, W_w, bias, h_, h32_: (ops.gemm(A_, W_w, bias=bias, res=h_), None))
+        if s32:
+            h, h32 = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+        else:
+            h = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
             fuse = self.fuse_ln
@@ -403,7 +424,7 @@ class UNetEngine:
                 o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
             else:
                 o = self._self_attn(b, ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"]), heads)
-            h = ops.gemm(o, w[b + ".attn1.to_out.0.weight"], bias=w[b + ".attn1.to_out.0.bias"], res=h)
+            h, h32 = rg(o, w[b + ".attn1.to_out.0.weight"], w[b + ".attn1.to_out.0.bias"], h, h32)
             xf = self.xf.get(b) if fuse else None
             # Fused where it wins (measured, scripts/bench_xattn.py: 17 vs 31 us at 2 x 4096 tokens / C = 320, 22 vs 29 us at
             # 2 x 1024 / 640): with fewer than ~64 row tiles (the 16^2 / 8^2 maps at C = 1280: 46 vs 34 us, 36 vs 29 us) one block's
@@ -415,13 +436,21 @@ class UNetEngine:
                     o = self._cross_attn(b, h, heads, ln_input=True)
                 else:
                     o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
-                h = ops.gemm(o, w[b + ".attn2.to_out.0.weight"], bias=w[b + ".attn2.to_out.0.bias"], res=h)
+                h, h32 = rg(o, w[b + ".attn2.to_out.0.weight"], w[b + ".attn2.to_out.0.bias"], h, h32)
             if fuse:       # norm3 + GEGLU projection: one launch
                 g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
             else:
                 y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
                 g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
-            h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
+            h, h32 = rg(g, w[b + ".ff.net.2.weight"], w[b + ".ff.net.2.bias"], h, h32)
+        if s32:
+            x32 = getattr(x, "_s32", None)
+            out, out32 = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], want32=True,
+                                  res=None if x32 is not None else x.view(B, H * W_, C),
+                                  res32=None if x32 is None else x32.view(B, H * W_, C))
+            outv = out.view(B, H, W_, C)
+            outv._s32 = out32.view(B, H, W_, C)
+            return outv
         out = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res=x.view(B, H * W_, C))
         return out.view(B, H, W_, C)
 

@@ -43,8 +43,8 @@ def test_identity_and_argument_validation():
     # validation happens on the host before any launch: bad shapes return -1 with a message, no GPU needed
     assert lib.spider_gemv_bf16(None, None, None, None, None, None, 0.0, 17, 16, 64, None) == -1
     assert b"batch" in lib.spider_last_error()
-    assert lib.spider_gemm_bf16(None, None, None, None, None, None, None, 0, 4, 4, 7, 8, 4, 0, 1.0, 0, None, 0, None) == -1
-    assert lib.spider_gemm_f16(None, None, None, None, None, None, None, 0, 4, 4, 7, 8, 4, 0, 1.0, 0, None, 0, None) == -1
+    assert lib.spider_gemm_bf16(None, None, None, None, None, None, None, 0, 4, 4, 7, 8, 4, 0, 1.0, 0, None, None, None, 0, None) == -1
+    assert lib.spider_gemm_f16(None, None, None, None, None, None, None, 0, 4, 4, 7, 8, 4, 0, 1.0, 0, None, None, None, 0, None) == -1
     assert lib.spider_attn_bf16(None, None, None, None, *([0] * 12), 1, 8, 8, 16, 16, 200, 1.0, 0, 0, None, None, 0, 0, None) == -1
     assert b"head_dim" in lib.spider_last_error()
     try:

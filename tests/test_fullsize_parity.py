@@ -22,10 +22,11 @@ pytestmark = pytest.mark.gpu
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 # one UNet evaluation, rel-L2 against the fp32 oracle; measured on MI355X (round 3) + 20 %
 BOUND = {
-    "sd15": {"bf16": 2.2e-2, "f16": 3.0e-3},
-    "sdxl": {"bf16": 3.0e-2, "f16": 4.0e-3},
-    "audioldm_l": {"bf16": 2.2e-2, "f16": 3.0e-3},
-    "zeroscope": {"bf16": 2.6e-2, "f16": 3.5e-3},
+    "sd15": {"bf16": 1.6e-2, "f16": 2.0e-3},             # measured 1.305e-2 / 1.64e-3
+    "sd15_s32": {"bf16": 1.6e-2, "f16": 2.0e-3},         # fp32 residual stream: must not exceed the 16-bit-stream bound
+    "sdxl": {"bf16": 2.0e-2, "f16": 2.4e-3},             # 1.637e-2 / 1.97e-3
+    "audioldm_l": {"bf16": 1.4e-2, "f16": 1.75e-3},      # 1.154e-2 / 1.43e-3
+    "zeroscope": {"bf16": 1.9e-2, "f16": 2.3e-3},        # 1.541e-2 / 1.92e-3
 }
 
 
@@ -54,20 +55,22 @@ def sd15_case():
     _free()
 
 
+@pytest.mark.parametrize("stream32", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype):
+def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype, stream32):
+    """The 2 x 2 precision table of DESIGN.md section 4 at the configs[1] size: {bf16, f16} x {16-bit, fp32 residual stream}."""
     from spider_amd.unet import UNetConfig, UNetEngine
     ocfg, w, x, enc, t, ref = sd15_case
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype])
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=DT[dtype], stream32=stream32)
     eng.prepare(torch.tensor([int(t)]), enc.to(dev))
-    assert len(eng.xf) > 0, "the SD-v1.5 64^2 / 32^2 sites must take the fused cross-attention path"
+    assert stream32 or len(eng.xf) > 0, "the SD-v1.5 64^2 / 32^2 sites must take the fused cross-attention path"
     xn = x.permute(0, 2, 3, 1).contiguous().to(dev).to(DT[dtype])
     eager = eng.step(xn, 0, use_graph=False).permute(0, 3, 1, 2).clone()
     graph = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
     assert torch.equal(eager, graph), "hipGraph replay must be bit-identical to eager launches"
     r = _rel(eager, ref)
-    print(f"MEASURED fullsize sd15 unet_step dtype={dtype} rel={r:.5f}")
-    assert r < BOUND["sd15"][dtype], r
+    print(f"MEASURED fullsize sd15 unet_step dtype={dtype} stream32={stream32} rel={r:.5f}")
+    assert r < BOUND["sd15_s32" if stream32 else "sd15"][dtype], r
     del eng
     _free()
 
@@ -173,7 +176,7 @@ def test_llm_fullwidth_layers_match_oracle(dev, model):
     ref_steps = logits[:, S - 1:S + T - 1]
     r = float((got_steps - ref_steps).norm() / ref_steps.norm())
     print(f"MEASURED fullwidth {model} step-logits rel={r:.5f}")
-    assert r < 2.5e-2, r
+    assert r < 2.1e-2, r        # measured 1.62e-2 (Qwen) / 1.71e-2 (Llama) + 20 %
     # the engine's choice is within bf16 resolution of the oracle's best logit at every step
     for t in range(T):
         tok = int(seq[0, S + t])
