@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--throughput-batch", type=int, default=8,
                    help="also report (outside the timed region, as an extra field) the rate with this many prompts per GPU; 0 = skip")
     p.add_argument("--llm", default="qwen25_7b", choices=["qwen25_7b", "llama3_8b"])
+    p.add_argument("--no-stream32", action="store_true",
+                   help="UNet residual stream in 16 bits instead of the fp32 master + 16-bit shadow the pipelines load by default")
     p.add_argument("--diffusion-dtype", default="f16", choices=["f16", "bf16"],
                    help="16-bit format of the UNet / text-encoder / VAE engines (f16 = the reference's torch_dtype)")
     a = p.parse_args()
@@ -114,7 +116,7 @@ class Responder:
         cfg = getattr(LLMConfig, args.llm)()
         self.max_batch = max(args.batch, min(args.throughput_batch, 8))
         self.llm = LlamaEngine.random_init(cfg, device, max_batch=self.max_batch, max_len=args.prompt_len + args.new_tokens + 8, seed=0)
-        self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1, dtype=DIFF_DT)
+        self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1, dtype=DIFF_DT, stream32=not args.no_stream32)
         self.sched = PNDMScheduler()
         self.text_enc = self.vae = None
         try:
@@ -243,10 +245,10 @@ class AnyToManyResponder:
         cfg = getattr(LLMConfig, args.llm)()
         self.llm = LlamaEngine.random_init(cfg, dev, max_batch=min(args.batch, 8), max_len=args.prompt_len + args.new_tokens + 8, seed=0)
         D = DIFF_DT
-        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1, dtype=D), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2, dtype=D),
+        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1, dtype=D, stream32=not args.no_stream32), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2, dtype=D),
                                      CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 3, dtype=D), FakeTokenizer(40000))
         ad = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), dev, 4, dtype=D), ClapTextEngine.random_init(ClapTextConfig(), dev, 5, dtype=D),
-                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6, dtype=D),
+                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6, dtype=D, stream32=not args.no_stream32),
                               DDIMScheduler(beta_start=0.0015, beta_end=0.0195), HifiGanEngine.random_init(HifiGanConfig.audioldm(), dev, 7, dtype=D))
         vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8, dtype=D), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9, dtype=D),
                                    CLIPTextEngine.random_init(CLIPTextConfig(49408, 1024, 23, 16, 4096, 77, 1e-5, "gelu"), dev, 10, dtype=D),
@@ -733,7 +735,8 @@ def main():
         total = world * args.batch * args.steps
         base = {"value": round(total / dt, 4), "unit": "responses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "diffusion_dtype": args.diffusion_dtype, "data": "synthetic", "dist": dist_info}
+                "dtype": "bf16", "diffusion_dtype": args.diffusion_dtype, "unet_residual_stream": "fp32" if not args.no_stream32 else "16-bit",
+                "data": "synthetic", "dist": dist_info}
         if g is not None:
             base["gathered"] = {k: list(v.shape) for k, v in g.items()}
             base["gather_bytes_per_rank"] = int(sum(v[0].numel() * v[0].element_size() for v in g.values()))

@@ -133,7 +133,7 @@ int spider_gemm_ln_bf16(const void* A, const void* Wf, void* C, const float* col
  * x, out [B2 * n_tok, C] bf16 (sample-major rows); C % 64 == 0, C <= 1280; n_tok % 16 == 0. */
 int spider_xattn_fused_bf16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
                             const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
-                            void* stream);
+                            const float* x32, float* out32, void* stream);
 
 /* conv2d NHWC as implicit GEMM (ResnetBlock2D / Downsample2D / Upsample2D convs reached from
  * custom_sd.py:634-639). w is OHWI [Cout,ks,ks,Cin]; ups=1 fuses the nearest-2x upsample. */
@@ -263,7 +263,7 @@ int spider_gemm_ln_f16(const void* A, const void* Wf, void* C, const float* cols
                         int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream);
 int spider_xattn_fused_f16(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
                             const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
-                            void* stream);
+                            const float* x32, float* out32, void* stream);
 int spider_conv2d_nhwc_f16(const void* x, const void* w, void* y, const void* bias, const void* res,
                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride,
                             int pad, int ups, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);

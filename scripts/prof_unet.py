@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 import os
 DT = torch.float16 if os.environ.get("UNET_DTYPE", "f16") == "f16" else torch.bfloat16
-unet = UNetEngine.random_init(UNetConfig.sd15(), dev, seed=1, dtype=DT)
+unet = UNetEngine.random_init(UNetConfig.sd15(), dev, seed=1, dtype=DT, stream32=os.environ.get("UNET_STREAM32", "0") == "1")
 g = torch.Generator(device=dev).manual_seed(0)
 lat = torch.randn(1, 4, 64, 64, generator=g, device=dev)
 enc = torch.randn(2, 77, 768, generator=g, device=dev).to(DT)

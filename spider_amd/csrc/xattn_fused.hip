@@ -37,6 +37,8 @@ struct XArgs {
     const float* colbias;   // [B2, XHL]
     const h16_t* bias_o;   // [C]
     h16_t* out;            // [rows, C]
+    const float* x32;      // optional fp32 master of the residual stream [rows, C]: added to the unrounded result instead of x
+    float* out32;          // optional fp32 master of the output [rows, C] (UNetEngine stream32, see gemm.hip GemmArgs::res32)
     int rows, C, n_tok, n_keys;
     float eps;
 };
@@ -243,11 +245,17 @@ __global__ __launch_bounds__(512) void xattn_fused_kernel(XArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const size_t off = (size_t)(row0 + mt * 16 + r16) * C + c;
-            const u32x2 rq = *reinterpret_cast<const u32x2*>(p.x + off);
             float v0 = acc2[i][mt][0] + h16lo_to_f32(bq.x), v1 = acc2[i][mt][1] + h16hi_to_f32(bq.x);
             float v2 = acc2[i][mt][2] + h16lo_to_f32(bq.y), v3 = acc2[i][mt][3] + h16hi_to_f32(bq.y);
-            v0 = h16_to_f32(f32_to_h16(v0)) + h16lo_to_f32(rq.x); v1 = h16_to_f32(f32_to_h16(v1)) + h16hi_to_f32(rq.x);
-            v2 = h16_to_f32(f32_to_h16(v2)) + h16lo_to_f32(rq.y); v3 = h16_to_f32(f32_to_h16(v3)) + h16hi_to_f32(rq.y);
+            if (p.x32) {      // fp32 residual stream: no rounding before the add
+                const f32x4 rq = *reinterpret_cast<const f32x4*>(p.x32 + off);
+                v0 += rq[0]; v1 += rq[1]; v2 += rq[2]; v3 += rq[3];
+            } else {
+                const u32x2 rq = *reinterpret_cast<const u32x2*>(p.x + off);
+                v0 = h16_to_f32(f32_to_h16(v0)) + h16lo_to_f32(rq.x); v1 = h16_to_f32(f32_to_h16(v1)) + h16hi_to_f32(rq.x);
+                v2 = h16_to_f32(f32_to_h16(v2)) + h16lo_to_f32(rq.y); v3 = h16_to_f32(f32_to_h16(v3)) + h16hi_to_f32(rq.y);
+            }
+            if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + off) = f32x4{v0, v1, v2, v3};
             u32x2 o2;
             o2.x = pack_h16x2(v0, v1);
             o2.y = pack_h16x2(v2, v3);
@@ -275,7 +283,7 @@ extern "C" {
 // output column tiles per wave), n_tok a multiple of the row tile (16; 32 / 64 are chosen when the grid still fills the chip).
 int SPIDER_FN(spider_xattn_fused)(const void* x, const void* mq_fm, const void* mo_fm, const float* colsum, const float* colbias,
                             const void* bias_o, void* out, int B2, int n_tok, int C, int heads, int n_keys, float eps,
-                            void* stream) {
+                            const float* x32, float* out32, void* stream) {
     SPIDER_CHECK(heads == XH, "xattn_fused: built for 8 heads");
     SPIDER_CHECK(B2 > 0 && n_tok > 0 && n_tok % 16 == 0, "xattn_fused: tokens per sample must be a multiple of 16");
     SPIDER_CHECK(C % 64 == 0 && C >= 64 && C <= 1280, "xattn_fused: C must be a multiple of 64, <= 1280");
@@ -283,6 +291,7 @@ int SPIDER_FN(spider_xattn_fused)(const void* x, const void* mq_fm, const void* 
     SPIDER_CHECK((size_t)B2 * n_tok * C * 2 < ((size_t)1 << 31), "xattn_fused: activations must be < 2 GiB");
     XArgs a{};
     a.x = (const h16_t*)x; a.mq = (const h16_t*)mq_fm; a.mo = (const h16_t*)mo_fm; a.colsum = colsum; a.colbias = colbias;
+    a.x32 = x32; a.out32 = out32;
     a.bias_o = (const h16_t*)bias_o; a.out = (h16_t*)out; a.rows = B2 * n_tok; a.C = C; a.n_tok = n_tok; a.n_keys = n_keys; a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     const int ctw = (C / 16 + 7) / 8;           // output column tiles per wave

@@ -43,7 +43,7 @@ SIGNATURES = {
     "spider_attn_decode_fused_bf16": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _l, _vp]),
-    "spider_xattn_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "spider_xattn_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "spider_conv2d_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_conv_nhwc_ex_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_attn_bf16": (_i, [_vp, _vp, _vp, _vp] + [_l] * 12 + [_i] * 6 + [_f, _i, _i, _vp, _vp, _i, _i, _vp]),

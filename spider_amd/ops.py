@@ -365,7 +365,7 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
 XATTN_LP = 80     # keys per head in the folded cross-attention operands (77 text tokens padded to a multiple of 16)
 
 
-def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps=1e-5, out=None):
+def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps=1e-5, out=None, x32=None, want32=False):
     """x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) with the prompt's K / V folded into mq_fm / mo_fm (see
     include/spider_hip.h, spider_xattn_fused_bf16, and UNetEngine.prepare). x [B2, n_tok, C] or [B2 * n_tok, C] bf16."""
     dt, sfx = _h16(x)
@@ -375,9 +375,12 @@ def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps
     n_tok = x.numel() // (C * B2)
     if out is None:
         out = torch.empty_like(x)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
+    if x32 is not None:
+        _chk(x32, torch.float32, "x32")
     _lib.call(f"spider_xattn_fused_{sfx}", _p(x), _p(mq_fm), _p(mo_fm), _p(colsum), _p(colbias), _p(bias_o), _p(out), B2, n_tok, C,
-              heads, n_keys, float(eps), _stream())
-    return out
+              heads, n_keys, float(eps), _p(x32), _p(o32), _stream())
+    return (out, o32) if want32 else out
 
 
 def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None, res32=None, want32=False):

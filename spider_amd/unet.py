@@ -120,7 +120,7 @@ class UNetEngine:
         stream32: carry the residual stream (resnet outputs, the token stream of the transformer blocks) as an fp32 master beside
         its 16-bit shadow: every `x + f(x)` adds in fp32 (GEMM / conv epilogue operands res32 / c32d), every consumer (GroupNorm,
         folded LayerNorm, MFMA operands) reads the shadow. Removes the accumulating rounding of ~70 residual adds per evaluation
-        (the second precision lever next to dtype); the fused cross-attention kernel is not used in this mode."""
+        (the second precision lever next to dtype)."""
         assert dtype in (torch.bfloat16, torch.float16), "UNetEngine: dtype must be bfloat16 or float16"
         self.cfg, self.device, self.dtype, self.stream32 = cfg, torch.device(device), dtype, bool(stream32)
         BF16 = dtype      # every 16-bit tensor this engine creates is of the engine dtype
@@ -156,7 +156,7 @@ class UNetEngine:
                                                     W[b + ".ff.net.0.proj.bias"])
         # Fused cross-attention sub-block (ops.xattn_fused): weight-only halves of the per-prompt fold (prepare() finishes it
         # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
-        self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0" and not self.stream32
+        self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
         self.gn_cat = os.environ.get("SPIDER_GN_CAT", "1") != "0"     # up-block norm1 reads (hidden, skip) in place (tuning aid)
         self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
         self.xw: Dict[str, dict] = {}
@@ -430,7 +430,11 @@ class UNetEngine:
             # 2 x 1024 / 640): with fewer than ~64 row tiles (the 16^2 / 8^2 maps at C = 1280: 46 vs 34 us, 36 vs 29 us) one block's
             # serial chain of 20 + 20 dependent operand loads is longer than the three launches it replaces, which spread over the chip.
             if xf is not None and (H * W_) % 16 == 0 and B * H * W_ >= self.xattn_min_rows:   # norm2 + to_q + attention + to_out + residual
-                h = ops.xattn_fused(h, xf["mq_fm"], xf["mo_fm"], xf["cs"], xf["cb"], w[b + ".attn2.to_out.0.bias"], B, heads, self._enc_len)
+                if s32:
+                    h, h32 = ops.xattn_fused(h, xf["mq_fm"], xf["mo_fm"], xf["cs"], xf["cb"], w[b + ".attn2.to_out.0.bias"], B, heads,
+                                             self._enc_len, x32=h32, want32=True)
+                else:
+                    h = ops.xattn_fused(h, xf["mq_fm"], xf["mo_fm"], xf["cs"], xf["cb"], w[b + ".attn2.to_out.0.bias"], B, heads, self._enc_len)
             else:
                 if fuse:
                     o = self._cross_attn(b, h, heads, ln_input=True)

@@ -17,7 +17,7 @@ def test_overlapped_schedule_equals_serial(dev):
     spec.loader.exec_module(bench)
     bench.DIFF_DT = torch.float16
     args = argparse.Namespace(llm="qwen25_7b", batch=1, throughput_batch=0, prompt_len=192, new_tokens=12, denoise_steps=5,
-                              schedule="overlap", workload="text_image")
+                              schedule="overlap", workload="text_image", no_stream32=False)
     resp = bench.Responder(args, dev)
     ref_tok, ref_img = resp.respond_serial()
     ref_tok, ref_img = ref_tok.clone(), ref_img.clone()
