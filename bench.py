@@ -54,6 +54,9 @@ def parse():
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--headline-only", action="store_true",
+                   help="timed region + roofline objects only (no serial / batched / other-decoder timings, no CPU baseline): the command "
+                        "the committed rocprofv3 summaries are taken from, so that their per-kernel averages are those of the timed region")
     p.add_argument("--schedule", default="overlap", choices=["overlap", "serial"],
                    help="text_image: overlap = response k's diffusion decoder on one stream beside response k+1's LLM pass on another "
                         "(one LLM pass + one decoder pass per step either way); serial = one stream")
@@ -296,7 +299,11 @@ class AnyToManyResponder:
 
 def measure_roofline(resp, device):
     """Dominant kernel: gemv_kernel<1,1,GATEUP> (fused gate/up projection + SwiGLU of one decoded token), the
-    largest weight stream of the decode step. Algorithmic bytes per launch = 2*I*H*2 (weights) + H*2 + I*2."""
+    largest weight stream of the decode step. Algorithmic bytes per launch = 2*I*H*2 (weights) + H*2 + I*2.
+    Timed live with HIP events on the stream the kernel is launched on, in the condition of the timed region: under the two-stream
+    schedule the LLM pass shares the chip with the decoder pass of the previous response, so the launches are timed while UNet
+    evaluations replay on the other stream (`achieved`, `frac`); the same loop alone on the chip is reported beside it
+    (`standalone`). With --schedule serial the two coincide."""
     from spider_amd import ops
     llm = resp.llm
     c = llm.cfg
@@ -307,23 +314,43 @@ def measure_roofline(resp, device):
     for lw in layers[:4]:
         ops.gemv_swiglu(lw["w_gu"], x, norm_w=lw["ln2"], eps=c.eps, out=out)
     torch.cuda.synchronize(device)
-    stream = torch.cuda.current_stream(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
-    e0.record(stream)
-    for _ in range(reps):
-        for lw in layers:   # cycle through all layers' weights: 28 x 272 MB >> 256 MiB Infinity Cache
-            ops.gemv_swiglu(lw["w_gu"], x, norm_w=lw["ln2"], eps=c.eps, out=out)
-    e1.record(stream)
-    e1.synchronize()
     n = reps * len(layers)
-    us = e0.elapsed_time(e1) * 1e3 / n
+
+    def timed_loop(stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            e0.record(stream)
+            for _ in range(reps):
+                for lw in layers:   # cycle through all layers' weights: 28 x 272 MB >> 256 MiB Infinity Cache
+                    ops.gemv_swiglu(lw["w_gu"], x, norm_w=lw["ln2"], eps=c.eps, out=out)
+            e1.record(stream)
+        return e0, e1
+
+    cur = torch.cuda.current_stream(device)
+    e0, e1 = timed_loop(cur)
+    e1.synchronize()
+    us_alone = e0.elapsed_time(e1) * 1e3 / n
+    us = us_alone
+    corun = resp.args.schedule == "overlap" and resp._streams is not None
+    if corun:
+        sL, sU = resp._streams
+        x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2, dtype=DIFF_DT)
+        sU.wait_stream(cur); sL.wait_stream(cur)
+        with torch.cuda.stream(sU), ops.workspace_scope("diffusion"):
+            for i in range(6):                       # >= 30 ms of UNet evaluations: covers the ~6 ms GEMV loop below
+                resp.unet.step(x2, i)
+        e0, e1 = timed_loop(sL)
+        e1.synchronize()
+        sU.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
     bytes_alg = 2 * c.inter * c.hidden * 2 + c.hidden * 2 + c.hidden * 2 + c.inter * 2
     achieved = bytes_alg / (us * 1e-6) / 1e9
+    alone = bytes_alg / (us_alone * 1e-6) / 1e9
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode_hbm.json")
         if os.path.exists(pm) and bytes_alg == 271633408:
             try:
@@ -335,7 +362,10 @@ def measure_roofline(resp, device):
     return {"bound": "hbm", "kernel": "gemv_kernel<NB=1,R=1,GATEUP=1,XLDS=1> (decode gate/up + SwiGLU)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
-            "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n}
+            "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n,
+            "condition": ("co-run: timed on the LLM stream while UNet evaluations replay on the decoder stream, as in the timed region of "
+                          "the two-stream schedule" if corun else "alone on the chip (serial schedule)"),
+            "standalone": {"achieved": round(alone, 1), "frac": round(alone / HBM_PEAK_GBS, 4), "avg_launch_us": round(us_alone, 2)}}
 
 
 def _unet_pmc_traffic(kernel_prefix):
@@ -751,14 +781,14 @@ def main():
                     "rank0_stage_ms_last_step": resp.stage, "roofline": None, "cpu_baseline": None}
             print(json.dumps(line), flush=True)
         else:
-            extra = text_image_extras(args, resp, device)
             roof = measure_roofline(resp, device)
-            if not args.no_extras and world == 1:
+            extra = text_image_extras(args, resp, device)
+            if not args.no_extras and not args.headline_only and world == 1:
                 del resp
                 torch.cuda.empty_cache()
                 extra.update(other_decoders(device))
                 extra["llama3_8b"] = llama8b_numbers(device)
-            cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # reported at N=1 only
+            cpu = None if (args.no_cpu_baseline or args.headline_only or world > 1) else cpu_baseline(args)   # reported at N=1 only
             extra["roofline_response"] = response_roofline(args, extra, base["ms_per_step"])
             line = {"metric": "multimodal responses/sec (text->text+image)", **base,
                     "config": {"workload": f"SpiderFree text->text+1x512^2 image: {args.llm} text-decoder shapes, prompt {a.prompt_len} + "
@@ -847,6 +877,9 @@ def text_image_extras(args, resp, device):
         frac = (wbytes + B * kvb) * (tok_s / B) / 1e9 / HBM_PEAK_GBS
         return t_prefill, tok_s, frac
 
+    if a.headline_only:
+        extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / MFMA_PEAK_TF, 4)
+        return extra
     # one response start to finish on ONE stream (the latency of a single request; `value` counts a step of the overlapped
     # schedule when --schedule overlap)
     resp.respond_serial()

@@ -1,6 +1,8 @@
 """UNet attention shapes (SD-v1.5, CFG batch 2): self- and cross-attention at the three resolutions, graph-timed.
 With an argument ("cross64" | "self64" | ...) it just loops that case (for rocprofv3 --pmc)."""
 import sys, torch
+import os as _os
+DT = torch.bfloat16 if _os.environ.get("UNET_DTYPE", "f16") == "bf16" else torch.float16   # the diffusion engines\' format (f16 by default)
 from spider_amd import ops
 dev = torch.device("cuda:0")
 CASES = {"self64": (4096, 4096, 8, 40), "cross64": (4096, 77, 8, 40), "self32": (1024, 1024, 8, 80), "cross32": (1024, 77, 8, 80),
@@ -10,8 +12,8 @@ CASES = {"self64": (4096, 4096, 8, 40), "cross64": (4096, 77, 8, 40), "self32": 
 def mk(case):
     Lq, Lk, H, d = CASES[case]
     C = H * d
-    q = torch.randn(2, Lq, C, device=dev).bfloat16()
-    kv = torch.randn(2, Lk, 2 * C, device=dev).bfloat16()
+    q = torch.randn(2, Lq, C, device=dev).to(DT)
+    kv = torch.randn(2, Lk, 2 * C, device=dev).to(DT)
     return (lambda: ops.attention(q, kv[..., :C], kv[..., C:], H)), 4.0 * 2 * Lq * Lk * C
 
 

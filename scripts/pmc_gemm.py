@@ -1,22 +1,24 @@
 """PMC aid: repeated launches of one GEMM / conv shape (run under rocprofv3 --pmc ...)."""
 import sys, torch
+import os as _os
+DT = torch.bfloat16 if _os.environ.get("UNET_DTYPE", "f16") == "bf16" else torch.float16   # the diffusion engines\' format (f16 by default)
 from spider_amd import ops
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "gate_up"
 if which == "gate_up":
-    A = torch.randn(1536, 3584, device=dev).bfloat16(); W = (torch.randn(37888, 3584, device=dev) * 0.02).bfloat16()
+    A = torch.randn(1536, 3584, device=dev).to(DT); W = (torch.randn(37888, 3584, device=dev) * 0.02).to(DT)
     f = lambda: ops.gemm(A, W)
 elif which == "conv64":
-    x = torch.randn(2, 64, 64, 640, device=dev).bfloat16(); w = (torch.randn(320, 3, 3, 640, device=dev) * 0.02).bfloat16()
+    x = torch.randn(2, 64, 64, 640, device=dev).to(DT); w = (torch.randn(320, 3, 3, 640, device=dev) * 0.02).to(DT)
     f = lambda: ops.conv2d(x, w)
 elif which == "conv64_320":   # the roofline_unet_conv shape of bench.py
-    x = torch.randn(2, 64, 64, 320, device=dev).bfloat16(); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).bfloat16()
+    x = torch.randn(2, 64, 64, 320, device=dev).to(DT); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.conv2d(x, w)
 elif which == "ff1":
-    A = torch.randn(8192, 320, device=dev).bfloat16(); W = (torch.randn(2560, 320, device=dev) * 0.02).bfloat16()
+    A = torch.randn(8192, 320, device=dev).to(DT); W = (torch.randn(2560, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.gemm(A, W)
 else:
-    A = torch.randn(8192, 320, device=dev).bfloat16(); W = (torch.randn(960, 320, device=dev) * 0.02).bfloat16()
+    A = torch.randn(8192, 320, device=dev).to(DT); W = (torch.randn(960, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.gemm(A, W)
 for _ in range(6):
     f()

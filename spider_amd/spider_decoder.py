@@ -33,6 +33,9 @@ class SpiderDecoder:
                  device="cuda:0", pipelines: Optional[Dict[str, object]] = None, diffusion_dtype=torch.float16):
         diffusion_modules = diffusion_modules or {}
         self.diffusion_dtype = diffusion_dtype   # the reference hard-codes torch.float16 (spider_decoder.py:109,114,130,136,153,159)
+        # generate_batch: captions per video pipeline call (4 x CFG 2 x 16 frames of 40 x 72 = 368,640 token rows per UNet3D
+        # evaluation; the kernels' 32-bit operand offsets allow < 2 GiB per activation tensor, i.e. up to 5 captions at 16 frames)
+        self.video_batch = 4
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -145,14 +148,18 @@ class SpiderDecoder:
     def decode_video_batch(self, captions, guidance_scale=7.5, num_inference_steps=40, height=320, width=576, num_frames=16):
         """tensor2vid (custom_vd.py:59-74) tiles the batch horizontally inside every frame: cut each frame back into the per-caption
         videos, so entry j is what the one-caption call returns (a list of `num_frames` [H, W, 3] uint8 frames)."""
-        out = self._decode_batch("VIDEO", self.vd_ckpt_path, captions, "video", guidance_scale=guidance_scale,
-                                 num_inference_steps=num_inference_steps, height=height, width=width, num_frames=num_frames)
-        if out is None:
-            return None
-        n = len(captions)
-        frames = out.frames
-        w = frames[0].shape[1] // n
-        return [[f[:, j * w:(j + 1) * w] for f in frames] for j in range(n)]
+        res = []
+        chunk = self.video_batch       # captions per pipeline call: 2 x chunk x num_frames images per UNet3D evaluation
+        for c0 in range(0, len(captions), chunk):
+            part = captions[c0:c0 + chunk]
+            out = self._decode_batch("VIDEO", self.vd_ckpt_path, part, "video", guidance_scale=guidance_scale,
+                                     num_inference_steps=num_inference_steps, height=height, width=width, num_frames=num_frames)
+            if out is None:
+                return None
+            frames = out.frames
+            w = frames[0].shape[1] // len(part)
+            res += [[f[:, j * w:(j + 1) * w] for f in frames] for j in range(len(part))]
+        return res
 
     @torch.no_grad()
     def generate_batch(self, samples_list, outputs=None):
