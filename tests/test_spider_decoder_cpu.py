@@ -103,7 +103,10 @@ def test_generate_batch_equals_per_sample_generate(golden_dir):
             assert len(v) == 4 and v[0].shape == (2, 3, 3)             # one caption's own frames, not the tiled batch
     n_img = sum(len(c["predictions_text"]["IMAGE"]) for c in cases)
     assert len(batch_pipes["IMAGE"].calls) == 1 and len(batch_pipes["IMAGE"].calls[0][0]) == n_img
-    assert len(batch_pipes["VIDEO"].calls) == 1 and len(batch_pipes["AUDIO"].calls) == 1
-    # the j-th caption of the VIDEO call gets the j-th width slice of every frame
+    assert len(batch_pipes["AUDIO"].calls) == 1
+    # videos go through the pipeline in chunks of `video_batch` captions (bounded activation tensors); the j-th caption of a call
+    # gets the j-th width slice of every frame
     vids = [v for _, p, _ in got for v in p["VIDEO"]]
-    assert [int(v[0][0, 0, 0]) for v in vids] == [10 * j for j in range(len(vids))]
+    assert len(batch_pipes["VIDEO"].calls) == (len(vids) + d2.video_batch - 1) // d2.video_batch
+    assert [len(c[0]) for c in batch_pipes["VIDEO"].calls] == [min(d2.video_batch, len(vids) - i) for i in range(0, len(vids), d2.video_batch)]
+    assert [int(v[0][0, 0, 0]) for v in vids] == [10 * (j % d2.video_batch) for j in range(len(vids))]
