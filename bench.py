@@ -300,10 +300,11 @@ class AnyToManyResponder:
 def measure_roofline(resp, device):
     """Dominant kernel: gemv_kernel<1,1,GATEUP> (fused gate/up projection + SwiGLU of one decoded token), the
     largest weight stream of the decode step. Algorithmic bytes per launch = 2*I*H*2 (weights) + H*2 + I*2.
-    Timed live with HIP events on the stream the kernel is launched on, in the condition of the timed region: under the two-stream
-    schedule the LLM pass shares the chip with the decoder pass of the previous response, so the launches are timed while UNet
-    evaluations replay on the other stream (`achieved`, `frac`); the same loop alone on the chip is reported beside it
-    (`standalone`). With --schedule serial the two coincide."""
+    Timed live with HIP events around back-to-back launches on the stream they are launched on (`achieved`, `frac`: the kernel's
+    own duration -- rocprofv3 reports the same average for it in BOTH schedules, profiles/r03_bench_kernel_stats_top.txt and
+    r03_bench_serial_kernel_stats_top.txt: 41.5 us). Under the two-stream schedule the same loop is timed a second time while UNet
+    evaluations replay on the decoder stream (`co_run`): the kernels do not run longer there, but each dependent launch starts
+    later (the interval per launch grows from 41.6 to ~50 us), which is where the LLM pass loses time when it shares the chip."""
     from spider_amd import ops
     llm = resp.llm
     c = llm.cfg
@@ -345,8 +346,8 @@ def measure_roofline(resp, device):
         sU.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
     bytes_alg = 2 * c.inter * c.hidden * 2 + c.hidden * 2 + c.hidden * 2 + c.inter * 2
+    us_corun, us = us, us_alone
     achieved = bytes_alg / (us * 1e-6) / 1e9
-    alone = bytes_alg / (us_alone * 1e-6) / 1e9
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
@@ -363,9 +364,9 @@ def measure_roofline(resp, device):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
             "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n,
-            "condition": ("co-run: timed on the LLM stream while UNet evaluations replay on the decoder stream, as in the timed region of "
-                          "the two-stream schedule" if corun else "alone on the chip (serial schedule)"),
-            "standalone": {"achieved": round(alone, 1), "frac": round(alone / HBM_PEAK_GBS, 4), "avg_launch_us": round(us_alone, 2)}}
+            "co_run": ({"launch_interval_us": round(us_corun, 2), "effective_GBps": round(bytes_alg / (us_corun * 1e-6) / 1e9, 1),
+                        "note": "same loop while UNet evaluations replay on the decoder stream (two-stream schedule): per-launch interval incl. "
+                                "the later start of each dependent launch; the kernel's own duration is unchanged (rocprofv3)"} if corun else None)}
 
 
 def _unet_pmc_traffic(kernel_prefix):
