@@ -19,9 +19,11 @@ class _Eng:
         self.w = w
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("key_lists", [True, False])
-def test_consistent_attention_matches_reference_sequence(dev, golden_dir, key_lists):
+def test_consistent_attention_matches_reference_sequence(dev, golden_dir, key_lists, dtype):
     from spider_amd.story import ConsistentSelfAttention, StoryState
+    BF = torch.bfloat16 if dtype == "bf16" else torch.float16
     z = np.load(os.path.join(golden_dir, "story_ref.npz"))
     C, heads, hh, ww = [int(v) for v in z["seq_cfg"]]
     coins = iter([float(c) for row in z["seq_coins"] for c in row if c >= 0])
@@ -47,7 +49,8 @@ def test_consistent_attention_matches_reference_sequence(dev, golden_dir, key_li
             got = F.linear(o, outw[tag][0].to(BF).float(), outw[tag][1])
             ref = torch.from_numpy(z[yk][step])
             rel = float((got - ref).norm() / ref.norm())
-            assert rel < 2e-2, (step, tag, rel)      # bf16 inputs/weights/P vs the reference's fp32 run
+            # 16-bit inputs / weights / P vs the reference's fp32 run (f16 measured 8x below bf16)
+            assert rel < {"bf16": 2e-2, "f16": 3e-3}[dtype], (step, tag, rel)
     assert st.cur_step == 7
 
 
@@ -75,8 +78,11 @@ class _OracleHook:
         return self.procs.setdefault(name, self.os.ProcessorOracle())(self.st, aw, y)
 
 
-def test_story_unet_write_then_read_matches_oracle(dev):
+@pytest.mark.parametrize("dtype,stream32", [("bf16", False), ("f16", True)])
+def test_story_unet_write_then_read_matches_oracle(dev, dtype, stream32):
+    """bf16 with the 16-bit stream (round 2's mode) and f16 with the fp32 residual stream (what init_story_generation loads)."""
     from oracle import story as ostory
+    BF = torch.bfloat16 if dtype == "bf16" else torch.float16
     from oracle.unet import UNetOracle
     from spider_amd.story import ConsistentSelfAttention, StoryState
     from spider_amd.unet import UNetEngine
@@ -97,7 +103,7 @@ def test_story_unet_write_then_read_matches_oracle(dev):
             st.regen_masks()
             unet.attn_hook = _OracleHook(st, unet.w)
         else:
-            unet = UNetEngine(cfg, w, dev)
+            unet = UNetEngine(cfg, w, dev, dtype=BF, stream32=stream32)
             st = StoryState(total_count=ConsistentSelfAttention.count_processors(unet), height=hh, width=ww, **hooks)
             st.regen_masks(dev)
             unet.self_attn_hook = ConsistentSelfAttention(st)
@@ -124,8 +130,9 @@ def test_story_unet_write_then_read_matches_oracle(dev):
     assert st_o.cur_step == st_g.cur_step == 6
     for i, (a, b) in enumerate(zip(got, ref)):
         rel = float((a - b).norm() / b.norm())
-        print(f"MEASURED story_unet i={i} rel={rel:.5f}")
-        assert rel < 2.6e-2, (i, rel)      # measured 1.58 - 2.14e-2 over the 13 write / read steps (+20 %)
+        print(f"MEASURED story_unet dtype={dtype} stream32={stream32} i={i} rel={rel:.5f}")
+        # bf16: measured 1.58 - 2.14e-2 over the 13 write / read steps (+20 %); f16 + fp32 stream: 8x below
+        assert rel < {"bf16": 2.6e-2, "f16": 2.7e-3}[dtype], (i, rel)      # f16 measured 1.60 - 2.21e-3
 
 
 def _tiny_story_pipe(dev):
