@@ -282,6 +282,7 @@ class AnyToManyResponder:
             samples.append({"llm_text_all": [f"Sure. <IMAGE>scene {head}</IMAGE> <AUDIO>sound {head}</AUDIO> <VIDEO>clip {head}</VIDEO>"]})
         # Decoders-Controller, batched entry point: the rank's B responses are routed together and every diffusion decoder runs
         # ONCE at CFG batch 2 x B (SpiderDecoder.generate_batch; per-sample containers as in the reference's generate)
+        self.decoder.stage_ms = {}
         if a.serial_decoders:
             outs = [self.decoder.generate(s, *routing.new_outputs()) for s in samples]
         else:
@@ -292,7 +293,8 @@ class AnyToManyResponder:
             auds.append(torch.from_numpy(np.asarray(preds["AUDIO"][0], dtype=np.float32).reshape(-1)))           # [80000]
             vids.append(torch.from_numpy(np.stack([np.asarray(f, dtype=np.uint8) for f in preds["VIDEO"][0]])))  # [16, 320, 576, 3]
         torch.cuda.synchronize(dev)
-        self.stage = dict(llm_ms=round((t1 - t0) * 1e3, 1), decoders_ms=round((time.perf_counter() - t1) * 1e3, 1))
+        self.stage = dict(llm_ms=round((t1 - t0) * 1e3, 1), decoders_ms=round((time.perf_counter() - t1) * 1e3, 1),
+                          **{f"{m.lower()}_decoder_ms": round(v, 1) for m, v in self.decoder.stage_ms.items()})
         return {"tokens": toks.to(torch.int32), "image": torch.stack(imgs).to(dev), "audio": torch.stack(auds).to(dev),
                 "video": torch.stack(vids).to(dev)}
 

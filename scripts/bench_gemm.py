@@ -27,14 +27,41 @@ if os.environ.get("SHAPES") == "sdxl":   # SDXL story step at 768^2, CFG batch 8
         ("c24 2560>1280", 4608, 1280, 23040, 2560, 24),
     ]
 
+if os.environ.get("SHAPES") == "v3d":   # zeroscope UNet3D step, 2 x 16 frames at 40 x 72 (rows = sample, frame, pixel)
+    SHAPES = [
+        ("v0 out", 92160, 320, 320, 0, 0), ("v0 qkv", 92160, 960, 320, 0, 0), ("v0 ff1", 92160, 2560, 320, 0, 0), ("v0 ff2", 92160, 320, 1280, 0, 0),
+        ("v1 out", 23040, 640, 640, 0, 0), ("v1 qkv", 23040, 1920, 640, 0, 0), ("v1 ff2", 23040, 640, 2560, 0, 0),
+        ("v2 out", 5760, 1280, 1280, 0, 0), ("v2 qkv", 5760, 3840, 1280, 0, 0), ("v2 ff2", 5760, 1280, 5120, 0, 0),
+        ("vc0 320>320", 92160, 320, 2880, 320, (40, 72)), ("vc1 640>640", 23040, 640, 5760, 640, (20, 36)), ("vc2 1280>1280", 5760, 1280, 11520, 1280, (10, 18)),
+        ("vt0 320 (3,1,1)", 92160, 320, 960, 320, (16, 2880), "t"), ("vt1 640 (3,1,1)", 23040, 640, 1920, 640, (16, 720), "t"),
+        ("vt2 1280 (3,1,1)", 5760, 1280, 3840, 1280, (16, 180), "t"),
+        # LayerNorm-folded projections (plain / GEGLU) of the transformer blocks
+        ("v0 qkv ln", 92160, 960, 320, 0, 0, "ln"), ("v0 ff1 geglu ln", 92160, 2560, 320, 0, 0, "geglu"),
+        ("v1 qkv ln", 23040, 1920, 640, 0, 0, "ln"), ("v1 ff1 geglu ln", 23040, 5120, 640, 0, 0, "geglu"),
+        ("x48 qkv ln", 18432, 1920, 640, 0, 0, "ln"), ("x48 ff1 geglu ln", 18432, 5120, 640, 0, 0, "geglu"),
+        ("v0x4 qkv ln", 368640, 960, 320, 0, 0, "ln"), ("v0x4 ff1 geglu ln", 368640, 2560, 320, 0, 0, "geglu"),
+    ]
+
+
 
 def child():
     from spider_amd import ops
     dev = torch.device("cuda:0")
     out = {}
-    for tag, M, N, K, cin, hw in SHAPES:
-        if cin:
-            x = torch.randn(M // (hw * hw), hw, hw, cin, device=dev).bfloat16()
+    for tag, M, N, K, cin, hw, *kind in SHAPES:
+        if kind and kind[0] in ("ln", "geglu"):
+            A = torch.randn(M, K, device=dev).bfloat16()
+            W = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+            Wf, cs, cb = ops.fold_layernorm(W, torch.ones(K, device=dev).bfloat16(), torch.zeros(K, device=dev).bfloat16(), torch.zeros(N, device=dev).bfloat16())
+            act = "geglu" if kind[0] == "geglu" else None
+            f = lambda: ops.gemm_ln(A, Wf, cs, cb, act=act, eps=1e-5)
+        elif cin and kind:       # temporal conv (3,1,1) over [sample, frame, pixel, C]
+            x = torch.randn(M // (hw[0] * hw[1]), hw[0], hw[1], cin, device=dev).bfloat16()
+            w = (torch.randn(N, 3, 1, cin, device=dev) * 0.02).bfloat16()
+            f = lambda: ops.conv_ex(x, w, pad=(1, 0))
+        elif cin:
+            h_, w_ = hw if isinstance(hw, tuple) else (hw, hw)
+            x = torch.randn(M // (h_ * w_), h_, w_, cin, device=dev).bfloat16()
             w = (torch.randn(N, 3, 3, cin, device=dev) * 0.02).bfloat16()
             f = lambda: ops.conv2d(x, w)
         else:

@@ -1570,6 +1570,38 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
             else use_p8h = nk < 128;                 // the 256^2 kernel would split K: worth it only for a long K
         }
     }
+    // Very tall problems (UNet3D 16-frame maps: 92160 / 23040 rows and multiples; SDXL 96^2 / 48^2 maps): every kernel runs whole
+    // rounds of one block per CU (two for the 128^2 register-staged tiles), so the choice is made by a cost model instead of the
+    // size classes above:  time = ceil(tiles / resident blocks) x (t0 + nk x tk),  t0 = prologue + epilogue of a block, tk = one
+    // 64-deep K tile. Constants fitted on MI355X (scripts/bench_gemm.py, SHAPES=v3d / sdxl, 16 shapes x 4 kernels, within ~10 %):
+    // 256^2 8.4 + 1.40 nk (1.67 for convs), 256x128 7.0 + 0.78 nk, 128x160 LDS-DMA 5.5 + 0.68 nk, 128^2 5.7 + 1.0 nk at two blocks
+    // per CU; the GEGLU epilogue adds ~2.2 us per block, the LayerNorm-folded form on the 256^2 kernel its row-statistics pass.
+    // What the classes got wrong there: 270 tiles of 256^2 = two rounds at 53 % (23040 x 640 convs: 318 vs 201 us), and the K = 320
+    // linears kept off the 256^2 kernel by its nk >= 8 rule (92160 x 960 x 320: 123 vs 93 us; GEGLU ff1 390 vs ~270).
+    static const int model_env = getenv("SPIDER_GEMM_MODEL") ? atoi(getenv("SPIDER_GEMM_MODEL")) : 2;
+    const bool fused = a.geglu || a.ln_colsum;
+    if (model_env && (model_env >= 2 || !fused) && !force_tile && !force_splits && a.M >= 16384 && nk >= 4 && ncols >= 128) {
+        const bool p8_ok = p8_env && !(a.geglu && a.conv) &&
+                           (!a.ln_colsum || (a.ws && ln_rows_bytes <= (size_t)ws_bytes && a.act == 0));
+        const float epi = a.geglu ? 2.2f : 0.f;
+        const float ln_pass = a.ln_colsum ? 3.f + (float)((double)a.M * a.K * 2.0 / 5.0e6) : 0.f;   // ln_row_stats_kernel: one read of A
+        struct Cand { int bm, bn, slots; float t0, tk, pre; bool ok; };
+        const Cand cand[4] = {{256, 256, 256, 8.4f + epi, a.conv ? 1.67f : 1.40f, ln_pass, p8_ok},
+                              {256, 128, 256, 7.0f, 0.78f, 0.f, p8_env && p8h_env && !a.conv && !fused},
+                              {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
+                              {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true}};
+        int best = -1;
+        float best_t = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            if (!cand[i].ok) continue;
+            const long tiles_i = (long)((a.M + cand[i].bm - 1) / cand[i].bm) * ((ncols + cand[i].bn - 1) / cand[i].bn);
+            const float t = cand[i].pre + (float)((tiles_i + cand[i].slots - 1) / cand[i].slots) * (cand[i].t0 + (float)nk * cand[i].tk);
+            if (best < 0 || t < best_t) { best = i; best_t = t; }
+        }
+        use_p8 = best == 0; use_p8h = best == 1;
+        dma_bn = best == 2 ? 160 : 0; dma_bm = 128;
+        small = false; splits = 1; p8_splits = 1;
+    }
     if (use_p8h) { use_p8 = false; splits = 1; dma_bn = 0; }
     if (use_p8) { splits = p8_splits; dma_bn = 0; }
     if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)

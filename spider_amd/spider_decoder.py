@@ -36,6 +36,7 @@ class SpiderDecoder:
         # generate_batch: captions per video pipeline call (4 x CFG 2 x 16 frames of 40 x 72 = 368,640 token rows per UNet3D
         # evaluation; the kernels' 32-bit operand offsets allow < 2 GiB per activation tensor, i.e. up to 5 captions at 16 frames)
         self.video_batch = 4
+        self.stage_ms: Dict[str, float] = {}     # host wall time per modality of the batched decoders (reset by the caller)
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -130,10 +131,16 @@ class SpiderDecoder:
         if pipe is None:
             print(f"no input text prompt for {what} generation. or no {what} generation model.")
             return None
+        import time
+        t0 = time.perf_counter()
         if self.get_prompt_embed_for_diffusion:
             embeds = pipe(list(captions), return_prompts_only=True).detach()
-            return pipe(prompt_embeds=embeds, **call_kwargs)
-        return pipe(prompt=list(captions), **call_kwargs)
+            out = pipe(prompt_embeds=embeds, **call_kwargs)
+        else:
+            out = pipe(prompt=list(captions), **call_kwargs)
+        # host wall time of the pipeline call (every pipeline ends with a device -> host copy of its output): read by bench.py
+        self.stage_ms[modality] = self.stage_ms.get(modality, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
 
     def decode_image_batch(self, captions, guidance_scale=7.5, num_inference_steps=40):
         out = self._decode_batch("IMAGE", self.sd_ckpt_path, captions, "image", guidance_scale=guidance_scale,

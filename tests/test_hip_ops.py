@@ -144,7 +144,12 @@ def test_attn_decode(ops, dev, B, n_q, n_kv, T, nsplit, beg):
                                    (2100, 312, 2568),      # same path with ragged M / N / K tails (N, K multiples of 8 / 4 only)
                                    (4608, 3840, 1280),     # 256^2 LDS-DMA kernel (>= 160 tiles): SDXL 24^2 qkv
                                    (1536, 3584, 3584),     # 256^2 kernel with 3 K splits (84 tiles): LLM prefill o-proj
-                                   (4000, 2500, 1096)])    # 256^2 kernel, ragged M / N / K tails
+                                   (4000, 2500, 1096),     # 256^2 kernel, ragged M / N / K tails
+                                   # >= 16384 rows (UNet3D / SDXL maps): tile picked by the rounds x (t0 + nk tk) cost model
+                                   (16384, 320, 320),      # K = 320 (5 K tiles): 128 x 160 LDS-DMA tiles
+                                   (16500, 960, 320),      # 5 K tiles on the 256^2 kernel, ragged M
+                                   (23040, 640, 640),      # 256^2, one round
+                                   (16384, 320, 1280)])    # N = 320 on 256-wide tiles (62 % of the tile used)
 def test_gemm(ops, dev, M, N, K):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     ref = A.float() @ W.float().T
@@ -169,7 +174,9 @@ def test_gemm(ops, dev, M, N, K):
                                                           (2, 64, 64, 320, 320, 3, 2, False),     # stride 2 on the DMA path (M = 2048)
                                                           (8, 48, 48, 64, 640, 3, 1, False),      # 256^2 LDS-DMA kernel (216 tiles), halo taps
                                                           (8, 47, 49, 128, 632, 3, 1, False),     # the same, ragged rows / columns
-                                                          (8, 24, 24, 64, 1280, 3, 1, True)])     # the same through the fused 2x upsample
+                                                          (8, 24, 24, 64, 1280, 3, 1, True),      # the same through the fused 2x upsample
+                                                          (8, 40, 72, 64, 640, 3, 1, False),      # 23040 rows: cost-model dispatch (UNet3D 20x36 x 32 frames)
+                                                          (32, 40, 72, 64, 320, 3, 1, False)])    # 92160 rows (UNet3D 40x72 x 32 frames)
 def test_conv2d(ops, dev, B, H, W, Cin, Cout, ks, stride, ups):
     x, w, bias = rnd(B, H, W, Cin, seed=1), rnd(Cout, ks, ks, Cin, seed=2, scale=0.05), rnd(Cout, seed=3)
     xin = x.float().permute(0, 3, 1, 2)
@@ -428,7 +435,8 @@ def test_gemm_256_tile_repeatable_under_load(ops, dev):
 
 @pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280),
                                        (4608, 5120, 1280),    # 256^2 LDS-DMA kernel with the GEGLU epilogue (SDXL 24^2 ff1)
-                                       (4000, 2504, 1096)])   # the same, ragged M / N / K
+                                       (4000, 2504, 1096),    # the same, ragged M / N / K
+                                       (16400, 1280, 320)])   # >= 16384 rows: cost-model dispatch, 5 K tiles on the 256^2 kernel (UNet3D ff1)
 def test_gemm_fused_geglu(ops, dev, M, inner, K):
     A, W, b = rnd(M, K, seed=1), rnd(2 * inner, K, seed=2, scale=0.05), rnd(2 * inner, seed=3, scale=0.2)
     p = A.float() @ W.float().T + b.float()
@@ -462,6 +470,7 @@ def test_skinny_mfma_gemm(ops, dev, B, N, K):
     (2, 6, 35, 64, 64, 3, 1, 1, (1, 0), 1, None),        # (3,1) temporal kernel over "frames"
     (2, 8, 5, 128, 64, 3, 3, 1, (1, 1), 1, (15, 9)),     # upsample to 2n-1 (odd skip size), then 3x3
     (1, 7, 9, 64, 64, 3, 3, 2, (1, 1), 1, None),         # stride 2 on odd sizes
+    (2, 16, 720, 128, 640, 3, 1, 1, (1, 0), 1, None),    # UNet3D temporal conv at the 20 x 36 level: 23040 rows (cost-model dispatch)
 ])
 def test_conv_ex(ops, dev, B, H, W, Cin, Cout, kh, kw, stride, pad, dil, up):
     x, w, b = rnd(B, H, W, Cin, seed=1), rnd(Cout, kh, kw, Cin, seed=2, scale=(kh * kw * Cin) ** -0.5), rnd(Cout, seed=3)
@@ -535,7 +544,9 @@ def test_attention_late_max_jump(ops, dev, spike_tile):
 @pytest.mark.parametrize("M,N,K,mean", [(8192, 960, 320, 0.0), (2048, 640, 640, 3.0), (520, 1280, 1280, -8.0), (77, 72, 64, 0.5),
                                         (300, 3840, 1280, 0.0), (8192, 320, 320, 1.0),
                                         (4608, 10240, 1280, 2.0),     # 256^2 LDS-DMA kernel, row statistics from their own pass
-                                        (4100, 3848, 1096, -1.0)])    # the same, ragged M / N / K
+                                        (4100, 3848, 1096, -1.0),     # the same, ragged M / N / K
+                                        (16400, 960, 320, 1.5),       # >= 16384 rows: cost-model dispatch (UNet3D qkv, 5 K tiles)
+                                        (16384, 2560, 320, 0.0)])     # GEGLU ff1 with the LayerNorm folded in
 def test_gemm_layernorm_folded(ops, dev, M, N, K, mean):
     """LayerNorm folded into the consuming GEMM (spider_gemm_ln_bf16) against torch fp32 LayerNorm -> linear, plain / + residual /
     GEGLU; rows with a large common offset (|mean| >> std) exercise the mean-cancellation term."""
