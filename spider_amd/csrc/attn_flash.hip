@@ -693,6 +693,84 @@ __global__ __launch_bounds__(1024) void key_lists_kernel(const unsigned long lon
 
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------
+// Short sequences (Lq, Lk <= 16; head_dim 64): the UNet3D's temporal attention -- every pixel of a sample is its own sequence
+// of F = 16 frames (TransformerTemporalModel, custom_vd.py:25), 2880 x 5 sequence-heads per sample at 40 x 72. In the 128-row
+// flash tiling above such a problem is one block of 256 threads per sequence-head with 16 of its rows in use; here ONE WAVE
+// owns a sequence-head, with no block-level synchronisation:
+//   S^T = K . Q^T  by two mfma_16x16x32 (A = K rows, B = Q rows: both fragments are 16-byte global loads, row lane & 15, head
+//         dims 32 kb + 8 (lane >> 4) ..+7), so the lane holds S^T[key 4g + i][query lane & 15];
+//   softmax over the keys = over the 4 registers and the lane groups g (two cross-lane steps);
+//   O^T = V^T . P^T by four mfma_16x16x16 (one per 16 head dims): the B fragment IS the lane's 4 probabilities (keys 4g..4g+3 of
+//         its query), the A fragment V[4g + j][16 t + (lane & 15)] comes from the wave's own 16 x 64 V tile in LDS through
+//         ds_read_b64_tr_b16 (lane 4q + p of a group addresses row 4g + q, columns 16 t + 4p ..+3).
+// The kernel is HBM-bound by construction (8 KiB in / 2 KiB out per sequence-head for ~6 MFMAs).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
+    constexpr int VS = 72;                                   // V tile row stride (elements): 144 B, 8-byte aligned rows
+    __shared__ __attribute__((aligned(16))) h16_t vs_all[4][16 * VS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long total = (long)a.B * a.Hq;
+    long wid = (long)blockIdx.x * 4 + wave;
+    const bool live = wid < total;
+    if (!live) wid = total - 1;                              // keep EXEC full for the transposed reads: recompute, never store
+    const int b = (int)(wid / a.Hq), h = (int)(wid % a.Hq);
+    const int r = lane & 15, g = lane >> 4;
+    const h16_t* qp = a.q + (long)b * a.q_bs + (long)h * a.q_hs + (long)min(r, a.Lq - 1) * a.q_rs + 8 * g;
+    const h16_t* kp = a.k + (long)b * a.k_bs + (long)h * a.k_hs + (long)min(r, a.Lk - 1) * a.k_rs + 8 * g;
+    const h16_t* vp = a.v + (long)b * a.v_bs + (long)h * a.v_hs + (long)min(r, a.Lk - 1) * a.v_rs + 8 * g;
+    const h16x8 q0 = *reinterpret_cast<const h16x8*>(qp), q1 = *reinterpret_cast<const h16x8*>(qp + 32);
+    const h16x8 k0 = *reinterpret_cast<const h16x8*>(kp), k1 = *reinterpret_cast<const h16x8*>(kp + 32);
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(vp), v1 = *reinterpret_cast<const u32x4*>(vp + 32);
+    h16_t* vs = vs_all[wave];
+    *reinterpret_cast<u32x4*>(vs + r * VS + 8 * g) = v0;
+    *reinterpret_cast<u32x4*>(vs + r * VS + 32 + 8 * g) = v1;
+
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    s = mfma_16x16x32_h16(k0, q0, s);
+    s = mfma_16x16x32_h16(k1, q1, s);
+    // lane: S^T[key 4g + i][query r]; softmax over the keys in the exp2 domain
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[i] = (4 * g + i < a.Lk) ? s[i] * a.scale_log2e : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float pr[4], l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t pk = pack_h16x2(exp2f(s[i] - mx), 0.f);      // P is rounded to 16 bits, as the MFMA consumes it
+        pr[i] = h16lo_to_f32(pk);
+        l += pr[i];
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    u32x2 pp;
+    pp.x = pack_h16x2(pr[0], pr[1]);
+    pp.y = pack_h16x2(pr[2], pr[3]);
+    const h16x4 pf = __builtin_bit_cast(h16x4, pp);
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own V tile is in LDS (no other wave touches it)
+    const float inv = 1.f / l;
+    const int i16 = lane & 15;
+    h16_t* op = a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)r * a.o_rs + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const h16_t* va = vs + (4 * g + (i16 >> 2)) * VS + 16 * t + 4 * (i16 & 3);
+        const h16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4*)(va));
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = mfma_16x16x16_h16(vf, pf, o);                     // O^T[dim 16 t + 4g + i][query r]
+        if (live && r < a.Lq) {
+            u32x2 w;
+            w.x = pack_h16x2(o[0] * inv, o[1] * inv);
+            w.y = pack_h16x2(o[2] * inv, o[3] * inv);
+            *reinterpret_cast<u32x2*>(op + 16 * t) = w;
+        }
+    }
+}
+
 template <int DP>
 int launch(const AttnArgs& a, void* stream) {
     using C = Cfg<DP>;
@@ -711,6 +789,15 @@ int launch(const AttnArgs& a, void* stream) {
         return -1;
     }
     const bool plain = !a.causal && !a.keep_bits && !a.kv_beg && !a.tiles;
+    static const int short_env = [] { const char* e = getenv("SPIDER_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+    if constexpr (DP == 64) {
+        if (plain && short_env && a.d == 64 && a.Lq <= 16 && a.Lk <= 16 && a.Hq == a.Hkv) {     // one wave per sequence-head
+            const long total = (long)a.B * a.Hq;
+            attn_short_kernel<<<(unsigned)((total + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+            SPIDER_LAUNCH_OK();
+            return 0;
+        }
+    }
     static const int pipe_env = [] { const char* e = getenv("SPIDER_ATTN_PIPE"); return e ? atoi(e) : 1; }();
     if (plain && pipe_env && a.Lk % 64 == 0 && a.Lk >= 128 && DP <= 96) {      // software-pipelined dense form (whole 64-key tiles)
         if constexpr (DP == 64) {

@@ -72,6 +72,10 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_h16(h16x8 a, h16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x16 mfma_32x32x16_h16(h16x8 a, h16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hw_f16x8, a), __builtin_bit_cast(hw_f16x8, b), c, 0, 0, 0);
 }
+typedef _Float16 hw_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_16x16x16_h16(h16x4 a, h16x4 b, f32x4 c) {     // K = 16: 4 values per lane
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(hw_f16x4, a), __builtin_bit_cast(hw_f16x4, b), c, 0, 0, 0);
+}
 #else
 #define SPIDER_DT bf16
 #define SPIDER_DT_NAME "bf16"
@@ -89,6 +93,9 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_h16(h16x8 a, h16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x16 mfma_32x32x16_h16(h16x8 a, h16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_16x16x16_h16(h16x4 a, h16x4 b, f32x4 c) {     // K = 16: 4 values per lane
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 #endif
 #define SPIDER_FN(name) SPIDER_CAT2(name, SPIDER_DT)

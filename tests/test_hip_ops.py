@@ -219,6 +219,27 @@ def test_attention(ops, dev, B, heads, kvh, Lq, Lk, d, causal):
     close(out, _attn_ref(q, k, v, heads, kvh, causal, Lk - Lq), 1.5e-2, 1.5e-2, "attention")
 
 
+@pytest.mark.parametrize("HW,F_,heads", [(37, 16, 5), (50, 5, 2), (9, 3, 10), (2880, 16, 5), (3, 1, 1)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_attention_short_sequences(ops, dev, HW, F_, heads, dtype):
+    """The one-wave-per-sequence kernel (Lq = Lk <= 16, head_dim 64) on the UNet3D's temporal layout: q / k / v are column slices of
+    the fused projection of [frame, pixel] rows viewed as [pixel, frame] (batch stride = one row, row stride = HW rows, no copies),
+    the output goes into the same kind of strided view. Against the fp32 reference and against the 128-row flash kernel."""
+    import os
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    inner = heads * 64
+    qkv = rnd(F_ * HW, 3 * inner, seed=1).float().to(dt)
+    qv = qkv.to(dev).view(F_, HW, 3 * inner).permute(1, 0, 2)          # [HW, F, 3*inner]
+    o = torch.zeros(F_ * HW, inner, dtype=dt, device=dev)
+    ov = o.view(F_, HW, inner).permute(1, 0, 2)
+    ops.attention(qv[..., :inner], qv[..., inner:2 * inner], qv[..., 2 * inner:], heads, out=ov)
+    c = qkv.float().view(F_, HW, 3 * inner).permute(1, 0, 2)
+    ref = _attn_ref(c[..., :inner], c[..., inner:2 * inner], c[..., 2 * inner:], heads, heads)       # [HW, F, inner]
+    tol = 1.5e-2 if dtype == "bf16" else 3e-3
+    close(ov, ref, tol, tol, "short-sequence attention")
+    assert bool((o.view(F_, HW, inner).permute(1, 0, 2).float().cpu() - ref).abs().max() < 10 * tol)
+
+
 def test_attention_fused_qkv_strides(ops, dev):
     """q/k/v as column slices of one fused projection output (row stride 3C): no copies needed."""
     B, N, heads, d = 2, 256, 8, 40
