@@ -198,8 +198,10 @@ class Responder:
             # the decoder pass is a dependent chain of ~370 short kernels per UNet evaluation: its stream gets the higher priority, so
             # its workgroups are dispatched as soon as a CU frees up; the LLM's long weight-streaming grids fill the rest of the chip
             prio = os.environ.get("SPIDER_BENCH_PRIO", "u")
-            self._streams = (torch.cuda.Stream(device=dev, priority=-1 if prio == "l" else 0),
-                             torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0))
+            sL_ = torch.cuda.Stream(device=dev, priority=-1 if prio == "l" else 0)
+            # tuning aid: HIP hands out its hardware queues round-robin; skipping n of them changes which queue / pipe the pair shares
+            self._skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("SPIDER_BENCH_STREAM_SKIP", "0")))]
+            self._streams = (sL_, torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0))
         sL, sU = self._streams
         cur = torch.cuda.current_stream(dev)
         if self._pending is None:                   # pipeline empty (first step): this response's own LLM pass comes first
