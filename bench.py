@@ -202,6 +202,28 @@ class Responder:
             # tuning aid: HIP hands out its hardware queues round-robin; skipping n of them changes which queue / pipe the pair shares
             self._skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("SPIDER_BENCH_STREAM_SKIP", "0")))]
             self._streams = (sL_, torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0))
+            # tuning aid: CU-masked streams (hipExtStreamCreateWithCUMask): SPIDER_BENCH_CUMASK_U / _L = "<n>[:stride]" enables n CUs
+            # (every stride-th bit from 0) for the decoder / LLM stream
+            def _masked(spec):
+                import ctypes
+                n, _, stride = spec.partition(":")
+                n, stride = int(n), int(stride or 1)
+                bits = [0] * 8
+                i = c = 0
+                while c < n and i < 256:
+                    bits[i // 32] |= 1 << (i % 32)
+                    i += stride
+                    c += 1
+                hip = ctypes.CDLL("libamdhip64.so")
+                st = ctypes.c_void_p()
+                arr = (ctypes.c_uint32 * 8)(*bits)
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, arr)
+                assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
+                return torch.cuda.ExternalStream(st.value, device=dev)
+            if os.environ.get("SPIDER_BENCH_CUMASK_U"):
+                self._streams = (self._streams[0], _masked(os.environ["SPIDER_BENCH_CUMASK_U"]))
+            if os.environ.get("SPIDER_BENCH_CUMASK_L"):
+                self._streams = (_masked(os.environ["SPIDER_BENCH_CUMASK_L"]), self._streams[1])
         sL, sU = self._streams
         cur = torch.cuda.current_stream(dev)
         if self._pending is None:                   # pipeline empty (first step): this response's own LLM pass comes first

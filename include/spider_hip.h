@@ -49,6 +49,12 @@ int spider_gemv_swiglu_bf16(const void* W_gate_up, const void* x, void* out, con
 /* final norm + lm_head + greedy argmax (modeling_llama3.py:619,870-871; HF greedy loop driven from
  * spider.py:1492-1508). logits (bf16 [B,V]) optional. ws_val/ws_idx: B*spider_lm_head_nparts(V) floats/ints. */
 int spider_lm_head_nparts(int V);
+
+/* End of one greedy decode step (the bookkeeping of GenerationMixin's loop, spider.py:1492-1508, kept on the device so that the
+ * step is one hipGraph): cur_ids <- next_ids; pos, slot, kv_end += 1; hist[b][n_hist[b]++] = next_ids[b]. int32 [B] each; hist
+ * [B, cap] / n_hist [B] optional (both NULL: cursors only); entries past cap are dropped, the counter still advances. */
+int spider_decode_advance_i32(const int* next_ids, int* cur_ids, int* pos, int* slot, int* kv_end, int* hist, int* n_hist,
+                              int cap, int B, void* stream);
 int spider_lm_head_argmax_bf16(const void* W, const void* x, const void* norm_w, float eps, int* out_ids, void* logits,
                                void* ws_val, void* ws_idx, int B, int V, int K, void* stream);
 

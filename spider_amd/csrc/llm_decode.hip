@@ -455,6 +455,26 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
     if (threadIdx.x == 0) out[b] = si[0];
 }
 
+// End of a decode step, one launch instead of five elementwise ones: the token just chosen becomes the next input, the
+// position / cache cursors advance, and the token is appended to the sequence's row of the on-device token history
+// (hist [B, cap], n_hist [B] tokens already there) that generate() returns. All index math, one thread per sequence.
+__global__ void decode_advance_kernel(const int* __restrict__ next_ids, int* __restrict__ cur_ids, int* __restrict__ pos,
+                                      int* __restrict__ slot, int* __restrict__ kv_end, int* __restrict__ hist,
+                                      int* __restrict__ n_hist, int cap, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int id = next_ids[b];
+    cur_ids[b] = id;
+    pos[b] += 1;
+    slot[b] += 1;
+    kv_end[b] += 1;
+    if (hist) {
+        const int n = n_hist[b];
+        if (n < cap) hist[(size_t)b * cap + n] = id;
+        n_hist[b] = n + 1;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // RoPE (half-rotation layout) on q and k + append of k, v into the KV cache.
 //   qkv   [rows, (n_q + 2 n_kv) * d]  (rows = B*S, output of the fused QKV projection)
@@ -1302,6 +1322,16 @@ int spider_gemv_swiglu_bf16(const void* W_gate_up, const void* x, void* out, con
     lmhead_partial_kernel<NB_, 2><<<nparts, 256, (size_t)NB_ * K * 2, (hipStream_t)stream>>>(                   \
         (const bf16_t*)W, (const bf16_t*)x, (const bf16_t*)norm_w, eps, (float*)ws_val, (int*)ws_idx,          \
         (bf16_t*)logits, V, K)
+
+// cur_ids <- next_ids; pos, slot, kv_end += 1; hist[b, n_hist[b]++] = next_ids[b] (hist / n_hist may be NULL). All int32 [B].
+int spider_decode_advance_i32(const int* next_ids, int* cur_ids, int* pos, int* slot, int* kv_end, int* hist, int* n_hist,
+                              int cap, int B, void* stream) {
+    SPIDER_CHECK(next_ids && cur_ids && pos && slot && kv_end && B > 0, "decode_advance: cursors required");
+    SPIDER_CHECK(!hist || (n_hist && cap > 0), "decode_advance: history needs its counters and capacity");
+    decode_advance_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(next_ids, cur_ids, pos, slot, kv_end, hist, n_hist, cap, B);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
 
 int spider_lm_head_nparts(int V) {
     int n = (V + 63) / 64;  // 64 rows per block

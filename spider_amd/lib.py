@@ -33,6 +33,7 @@ SIGNATURES = {
     "spider_gemv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "spider_gemv_swiglu_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "spider_lm_head_nparts": (_i, [_i]),
+    "spider_decode_advance_i32": (_i, [_vp] * 7 + [_i, _i, _vp]),
     "spider_lm_head_argmax_bf16": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "spider_gemv_fm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "spider_gemv_swiglu_fm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -349,11 +349,8 @@ class LlamaEngine:
                                logits=st.get("logits"))
         if hs is not None:  # HF reports the normed state as the last hidden state (modeling_llama3.py:619-623)
             ops.rmsnorm(h, self.norm, c.eps, out=hs[c.layers])
-        # advance the device-side cursors (index math only)
-        st["cur_ids"].copy_(st["next_ids"])
-        st["pos"].add_(1)
-        st["slot"].add_(1)
-        st["kv_end"].add_(1)
+        # advance the device-side cursors and append the token to the on-device history (index math only, one launch)
+        ops.decode_advance(st["next_ids"], st["cur_ids"], st["pos"], st["slot"], st["kv_end"], st["hist"], st["n_hist"])
 
     def _make_state(self, B: int, want_hidden: bool, want_logits: bool) -> dict:
         c, dv = self.cfg, self.device
@@ -371,7 +368,7 @@ class LlamaEngine:
                   attn_ws=(torch.empty(B * c.n_q * nsplit * c.head_dim, dtype=torch.float32, device=dv),
                            torch.empty(B * c.n_q * nsplit * 2, dtype=torch.float32, device=dv)),
                   lm_ws=(torch.empty(B * npart, dtype=torch.float32, device=dv), i32(B * npart)),
-                  attn_cnt=i32(B * c.n_kv), embeds_in=None)
+                  attn_cnt=i32(B * c.n_kv), embeds_in=None, hist=i32(B, self.max_len), n_hist=i32(B))
         if want_hidden:
             st["hidden_buf"] = bf(c.layers + 1, B, c.hidden)
         if want_logits:
@@ -464,8 +461,13 @@ class LlamaEngine:
         st["slot"].fill_(S)
         st["kv_end"].fill_(S + 1)
 
-        tokens = torch.empty(B, max_new_tokens, dtype=torch.int32, device=dv)
+        # generated ids live in the decode state's history buffer: every decode step appends its token there itself
+        # (decode_advance), so the loop below issues nothing but the graph replay
+        if max_new_tokens > st["hist"].shape[1]:
+            raise ValueError(f"max_new_tokens={max_new_tokens} exceeds the engine's max_len={st['hist'].shape[1]}")
+        tokens = st["hist"][:, :max_new_tokens]
         tokens[:, 0].copy_(st["next_ids"])
+        st["n_hist"].fill_(1)
         logits_steps = [st["logits"].clone()] if return_logits else None
         eos = _id_list(eos_token_id)
         prompt_cpu = None if embeds_only else input_ids.cpu().long()
@@ -485,7 +487,7 @@ class LlamaEngine:
         final = check(1, 0)
         if use_graph and graph is None and final is None and max_new_tokens > 2:
             # warm the kernels outside capture, then capture one decode step; cursors live on device
-            snap = {k: st[k].clone() for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end")}
+            snap = {k: st[k].clone() for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end", "n_hist")}
             s = torch.cuda.Stream(device=dv)
             s.wait_stream(torch.cuda.current_stream(dv))
             with torch.cuda.stream(s):
@@ -504,7 +506,6 @@ class LlamaEngine:
                 graph.replay()
             else:
                 self._decode_step(st)
-            tokens[:, n].copy_(st["next_ids"])
             if output_hidden_states:
                 hidden_steps.append(tuple(t.clone().unsqueeze(1) for t in st["hidden_buf"]))
             if return_logits:

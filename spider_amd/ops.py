@@ -150,6 +150,20 @@ def rmsnorm(x, w, eps, res=None, res_out=None, out=None):
     return out
 
 
+def decode_advance(next_ids, cur_ids, pos, slot, kv_end, hist=None, n_hist=None):
+    """End of a decode step in one launch: cur_ids <- next_ids; pos, slot, kv_end += 1; hist[b, n_hist[b]++] = next_ids[b]."""
+    for t, n in ((next_ids, "next_ids"), (cur_ids, "cur_ids"), (pos, "pos"), (slot, "slot"), (kv_end, "kv_end")):
+        _chk(t, torch.int32, n)
+    B = next_ids.numel()
+    assert cur_ids.numel() == B and pos.numel() == B and slot.numel() == B and kv_end.numel() == B
+    cap = 0
+    if hist is not None:
+        _chk(hist, torch.int32, "hist"); _chk(n_hist, torch.int32, "n_hist")
+        assert hist.dim() == 2 and hist.shape[0] == B and n_hist.numel() == B
+        cap = hist.shape[1]
+    _lib.call("spider_decode_advance_i32", _p(next_ids), _p(cur_ids), _p(pos), _p(slot), _p(kv_end), _p(hist), _p(n_hist), cap, B, _stream())
+
+
 def gemv(W, x, bias=None, res=None, norm_w=None, eps=0.0, out=None):
     """out[b,n] = sum_k xin[b,k] W[n,k] (+bias) (+res); xin = rmsnorm(x)*norm_w if norm_w is given. 1 <= B <= 8."""
     _chk(W, BF16, "W"); _chk(x, BF16, "x")
