@@ -885,6 +885,82 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_fused_kernel(
         }
     }
     __syncthreads();
+    if (nsplit > 1 && inline_combine) {
+        // ---- one launch: publish this split's partial with write-through (sc1) 16-byte stores, take a ticket; the block that
+        // draws the last ticket of its (sequence, kv head) merges all splits in split order (so the result does not depend on
+        // which block that is) and writes the output. Hand-off (MI355X_MICROARCH.md, valid forms): every byte stored sc1, each
+        // storing wave drains (vmcnt(0)), workgroup barrier, ONE lane's agent-scope atomic add; the last arriver takes an
+        // agent-scope acquire before its plain loads. The counter is reset by the reducer: graph replays need no memset.
+        for (int idx = threadIdx.x; idx < G * (D / 4); idx += NWV * 64) {
+            const int g = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
+            float mm = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) mm = fmaxf(mm, sm_m[w][g]);
+            float ll = 0.f;
+            f32x4 oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) {
+                const float a = (sm_m[w][g] == -INFINITY) ? 0.f : __expf(sm_m[w][g] - mm);
+                ll += sm_l[w][g] * a;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oo[j] += sm_o[w][g][d4 + j] * a;
+            }
+            const size_t pi = ((size_t)b * n_q + hk * G + g) * nsplit + split;
+            float* po = part_o + pi * D + d4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(po), "v"(oo) : "memory");
+            if (d4 == 0) {
+                const float2 mlv = float2{mm, ll};
+                float* pm = part_ml + pi * 2;
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(pm), "v"(mlv) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int ticket = __hip_atomic_fetch_add(cnt + (size_t)b * n_kv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm_last = (ticket == nsplit - 1) ? 1 : 0;
+            if (sm_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (!sm_last) return;
+        // reducer: thread (g, 4 head dims) walks the splits; 16 partial rows in flight per thread
+        for (int idx = threadIdx.x; idx < G * (D / 4); idx += NWV * 64) {
+            const int g = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
+            const size_t bh = (size_t)b * n_q + hk * G + g;
+            const float2* ml = reinterpret_cast<const float2*>(part_ml) + bh * nsplit;
+            float mx = -INFINITY;
+            for (int sidx = 0; sidx < nsplit; ++sidx) mx = fmaxf(mx, ml[sidx].x);
+            float lsum = 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < nsplit; s0 += 16) {
+                f32x4 ov[16];
+                float2 mv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int sidx = min(s0 + u, nsplit - 1);
+                    ov[u] = *reinterpret_cast<const f32x4*>(part_o + (bh * nsplit + sidx) * D + d4);
+                    mv[u] = ml[sidx];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float w = (s0 + u < nsplit && mv[u].x != -INFINITY) ? __expf(mv[u].x - mx) : 0.f;
+                    lsum += mv[u].y * w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += ov[u][j] * w;
+                }
+            }
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+            u32x2 o2;
+            o2.x = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+            o2.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+            *reinterpret_cast<u32x2*>(out + bh * D + d4) = o2;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(cnt + (size_t)b * n_kv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     for (int idx = threadIdx.x; idx < G * D; idx += NWV * 64) {
         const int g = idx / D, dd = idx % D;
         float mm = -INFINITY;
@@ -906,43 +982,6 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_fused_kernel(
             if (dd == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
         }
     }
-    if (nsplit == 1 || !inline_combine) return;
-
-    // ---- publish the partials, take a ticket; the last arriver reduces ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep: the compiler may drop the fence's own wait
-        const int ticket = __hip_atomic_fetch_add(cnt + (size_t)b * n_kv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm_last = (ticket == nsplit - 1) ? 1 : 0;
-        if (sm_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!sm_last) return;
-    // reducer: wave w owns heads w, w+4 (no LDS, no barriers); each lane 2 head-dim elements, loop over the splits
-    for (int g = wave; g < G; g += NWV) {
-        const size_t bh = (size_t)b * n_q + hk * G + g;
-        float mr = -INFINITY, lr = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll 4
-        for (int sidx = 0; sidx < nsplit; ++sidx) {
-            const float ms = part_ml[(bh * nsplit + sidx) * 2], ls = part_ml[(bh * nsplit + sidx) * 2 + 1];
-            const float2 ov = *reinterpret_cast<const float2*>(part_o + (bh * nsplit + sidx) * D + lane * 2);
-            const float mn = fmaxf(mr, ms);
-            const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mn);
-            const float bs = (ms == -INFINITY) ? 0.f : __expf(ms - mn);
-            lr = lr * a + ls * bs;
-            o0 = o0 * a + ov.x * bs;
-            o1 = o1 * a + ov.y * bs;
-            mr = mn;
-        }
-        const float inv = lr > 0.f ? 1.f / lr : 0.f;
-        *reinterpret_cast<uint32_t*>(out + bh * D + lane * 2) = pack_bf16x2(o0 * inv, o1 * inv);
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(cnt + (size_t)b * n_kv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1272,6 +1311,8 @@ static int gemv_batch(const void* W, const void* x, void* out, const void* bias,
 }
 
 
+#define SPIDER_ATTN_INLINE_DEFAULT 0
+
 // ==============================================================================================
 // C ABI
 // ==============================================================================================
@@ -1490,7 +1531,10 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
     const int G = n_q / n_kv;
     dim3 grid(nsplit, n_kv, B);
     // combine inline (ticket + last-arriver reduce) or by the separate combine kernel (SPIDER_ATTN_INLINE=0/1)
-    static const int inline_combine = [] { const char* e = getenv("SPIDER_ATTN_INLINE"); return e ? atoi(e) : 0; }();
+    // split-KV combine by the last-arriving block of the same launch (1) or by attn_combine_kernel (0); read per call so that
+    // tests can exercise both forms in one process
+    const char* inl_e = getenv("SPIDER_ATTN_INLINE");
+    const int inline_combine = inl_e ? atoi(inl_e) : SPIDER_ATTN_INLINE_DEFAULT;
     static const int wide_env = [] { const char* e = getenv("SPIDER_ATTN_WIDE"); return e ? atoi(e) : -1; }();
     const bool wide = wide_env >= 0 ? wide_env != 0 : (T_max / nsplit >= 96);
     switch (G) {

@@ -403,11 +403,14 @@ def test_latent_plumbing(ops, dev):
 
 @pytest.mark.parametrize("B,n_q,n_kv,T,nsplit,beg", [(1, 28, 4, 1537, 32, 0), (2, 32, 8, 300, 8, 0), (3, 8, 8, 1, 4, 0),
                                                     (2, 4, 2, 130, 5, 17), (1, 7, 1, 6, 1, 0), (1, 28, 4, 2000, 32, 0)])
-def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
+@pytest.mark.parametrize("inline", ["0", "1"])
+def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg, inline, monkeypatch):
     """One-launch RoPE + KV append + split-KV attention + cross-block combine == the three separate kernels
     (bit-identical cache rows, outputs equal up to fp32 summation order), repeated to exercise the self-resetting
-    ticket counters the way hipGraph replays do."""
+    ticket counters the way hipGraph replays do. inline = 1: the combine by the last-arriving block of the same launch
+    (write-through partial stores + ticket); 0: by attn_combine_kernel."""
     from oracle.llama import LlamaCfg, rope_table
+    monkeypatch.setenv("SPIDER_ATTN_INLINE", inline)
     d, Tmax = 128, T + 5
     cs = rope_table(LlamaCfg(head_dim=d, rope_theta=1e6), Tmax + 8).to(dev)
     kc0, vc0 = rnd(B, n_kv, Tmax, d, seed=2).to(dev), rnd(B, n_kv, Tmax, d, seed=3).to(dev)
@@ -430,6 +433,9 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg):
         assert torch.equal(k1, k2) and torch.equal(v1, v2), "KV append must be bit-identical"
         close(out, ref.float(), 4e-3, 1e-2, f"fused decode attention rep {rep}")
         assert int(cnt.abs().sum()) == 0, "ticket counters must be back to zero after every launch"
+        out2 = torch.empty_like(out)
+        ops.attn_decode_fused(qkv, pos, cs, kc0.clone(), vc0.clone(), kv_end, kv_beg, cnt, n_q, nsplit, ws, out2)
+        assert torch.equal(out, out2), "the merge order is fixed: repeats are bit-identical whichever block arrives last"
 
 
 def test_gemm_256_tile_repeatable_under_load(ops, dev):
