@@ -391,8 +391,9 @@ def measure_roofline(resp, device):
             "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
             "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n,
             "co_run": ({"launch_interval_us": round(us_corun, 2), "effective_GBps": round(bytes_alg / (us_corun * 1e-6) / 1e9, 1),
-                        "note": "same loop while UNet evaluations replay on the decoder stream (two-stream schedule): per-launch interval incl. "
-                                "the later start of each dependent launch; the kernel's own duration is unchanged (rocprofv3)"} if corun else None)}
+                        "note": "same loop while UNet evaluations replay on the decoder stream (two-stream schedule): launch-to-launch interval "
+                                "of the dependent chain (kernel + the dispatch gap between dependent launches; rocprofv3 serialises the two "
+                                "streams, so the split between the two is not observable with it)"} if corun else None)}
 
 
 def _unet_pmc_traffic(kernel_prefix):

@@ -21,7 +21,7 @@ if ks:
     rows = list(csv.DictReader(open(ks)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(f"{P}/{tag}_bench_kernel_stats_top.txt", "w") as f:
-        f.write(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --headline-only (two-stream schedule: LLM kernels co-run with the decoder pass) : total kernel time {tot / 1e6:.1f} ms\n")
+        f.write(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --headline-only (two-stream schedule requested; NOTE: rocprofv3 kernel tracing serialises the two streams -- the step takes the serial sum under the profiler, see r03_bench_under_rocprof.json -- so these are every kernel's durations ALONE on the chip, as in the serial file) : total kernel time {tot / 1e6:.1f} ms\n")
         for r in rows[:25]:
             f.write(f"{short(r['Name']):80s} calls {int(float(r['Calls'])):7d} avg_us {float(r['AverageNs']) / 1e3:9.1f} "
                     f"total_ms {float(r['TotalDurationNs']) / 1e6:9.2f} {float(r['Percentage']):5.1f}%\n")
@@ -57,6 +57,21 @@ if ku:
             f.write(f"{short(r['Name']):80s} n/step {float(r['Calls']) / evals:6.1f} avg_us {float(r['AverageNs']) / 1e3:8.1f} "
                     f"ms/step {float(r['TotalDurationNs']) / 1e6 / evals:7.3f}\n")
     unet = dict(launches_per_step=round(n_launch), kernel_ms_per_step=round(t_ms, 3))
+
+
+# ---- zeroscope UNet3D step alone (2 x 16 frames at 40 x 72; scripts/bench_video.py 4: warm-up + 4 timed evaluations + VAE decode)
+kv = newest(f"{G}/prof_{tag}_unet3d/**/*kernel_stats.csv")
+if kv:
+    rows = list(csv.DictReader(open(kv)))
+    log = open(f"{G}/{tag}_prof_unet3d.log").read() if os.path.exists(f"{G}/{tag}_prof_unet3d.log") else ""
+    step = [l for l in log.splitlines() if l.startswith("unet3d step ms")]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(f"{P}/{tag}_unet3d_step_stats.txt", "w") as f:
+        f.write("rocprofv3 --kernel-trace --stats -- python scripts/bench_video.py 4   (zeroscope UNet3D, batch 2 x 16 frames at 40 x 72: 5 evaluations + the VAE decode of 16 frames)\n")
+        f.write(f"total kernel time {tot / 1e6:.1f} ms   {step[-1] if step else ''}\n")
+        for r in rows[:30]:
+            f.write(f"{short(r['Name']):80s} calls {int(float(r['Calls'])):6d} avg_us {float(r['AverageNs']) / 1e3:8.1f} "
+                    f"total_ms {float(r['TotalDurationNs']) / 1e6:8.2f} {float(r['Percentage']):5.1f}%\n")
 
 
 def per_kernel(path, counter):
