@@ -151,10 +151,16 @@ class Responder:
         """LLM generate for B prompts on the CURRENT stream; ends with the one device->host copy of the generated ids."""
         from spider_amd import ops
         a = self.args
+        gen = self._llm_enqueue(B)
+        return gen, gen.cpu()                      # the one device->host sync of the LLM phase
+
+    def _llm_enqueue(self, B):
+        """the LLM pass without its final device->host copy: everything is enqueued on the current stream, the host does not wait"""
+        from spider_amd import ops
+        a = self.args
         with ops.workspace_scope("llm"):
             toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
-        gen = toks[:, a.prompt_len:]
-        return gen, gen.cpu()                      # the one device->host sync of the LLM phase
+        return toks[:, a.prompt_len:]
 
     def _decoder_pass(self, B, gen_host):
         """routing of the generated text + the image decoder (text encoder, UNet loop, VAE) on the CURRENT stream, no host sync"""
@@ -234,14 +240,37 @@ class Responder:
         sU.wait_stream(cur)
         sL.wait_stream(cur)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        with torch.cuda.stream(sU):                 # decoder pass of THIS response: enqueued first (asynchronous on the host)
-            ev[0].record(sU)
-            out = self._decoder_pass(B, gen_host)
-            ev[1].record(sU)
+        # The host enqueues the two passes from two threads: the LLM pass (the longer one: 22 k launches that fill its hardware queue,
+        # so its enqueue blocks for most of the pass) from this thread, the decoder pass of THIS response from a helper thread --
+        # neither stream waits for the other's host-side launch work (the current stream / workspace scope are per thread).
+        box = {}
+
+        def _dec():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(sU):
+                    ev[0].record(sU)
+                    box["out"] = self._decoder_pass(B, gen_host)
+                    ev[1].record(sU)
+            except BaseException as e:          # surfaced on the main thread below
+                box["err"] = e
+
+        th = None
+        if os.environ.get("SPIDER_BENCH_ENQUEUE_THREAD", "1") != "0":
+            import threading
+            th = threading.Thread(target=_dec, name="decoder-enqueue")
+            th.start()
+        else:
+            _dec()
         with torch.cuda.stream(sL):                 # LLM pass of the NEXT response, concurrently (blocks the host at its end)
             ev[2].record(sL)
             self._pending = self._llm_pass(B)
             ev[3].record(sL)
+        if th is not None:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        out = box["out"]
         sU.synchronize()
         sL.synchronize()
         self.overlap_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}

@@ -28,7 +28,15 @@ _WS = {}
 WS_BYTES = 64 << 20
 
 
-_WS_SCOPE = ["default"]
+import threading as _threading
+
+
+class _ScopeStack(_threading.local):       # per host thread: two threads may enqueue on two streams at once (bench.py)
+    def __init__(self):
+        self.names = ["default"]
+
+
+_WS_SCOPE = _ScopeStack()
 
 
 class workspace_scope:
@@ -41,18 +49,18 @@ class workspace_scope:
         self.name = name
 
     def __enter__(self):
-        _WS_SCOPE.append(self.name)
+        _WS_SCOPE.names.append(self.name)
         return self
 
     def __exit__(self, *exc):
-        _WS_SCOPE.pop()
+        _WS_SCOPE.names.pop()
         return False
 
 
 def _workspace(device) -> torch.Tensor:
     """Per-(device, scope) fp32 split-K workspace (stream-ordered reuse; allocated on first use, outside any graph capture:
     engines run an eager warm-up pass before they capture)."""
-    key = (device.type, device.index, _WS_SCOPE[-1])
+    key = (device.type, device.index, _WS_SCOPE.names[-1])
     if key not in _WS:
         _WS[key] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
     return _WS[key]
