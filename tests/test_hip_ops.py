@@ -460,6 +460,31 @@ def test_gemm_256_tile_repeatable_under_load(ops, dev):
     torch.cuda.synchronize()
 
 
+def test_attention_kernels_repeatable_under_load(ops, dev):
+    """Race screen of the attention kernels that overlap their own loads with compute: the software-pipelined dense flash kernel
+    (K / V images re-staged while the previous tile is still being scored: the round-2 advisor found its prologue one barrier
+    short), the one-wave-per-sequence kernel (wave-private LDS tile, no barrier) and the split-KV decode attention. Repeated
+    launches must be bit-identical while another stream keeps HBM busy and shifts the timing of the waves."""
+    side = torch.cuda.Stream()
+    junk = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+    q40 = rnd(2, 4096, 3 * 320, seed=1).to(dev)                       # SD-v1.5 64^2 self-attention: d = 40, pipelined kernel, KQ = 3
+    q80 = rnd(2, 1024, 3 * 640, seed=2).to(dev)                       # 32^2: d = 80 in 96-wide tiles
+    q64 = rnd(8, 2304, 3 * 640, seed=3).to(torch.float16).to(dev)     # SDXL 48^2: d = 64, f16 instantiation
+    t16 = rnd(16 * 700, 3 * 320, seed=4).to(dev).view(16, 700, 960).permute(1, 0, 2)      # temporal layout: 700 pixels x 16 frames
+    fs = [lambda: ops.attention(q40[..., :320], q40[..., 320:640], q40[..., 640:], 8),
+          lambda: ops.attention(q80[..., :640], q80[..., 640:1280], q80[..., 1280:], 8),
+          lambda: ops.attention(q64[..., :640], q64[..., 640:1280], q64[..., 1280:], 10),
+          lambda: ops.attention(t16[..., :320], t16[..., 320:640], t16[..., 640:], 5)]
+    for f in fs:
+        ref = f().clone()
+        for i in range(30):
+            if i % 2 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            assert torch.equal(f(), ref), f"repeat {i} differs"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,inner,K", [(8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (100, 72, 64), (128, 5120, 1280),
                                        (4608, 5120, 1280),    # 256^2 LDS-DMA kernel with the GEGLU epilogue (SDXL 24^2 ff1)
                                        (4000, 2504, 1096),    # the same, ragged M / N / K
