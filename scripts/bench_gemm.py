@@ -27,6 +27,14 @@ if os.environ.get("SHAPES") == "sdxl":   # SDXL story step at 768^2, CFG batch 8
         ("c24 2560>1280", 4608, 1280, 23040, 2560, 24),
     ]
 
+if os.environ.get("SHAPES") == "deep":   # SD-v1.5 UNet, 16^2 / 8^2 maps (CFG batch 2): the weight-bound small-M problems
+    SHAPES = [
+        ("c8 1280>1280", 128, 1280, 11520, 1280, 8), ("c8 2560>1280", 128, 1280, 23040, 2560, 8),
+        ("c16 1280>1280", 512, 1280, 11520, 1280, 16), ("c16 2560>1280", 512, 1280, 23040, 2560, 16), ("c16 640>1280", 512, 1280, 5760, 640, 16),
+        ("u16 out", 512, 1280, 1280, 0, 0), ("u16 ff2", 512, 1280, 5120, 0, 0), ("u16 qkv", 512, 3840, 1280, 0, 0),
+        ("u8 out", 128, 1280, 1280, 0, 0), ("u8 ff2", 128, 1280, 5120, 0, 0),
+    ]
+
 if os.environ.get("SHAPES") == "v3d":   # zeroscope UNet3D step, 2 x 16 frames at 40 x 72 (rows = sample, frame, pixel)
     SHAPES = [
         ("v0 out", 92160, 320, 320, 0, 0), ("v0 qkv", 92160, 960, 320, 0, 0), ("v0 ff1", 92160, 2560, 320, 0, 0), ("v0 ff2", 92160, 320, 1280, 0, 0),

@@ -1543,7 +1543,9 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     const int n160 = (a.N + 159) / 160;
     int dma_bm = 128;
     static const int bm64_env = getenv("SPIDER_GEMM_BM64") ? atoi(getenv("SPIDER_GEMM_BM64")) : 1;
-    if (!force_tile && !a.geglu && a.M >= (a.conv ? 512 : 2048) && nk >= (a.conv && a.M >= 2048 ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
+    // (a long-K linear with 512..2047 rows also belongs here: the UNet's 16^2 ff2, 512 x 1280 x 5120, 27.3 -> 20.6 us with 8 K splits)
+    const bool dma_rows = a.conv ? a.M >= 512 : (a.M >= 2048 || (a.M >= 512 && nk >= 64));
+    if (!force_tile && !a.geglu && dma_rows && nk >= (a.conv && a.M >= 2048 ? 16 : 40) && n160 * 160 * 25 <= a.N * 27) {
         // 64-row tiles when the 128-row tiling gives at most ~half a wave of blocks (<= 160) AND K is short (< 64 tiles): the
         // 8192 x 320 x 2880 convs -> 256 tiles, no split-K (measured 29.7 vs 33.8 us); with a longer K the 16 x 80 wave tile's
         // lower MFMA density costs more than the slab round trip of 2 splits (640 -> 320 at 64^2: 55 vs 49 us)
