@@ -84,7 +84,7 @@ def launch_ranks(args, script=None, argv=None) -> int:
     import socket
     import subprocess
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and not os.environ.get("SPIDER_SHARE_GPU"):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -795,7 +795,7 @@ def run_timed(resp, args, rank, world, device):
     dt = time.perf_counter() - t0
     dist_info = {"world_size": 1, "backend": None}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
@@ -818,6 +818,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+    if os.environ.get("SPIDER_SHARE_GPU"):      # rehearsal: every rank computes on cuda:0 (with SPIDER_DIST_BACKEND=gloo)
+        local = 0
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     a2m = args.workload == "any2many"
@@ -914,7 +916,7 @@ def text_image_extras(args, resp, device):
     torch.cuda.synchronize(device)
     e0.record()
     for i in range(10):
-        resp.unet.step(x2, i)
+        resp.unet.step(x2, i % len(ts))
     e1.record(); e1.synchronize()
     unet_ms = e0.elapsed_time(e1) / 10
     fl = unet_flops(UNetConfig.sd15(), 64, 64)

@@ -26,8 +26,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # SPIDER_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+            backend = os.environ.get("SPIDER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -68,10 +68,14 @@ def gather_padded(local: Dict[str, torch.Tensor], counts_max: int, rank: int, wo
     if world == 1:
         bufs = [flat]
     else:
+        if flat.is_cuda and dist.get_backend() == "gloo":     # gloo gathers host buffers only (rehearsal transport; RCCL takes the
+            flat = flat.cpu()                                 # device buffer as it is)
         bufs = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
         dist.gather(flat, bufs, dst=dst)
         if rank != dst:
             return None
+        if bufs[0].device != dev:
+            bufs = [b_.to(dev) for b_ in bufs]
     out, off = {}, 0
     for nme, dt, shp, nb, padded in meta:
         out[nme] = torch.stack([b[off:off + nb].view(dt).reshape(shp) for b in bufs])

@@ -1,0 +1,30 @@
+"""GPU: the whole `bench.py --gpus 2` path with real responders -- two rank processes, each with its own engines, two-stream
+schedule, barrier + max-over-ranks timing, ONE gather of the padded outputs to rank 0 -- rehearsed on ONE GPU: both ranks compute on
+cuda:0 (SPIDER_SHARE_GPU=1) and the collective runs over gloo (SPIDER_DIST_BACKEND=gloo) because RCCL refuses two ranks on one
+device. The RCCL transport itself is covered by tests/test_dp_nccl_gpu.py where two GPUs are visible."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ, SPIDER_SHARE_GPU="1", SPIDER_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only",
+           "--prompt-len", "192", "--new-tokens", "12", "--denoise-steps", "5"]
+    o = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert o.returncode == 0, o.stderr[-2000:]
+    lines = [l for l in o.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dist"] == {"world_size": 2, "backend": "gloo"}
+    assert d["gathered"]["tokens"] == [2, 1, 12] and d["gathered"]["out"] == [2, 1, 3, 512, 512] and d["gathered"]["count"] == [2]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-2 * d["value"]   # all ranks' responses / max time
