@@ -15,6 +15,8 @@ $P --stats -d gpurun_out/prof_r03_serial -- python3 bench.py --steps 3 --warmup 
 export UNET_DTYPE=f16 UNET_STREAM32=1      # the engines as the pipelines / bench.py load them
 $P --stats -d gpurun_out/prof_r03_unet -- python3 scripts/prof_unet.py 20 > gpurun_out/r03_prof_unet.log 2>&1
 $P --stats -d gpurun_out/prof_r03_unet3d -- python3 scripts/bench_video.py 4 > gpurun_out/r03_prof_unet3d.log 2>&1
+$P --pmc FETCH_SIZE -d gpurun_out/pmc_r03_unet3d_fetch -- python3 scripts/bench_video.py 2 > /dev/null 2>&1
+$P --pmc WRITE_SIZE -d gpurun_out/pmc_r03_unet3d_write -- python3 scripts/bench_video.py 2 > /dev/null 2>&1
 $P --pmc FETCH_SIZE -d gpurun_out/pmc_r03_unet_fetch -- python3 scripts/prof_unet.py 4 > /dev/null 2>&1
 $P --pmc WRITE_SIZE -d gpurun_out/pmc_r03_unet_write -- python3 scripts/prof_unet.py 4 > /dev/null 2>&1
 $P --pmc FETCH_SIZE -d gpurun_out/pmc_r03_dec1_fetch -- python3 scripts/prof_decode.py 12 > /dev/null 2>&1

@@ -102,6 +102,21 @@ if fe:
     out.update(unet)
     json.dump(out, open(f"{P}/{tag}_pmc_unet_hbm.json", "w"), indent=1)
 
+# ---- HBM bytes of the UNet3D step's kernels (temporal attention, GroupNorm passes, the big convs)
+fe3, wr3 = per_kernel(f"{G}/pmc_{tag}_unet3d_fetch", "FETCH_SIZE"), per_kernel(f"{G}/pmc_{tag}_unet3d_write", "WRITE_SIZE")
+if fe3:
+    ours3 = [k for k in fe3 if not k.startswith("at::") and not k.startswith("void at::") and "rocblas" not in k and "rocclr" not in k]
+    top3 = sorted(ours3, key=lambda k: -fe3[k][0] * fe3[k][1])[:12]
+    top3 += [k for k in ours3 if k.startswith("attn_short_kernel") and k not in top3]
+    out3 = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python scripts/bench_video.py 2 (zeroscope UNet3D, "
+                    "2 x 16 frames at 40 x 72, bf16 engines); per-launch averages; FETCH_SIZE in KB, x2 gfx950 correction applied in hbm_read_bytes. "
+                    "attn_short_kernel (temporal attention, one launch per sample): algorithmic 2880 x 5 sequence-heads x (3 x 16 x 64 + 16 x 64) x 2 B = "
+                    "88.5 MB read + 29.5 MB written", "kernels": []}
+    for k in top3:
+        out3["kernels"].append(dict(kernel=k, launches=fe3[k][0], FETCH_SIZE_avg_KB=round(fe3[k][1], 1), hbm_read_bytes=int(fe3[k][1] * 1024 * 2),
+                                    WRITE_SIZE_avg_KB=round(wr3.get(k, (0, 0.0))[1], 1), hbm_write_bytes=int(wr3.get(k, (0, 0.0))[1] * 1024)))
+    json.dump(out3, open(f"{P}/{tag}_pmc_unet3d_hbm.json", "w"), indent=1)
+
 # ---- decode weight streams
 dec = {}
 for key, d, kname in (("b1", "dec1", "gemv_kernel<1, 1, true, true"), ("b8", "dec8", "skinny_fm_kernel<1, 8, true>")):
