@@ -14,6 +14,12 @@ elif which == "conv64":
 elif which == "conv64_320":   # the roofline_unet_conv shape of bench.py
     x = torch.randn(2, 64, 64, 320, device=dev).to(DT); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.conv2d(x, w)
+elif which == "conv48_640":   # SDXL 48^2 level (CFG batch 8): 18432 rows, input 23.6 MB
+    x = torch.randn(8, 48, 48, 640, device=dev).to(DT); w = (torch.randn(640, 3, 3, 640, device=dev) * 0.02).to(DT)
+    f = lambda: ops.conv2d(x, w)
+elif which == "conv3d_640":   # zeroscope 20 x 36 level, 2 x 16 frames: 23040 rows, input 29.5 MB
+    x = torch.randn(32, 20, 36, 640, device=dev).to(DT); w = (torch.randn(640, 3, 3, 640, device=dev) * 0.02).to(DT)
+    f = lambda: ops.conv2d(x, w)
 elif which == "ff1":
     A = torch.randn(8192, 320, device=dev).to(DT); W = (torch.randn(2560, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.gemm(A, W)

@@ -55,6 +55,12 @@ struct GemmArgs {
     // ups: the conv reads a virtual nearest-2x upsampled image cropped to lim_h x lim_w (= 2*Hin or 2*Hin-1, ...);
     // without ups lim_h/lim_w = Hin/Win. cin64: a 64-wide K tile never straddles two taps (uniform tap per tile).
     int conv, Hin, Win, Cin, Hout, Wout, kh, kw, stride, pad_h, pad_w, dil, ups, lim_h, lim_w, cin64;
+    // kcm (with cin64): the K tiles are walked CHANNEL-BLOCK major, tap minor, instead of in the weight's own (tap, channel) order:
+    // the kh*kw consecutive K tiles of one 64-channel block read the same input rows shifted by the tap, so all but the first of
+    // them hit in L2 (each XCD keeps ~50 KB per resident tile instead of cycling through the whole Cin-wide rows nine times:
+    // FETCH_SIZE of the 64^2 3x3 convs was 2.5x their algorithmic bytes, more on the UNet3D / SDXL maps that exceed the L2).
+    // The weight tile of a step is the walk's (tap, channel block): same products, another fp32 summation order.
+    int kcm;
     int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
     // tile order: 0 = m fastest (neighbouring blocks share a W tile: LLM prefill, W >> A), 1 = n fastest (they share the A tile:
     // the UNet's 8192-row activations against 320..2560 output columns -- with m fastest every column tile re-streamed all of A
@@ -93,6 +99,31 @@ __device__ __forceinline__ uint32_t w_row_byte(const GemmArgs& p, int n) {
     return p.w_tiled ? ((uint32_t)(n >> 6) * nk * 8192u + (uint32_t)(n & 63) * 128u) : (uint32_t)n * (uint32_t)p.K * 2u;
 }
 __device__ __forceinline__ uint32_t w_tile_step(const GemmArgs& p) { return p.w_tiled ? 8192u : (uint32_t)(BK * 2); }
+
+// Walk over the K tiles of an implicit-GEMM conv whose 64-wide K tiles never straddle taps (Cin % 64 == 0): the (channel, tap
+// row, tap column) of the NEXT tile are carried along instead of being re-derived by integer divisions per tile. Order: see
+// GemmArgs::kcm. wtile() = index of the tile in the weight's K order (tap-major, channel-minor).
+struct TapWalk {
+    int c, ky, kx;
+    __device__ __forceinline__ void init(const GemmArgs& p, int kt0) {
+        if (p.kcm) {
+            const int nt = p.kh * p.kw, cb = kt0 / nt, tap = kt0 - cb * nt;
+            c = cb * BK; ky = tap / p.kw; kx = tap - ky * p.kw;
+        } else {
+            const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
+            c = kk0 - tap0 * p.Cin; ky = tap0 / p.kw; kx = tap0 - ky * p.kw;
+        }
+    }
+    __device__ __forceinline__ void next(const GemmArgs& p) {
+        if (p.kcm) {
+            if (++kx == p.kw) { kx = 0; if (++ky == p.kh) { ky = 0; c += BK; } }
+        } else {
+            c += BK;
+            if (c >= p.Cin) { c = 0; if (++kx == p.kw) { kx = 0; ++ky; } }
+        }
+    }
+    __device__ __forceinline__ uint32_t wtile(const GemmArgs& p) const { return (uint32_t)((ky * p.kw + kx) * (p.Cin >> 6) + (c >> 6)); }
+};
 
 // bias / rowbias / activation / residual / scale on 4 consecutive columns of one row, then store
 // EPI selects what is compiled in: 0 = bias / rowbias / residual / scale only, 1 = + activation, 2 = GEGLU (kernel-level).
@@ -525,13 +556,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
     // running tap state of the next K tile to load (CONV with Cin % 64 == 0): see load_tile
-    int run_c = 0, run_ky = 0, run_kx = 0;
-    if (CONV && p.cin64) {
-        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
-        run_c = kk0 - tap0 * p.Cin;
-        run_ky = tap0 / p.kw;
-        run_kx = tap0 - run_ky * p.kw;
-    }
+    TapWalk walk{0, 0, 0};
+    if (CONV && p.cin64) walk.init(p, kt0);
     // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring); branch-free
     auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC]) {
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
@@ -539,6 +565,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         // such loads return zeros, so the K loop below needs no conditionals at all (the compiler then counts the
         // outstanding loads exactly and waits only for the register set it is about to store)
         const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + chunk * 8)) >> 31) | (uint32_t)((kt1 - 1 - kt) >> 31);
+        uint32_t ktw = (uint32_t)kt;           // the weight's K tile of this step
         if (CONV) {
             // tap of this lane's 8 k-elements: uniform per tile when Cin % 64 == 0, per lane otherwise (Cin % 8 == 0
             // keeps a 16-byte chunk inside one tap). Tiles are requested in increasing kt order, so with Cin % 64 == 0 the
@@ -547,10 +574,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             int ky, kx;
             uint32_t cbyte;
             if (p.cin64) {
-                ky = run_ky; kx = run_kx;
-                cbyte = (uint32_t)(run_c + chunk * 8) * 2u;
-                run_c += BK;
-                if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+                ky = walk.ky; kx = walk.kx;
+                cbyte = (uint32_t)(walk.c + chunk * 8) * 2u;
+                ktw = walk.wtile(p);
+                walk.next(p);
             } else {
                 const int kk = kt * BK + chunk * 8;
                 const int tap = kk / p.Cin;
@@ -579,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WC; ++i) {
-            const uint32_t off = (w_base[i] + (uint32_t)kt * w_step) | w_inv[i] | k_inv;
+            const uint32_t off = (w_base[i] + ktw * w_step) | w_inv[i] | k_inv;
             rw[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
         }
     };
@@ -779,21 +806,17 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     // DMA of K tile kt into ring stage `stage` (wave-uniform); tiles >= kt1 / chunks >= K are all-ones offsets -> zeros
     // running tap state of the next K tile to issue (CONV with Cin % 64 == 0; tiles are issued in increasing kt order): the
     // tap row / column / channel are carried along instead of re-derived by two integer divisions per tile
-    int run_c = 0, run_ky = 0, run_kx = 0;
-    if (CONV && p.cin64) {
-        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
-        run_c = kk0 - tap0 * p.Cin;
-        run_ky = tap0 / p.kw;
-        run_kx = tap0 - run_ky * p.kw;
-    }
+    TapWalk walk{0, 0, 0};
+    if (CONV && p.cin64) walk.init(p, kt0);
     auto issue = [&](int kt, int stage) {
         char* sb = smem + stage * STAGE;
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
         const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
-        const int t_c = run_c, t_ky = run_ky, t_kx = run_kx;
+        const int t_c = walk.c, t_ky = walk.ky, t_kx = walk.kx;
+        uint32_t ktw = (uint32_t)kt;           // the weight's K tile of this step
         if (CONV && p.cin64) {
-            run_c += BK;
-            if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+            ktw = walk.wtile(p);
+            walk.next(p);
         }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -826,7 +849,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
         for (int j = 0; j < WJ; ++j) {
             if (W_RAGGED && j == WJ - 1 && wave >= WP % 8) break;
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)w_gch[j] * 8)) >> 31) | t_inv;
-            const uint32_t off = (w_base[j] + (uint32_t)kt * w_step) | w_inv[j] | k_inv;
+            const uint32_t off = (w_base[j] + ktw * w_step) | w_inv[j] | k_inv;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (BM / 8 + j * 8 + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -967,12 +990,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 
     // running tap state of the next K tile of each A half (CONV with Cin % 64 == 0): each half's shares are issued in increasing
     // kt order, so tap row / column / channel are carried along instead of re-derived by two integer divisions per share
-    int run_c[2] = {0, 0}, run_ky[2] = {0, 0}, run_kx[2] = {0, 0};
+    TapWalk wa[2] = {{0, 0, 0}, {0, 0, 0}}, ww[2] = {{0, 0, 0}, {0, 0, 0}};       // per A half / W half (each is issued once per K tile, in order)
     if (CONV && p.cin64) {
-        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
-        run_c[0] = run_c[1] = kk0 - tap0 * p.Cin;
-        run_ky[0] = run_ky[1] = tap0 / p.kw;
-        run_kx[0] = run_kx[1] = tap0 - run_ky[0] * p.kw;
+        wa[0].init(p, kt0);
+        wa[1] = wa[0]; ww[0] = wa[0]; ww[1] = wa[0];
     }
     // one half-tile share of this wave: kind 0 = A, 1 = W; tiles >= kt1 and chunks >= K are all-ones offsets (DMA writes zeros)
     auto issue = [&](int kind, int h, int kt, int buf) {
@@ -980,10 +1001,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
         const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
         int t_c = 0, t_ky = 0, t_kx = 0;
-        if (CONV && kind == 0 && p.cin64) {
-            t_c = run_c[h]; t_ky = run_ky[h]; t_kx = run_kx[h];
-            run_c[h] += BK;
-            if (run_c[h] >= p.Cin) { run_c[h] = 0; if (++run_kx[h] == p.kw) { run_kx[h] = 0; ++run_ky[h]; } }
+        uint32_t ktw = (uint32_t)kt;           // the weight's K tile of this step
+        if (CONV && p.cin64) {
+            if (kind == 0) {
+                t_c = wa[h].c; t_ky = wa[h].ky; t_kx = wa[h].kx;
+                wa[h].next(p);
+            } else {
+                ktw = ww[h].wtile(p);
+                ww[h].next(p);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1013,7 +1039,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             } else {
-                off = (w_base[h][j] + (uint32_t)kt * w_step) | w_inv[h][j] | k_inv;
+                off = (w_base[h][j] + ktw * w_step) | w_inv[h][j] | k_inv;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             }
         }
@@ -1181,19 +1207,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_total, kt0 + p.kt_per_split);
 
-    int run_c = 0, run_ky = 0, run_kx = 0;            // tap state of the next K tile (CONV, Cin % 64 == 0): tiles are issued in order
-    if (CONV && p.cin64) {
-        const int kk0 = kt0 * BK, tap0 = kk0 / p.Cin;
-        run_c = kk0 - tap0 * p.Cin;
-        run_ky = tap0 / p.kw;
-        run_kx = tap0 - run_ky * p.kw;
-    }
+    TapWalk walk{0, 0, 0};                            // tap state of the next K tile (CONV, Cin % 64 == 0): tiles are issued in order
+    if (CONV && p.cin64) walk.init(p, kt0);
     int t_c = 0, t_ky = 0, t_kx = 0;                  // tap of the K tile currently being issued (set by begin_tile)
+    uint32_t t_ktw = 0;                               // ... and its weight K tile (CONV, Cin % 64 == 0)
     auto begin_tile = [&]() {
-        t_c = run_c; t_ky = run_ky; t_kx = run_kx;
+        t_c = walk.c; t_ky = walk.ky; t_kx = walk.kx;
         if (CONV && p.cin64) {
-            run_c += BK;
-            if (run_c >= p.Cin) { run_c = 0; if (++run_kx == p.kw) { run_kx = 0; ++run_ky; } }
+            t_ktw = walk.wtile(p);
+            walk.next(p);
         }
     };
     // this wave's share (2 DMA instructions) of one half-tile of K tile kt: part 0 / 1 = A rows 0-127 / 128-255, part 2 = W
@@ -1230,7 +1252,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             } else {
-                off = (w_base[j] + (uint32_t)kt * w_step) | w_inv[j] | k_inv;
+                off = (w_base[j] + ((CONV && p.cin64) ? t_ktw : (uint32_t)kt) * w_step) | w_inv[j] | k_inv;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
             }
         }
@@ -1787,6 +1809,8 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
     a.act = act; a.act_param = act_param; a.out_scale = out_scale; a.ws = (float*)ws;
     a.conv = 1; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.kh = kh; a.kw = kw; a.stride = stride;
     a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil; a.ups = ups; a.lim_h = Hs; a.lim_w = Ws; a.cin64 = Cin % 64 == 0;
+    static const int kcm_env = getenv("SPIDER_CONV_KCM") ? atoi(getenv("SPIDER_CONV_KCM")) : 1;
+    a.kcm = (kcm_env && a.cin64 && kh * kw > 1) ? 1 : 0;
     SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
     a.w_tiled = w_tiled ? 1 : 0;
