@@ -434,15 +434,17 @@ def measure_roofline(resp, device):
 
 
 def _unet_pmc_traffic(kernel_prefix):
-    """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r02_pmc_unet_hbm.json:
+    """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r0N_pmc_unet_hbm.json:
     averages over every launch of that kernel in the UNet step, not only the roofline shape -- stated in `traffic_source`)."""
-    pm = os.path.join(ROOT, "profiles", "r02_pmc_unet_hbm.json")
-    try:
-        for k in json.load(open(pm))["kernels"]:
-            if k["kernel"].startswith(kernel_prefix):
-                return k["hbm_read_bytes"] + k["hbm_write_bytes"], f"profiles/r02_pmc_unet_hbm.json (average over the {k['launches']} launches of this kernel in the profiled UNet steps)"
-    except Exception:
-        pass
+    for tag in ("r03", "r02"):          # newest committed counter pass first
+        pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_unet_hbm.json")
+        try:
+            for k in json.load(open(pm))["kernels"]:
+                if k["kernel"].startswith(kernel_prefix):
+                    return (k["hbm_read_bytes"] + k["hbm_write_bytes"],
+                            f"profiles/{tag}_pmc_unet_hbm.json (average over the {k['launches']} launches of this kernel in the profiled UNet steps)")
+        except Exception:
+            pass
     return None, None
 
 
