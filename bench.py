@@ -136,8 +136,9 @@ class Responder:
         self.clip_ids_u = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
         self.clip_ids_c = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
         self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(DIFF_DT)
-        self._streams, self._pending, self.overlap_ms = None, None, None
-        self._captured = False
+        self._streams, self.overlap_ms = None, None
+        self._pending = {}            # batch size -> (ids on device, ids on host) of the response whose decoder pass comes next
+        self._captured = set()        # batch sizes whose graphs exist
 
     def includes(self):
         inc = ["llm_prefill", "llm_decode", "routing", "unet_denoise_loop"]
@@ -198,14 +199,14 @@ class Responder:
         decoder pass and returns the finished response k; the LLM output that response k+1 needs was produced one step earlier.
         `--schedule serial` runs the two passes of the same response back to back on one stream."""
         B = batch or self.args.batch
-        if self.args.schedule == "serial" or B != self.args.batch:
+        if self.args.schedule == "serial":
             return self.respond_serial(B)
-        if not self._captured:
+        if B not in self._captured:
             # the very first response runs start to finish on one stream and one host thread: every engine captures its hipGraphs
             # there (stream capture must not see another thread's allocations), the two-stream pipeline starts with the second call
-            self._captured = True
+            self._captured.add(B)
             first = self.respond_serial(B)
-            self._pending = self._llm_pass(B)         # ... already primed with the next response's LLM pass (untimed warm-up work)
+            self._pending[B] = self._llm_pass(B)      # ... already primed with the next response's LLM pass (untimed warm-up work)
             return first
         dev = self.dev
         if self._streams is None:
@@ -240,11 +241,11 @@ class Responder:
                 self._streams = (_masked(os.environ["SPIDER_BENCH_CUMASK_L"]), self._streams[1])
         sL, sU = self._streams
         cur = torch.cuda.current_stream(dev)
-        if self._pending is None:                   # pipeline empty (first step): this response's own LLM pass comes first
+        if B not in self._pending:                  # pipeline empty: this response's own LLM pass comes first
             sL.wait_stream(cur)
             with torch.cuda.stream(sL):
-                self._pending = self._llm_pass(B)
-        gen, gen_host = self._pending
+                self._pending[B] = self._llm_pass(B)
+        gen, gen_host = self._pending[B]
         sU.wait_stream(cur)
         sL.wait_stream(cur)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -272,7 +273,7 @@ class Responder:
             _dec()
         with torch.cuda.stream(sL):                 # LLM pass of the NEXT response, concurrently (blocks the host at its end)
             ev[2].record(sL)
-            self._pending = self._llm_pass(B)
+            self._pending[B] = self._llm_pass(B)
             ev[3].record(sL)
         if th is not None:
             th.join()
@@ -967,15 +968,19 @@ def text_image_extras(args, resp, device):
         tb = min(a.throughput_batch, 8)
         _, tok8, frac8 = llm_phase(tb)
         extra["llm_decode_batched"] = {"rows": tb, "tokens_per_s": round(tok8, 1), "hbm_frac": round(frac8, 4)}
+        resp.respond(tb)                           # serial + pipeline primed (graph captures)
         resp.respond(tb)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        resp.respond(tb)
+        for _ in range(2):
+            resp.respond(tb)
         torch.cuda.synchronize(device)
-        dtb = time.perf_counter() - t1
+        dtb = (time.perf_counter() - t1) / 2
         extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
-                                       "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU); "
-                                               "not the headline value"}
+                                       "schedule": a.schedule,
+                                       "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU), same "
+                                               "schedule as the headline (a step = one batched LLM pass + one batched decoder pass); not the "
+                                               "headline value"}
     extra["roofline_prefill_gemm"] = measure_prefill_gemm_roofline(device, resp.llm.cfg, a.prompt_len)
     extra["roofline_unet_conv"] = measure_mfma_roofline(device)
     extra["roofline_unet_attention"] = measure_attention_roofline(device)
