@@ -61,6 +61,10 @@ struct GemmArgs {
     // FETCH_SIZE of the 64^2 3x3 convs was 2.5x their algorithmic bytes, more on the UNet3D / SDXL maps that exceed the L2).
     // The weight tile of a step is the walk's (tap, channel block): same products, another fp32 summation order.
     int kcm;
+    // hbits (with cin64, no upsample, kh*kw <= 32): each A piece carries a bitmask "tap t reads outside the image for this
+    // pixel", built once per block, so the per-K-tile address of a DMA piece is base + (wave-uniform tap offset) | masks --
+    // 5 vector instructions instead of ~25 in the issue slot between two barriers of the LDS-DMA kernels.
+    int hbits;
     int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
     // tile order: 0 = m fastest (neighbouring blocks share a W tile: LLM prefill, W >> A), 1 = n fastest (they share the A tile:
     // the UNet's 8192-row activations against 320..2560 output columns -- with m fastest every column tile re-streamed all of A
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // divergent branch by the compiler, which again hides the loads from its vmcnt bookkeeping.
     uint32_t a_base[AC], a_inv[AC];   // byte offset of the row (linear) / image (conv); a_inv = ~0 for rows >= M
     uint32_t a_lin[AC];
+    uint32_t a_hb[AC];                                // CONV, p.hbits: bit t = tap t of this row's pixel lies outside the image
     int a_oy[AC], a_ox[AC];
     uint32_t w_base[WC], w_inv[WC];
 #pragma unroll
@@ -527,7 +532,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             a_ox[i] = (rem % p.Wout) * p.stride - p.pad_w;
             a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
             a_lin[i] = a_base[i] + (uint32_t)(a_oy[i] * p.Win + a_ox[i]) * (uint32_t)p.Cin * 2u;   // + tap offset = the tap's pixel (no upsample)
+            a_hb[i] = 0u;
+            if (p.hbits) {
+                a_lin[i] += chunk * 16u;                  // this thread's 16-byte chunk of the 64-channel block
+                {
+                    uint32_t hb = 0u;
+                    for (int ky = 0; ky < p.kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx) {
+                            const int iy = a_oy[i] + ky * p.dil, ix = a_ox[i] + kx * p.dil;
+                            const uint32_t out = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31) & 1u;
+                            hb |= out << (ky * p.kw + kx);
+                        }
+                    a_hb[i] = hb;
+                }
+            }
         } else {
+            a_hb[i] = 0u;
             a_base[i] = (uint32_t)mc * (uint32_t)p.lda * 2u + chunk * 16u;
             a_oy[i] = a_ox[i] = 0;
             a_lin[i] = 0;
@@ -587,6 +607,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             const int hlim = p.lim_h, wlim = p.lim_w;
             const int dy = ky * p.dil, dx = kx * p.dil;                                   // wave-uniform tap displacement
             const uint32_t tap_off = (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
+            if (p.hbits) {     // uniform tap offset + per-row masks (GemmArgs::hbits); cbyte's per-thread chunk is already in a_lin
+                const int tap = ky * p.kw + kx;
+                const uint32_t toff = tap_off - chunk * 16u;
+#pragma unroll
+                for (int i = 0; i < AC; ++i) {
+                    const uint32_t halo = 0u - ((a_hb[i] >> tap) & 1u);
+                    const uint32_t off = (a_lin[i] + toff) | halo | a_inv[i] | k_inv;
+                    ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
                 const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
@@ -765,6 +795,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     // this lane's slot in a piece: row prow of 8, 16-byte slot `slot` of 8; the global chunk it fetches is slot ^ swizzle(row)
     const int prow = lane >> 3, slot = lane & 7;
     uint32_t a_base[AJ], a_inv[AJ], a_gch[AJ], a_lin[AJ];
+    uint32_t a_hb[AJ];                                // CONV, p.hbits: bit t = tap t of this piece's pixel lies outside the image
     int a_oy[AJ], a_ox[AJ];
     uint32_t w_base[WJ], w_inv[WJ], w_gch[WJ];
 #pragma unroll
@@ -782,7 +813,22 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
             a_ox[j] = (rem % p.Wout) * p.stride - p.pad_w;
             a_base[j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
             a_lin[j] = a_base[j] + (uint32_t)(a_oy[j] * p.Win + a_ox[j]) * (uint32_t)p.Cin * 2u;
+            a_hb[j] = 0u;
+            if (p.hbits) {
+                a_lin[j] += a_gch[j] * 16u;               // this lane's 16-byte chunk of the 64-channel block
+                {
+                    uint32_t hb = 0u;
+                    for (int ky = 0; ky < p.kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx) {
+                            const int iy = a_oy[j] + ky * p.dil, ix = a_ox[j] + kx * p.dil;
+                            const uint32_t out = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31) & 1u;
+                            hb |= out << (ky * p.kw + kx);
+                        }
+                    a_hb[j] = hb;
+                }
+            }
         } else {
+            a_hb[j] = 0u;
             a_base[j] = (uint32_t)mc * (uint32_t)p.lda * 2u + a_gch[j] * 16u;
             a_oy[j] = a_ox[j] = 0;
             a_lin[j] = 0;
@@ -818,8 +864,20 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
             ktw = walk.wtile(p);
             walk.next(p);
         }
+        const bool fast_a = CONV && p.hbits;   // wave-uniform tap offset + per-piece masks (GemmArgs::hbits)
+        if (fast_a) {
+            const int tap = t_ky * p.kw + t_kx;
+            const uint32_t tap_off = (uint32_t)((t_ky * p.Win + t_kx) * p.dil) * (uint32_t)p.Cin * 2u + (uint32_t)t_c * 2u;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const uint32_t halo = 0u - ((a_hb[j] >> tap) & 1u);
+                const uint32_t off = (a_lin[j] + tap_off) | halo | a_inv[j] | t_inv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
+            if (fast_a) break;
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)a_gch[j] * 8)) >> 31) | t_inv;
             uint32_t off;
             if (CONV) {
@@ -946,6 +1004,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     // a DMA piece = 8 rows x 128 B (one wave instruction); a half-tile = 16 pieces, this wave issues pieces wave and 8 + wave
     const int prow = lane >> 3, slot = lane & 7;
     uint32_t a_base[2][2], a_inv[2][2], a_lin[2][2], w_base[2][2], w_inv[2][2], gch[2];
+    uint32_t a_hb[2][2] = {{0u, 0u}, {0u, 0u}};      // CONV, p.hbits: bit t = tap t of this piece's pixel lies outside the image
     int a_oy[2][2], a_ox[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -964,6 +1023,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 a_ox[h][j] = (rem % p.Wout) * p.stride - p.pad_w;
                 a_base[h][j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
                 a_lin[h][j] = a_base[h][j] + (uint32_t)(a_oy[h][j] * p.Win + a_ox[h][j]) * (uint32_t)p.Cin * 2u;
+                if (p.hbits) {
+                    a_lin[h][j] += gch[j] * 16u;         // this lane's 16-byte chunk of the 64-channel block
+                    uint32_t hb = 0u;
+                    for (int ky = 0; ky < p.kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx) {
+                            const int iy = a_oy[h][j] + ky * p.dil, ix = a_ox[h][j] + kx * p.dil;
+                            const uint32_t out = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31) & 1u;
+                            hb |= out << (ky * p.kw + kx);
+                        }
+                    a_hb[h][j] = hb;
+                }
             } else {
                 a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
                 a_oy[h][j] = a_ox[h][j] = 0;
@@ -1010,6 +1080,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
                 ktw = ww[h].wtile(p);
                 ww[h].next(p);
             }
+        }
+        if (CONV && kind == 0 && p.hbits) {      // wave-uniform tap offset + per-piece masks (GemmArgs::hbits)
+            const int tap = t_ky * p.kw + t_kx;
+            const uint32_t tap_off = (uint32_t)((t_ky * p.Win + t_kx) * p.dil) * (uint32_t)p.Cin * 2u + (uint32_t)t_c * 2u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t halo = 0u - ((a_hb[h][j] >> tap) & 1u);
+                const uint32_t off = (a_lin[h][j] + tap_off) | halo | a_inv[h][j] | t_inv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1632,7 +1713,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     // rounds of one block per CU (two for the 128^2 register-staged tiles), so the choice is made by a cost model instead of the
     // size classes above:  time = ceil(tiles / resident blocks) x (t0 + nk x tk),  t0 = prologue + epilogue of a block, tk = one
     // 64-deep K tile. Constants fitted on MI355X (scripts/bench_gemm.py, SHAPES=v3d / sdxl, 16 shapes x 4 kernels, within ~10 %):
-    // 256^2 8.4 + 1.40 nk (1.67 for convs), 256x128 7.0 + 0.78 nk, 128x160 LDS-DMA 5.5 + 0.68 nk, 128^2 5.7 + 1.0 nk at two blocks
+    // 256^2 8.4 + 1.40 nk (convs 1.47; 1.67 on the general address path), 256x128 7.0 + 0.78 nk, 128x160 LDS-DMA 5.5 + 0.68 nk, 128^2 5.7 + 1.0 nk at two blocks
     // per CU; the GEGLU epilogue adds ~2.2 us per block, the LayerNorm-folded form on the 256^2 kernel its row-statistics pass.
     // What the classes got wrong there: 270 tiles of 256^2 = two rounds at 53 % (23040 x 640 convs: 318 vs 201 us), and the K = 320
     // linears kept off the 256^2 kernel by its nk >= 8 rule (92160 x 960 x 320: 123 vs 93 us; GEGLU ff1 390 vs ~270).
@@ -1644,7 +1725,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         const float epi = a.geglu ? 2.2f : 0.f;
         const float ln_pass = a.ln_colsum ? 3.f + (float)((double)a.M * a.K * 2.0 / 5.0e6) : 0.f;   // ln_row_stats_kernel: one read of A
         struct Cand { int bm, bn, slots; float t0, tk, pre; bool ok; };
-        const Cand cand[4] = {{256, 256, 256, 8.4f + epi, a.conv ? 1.67f : 1.40f, ln_pass, p8_ok},
+        const Cand cand[4] = {{256, 256, 256, 8.4f + epi, a.conv ? (a.hbits ? 1.47f : 1.67f) : 1.40f, ln_pass, p8_ok},
                               {256, 128, 256, 7.0f, 0.78f, 0.f, p8_env && p8h_env && !a.conv && !fused},
                               {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
                               {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true}};
@@ -1811,6 +1892,8 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
     a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil; a.ups = ups; a.lim_h = Hs; a.lim_w = Ws; a.cin64 = Cin % 64 == 0;
     static const int kcm_env = getenv("SPIDER_CONV_KCM") ? atoi(getenv("SPIDER_CONV_KCM")) : 1;
     a.kcm = (kcm_env && a.cin64 && kh * kw > 1) ? 1 : 0;
+    static const int hb_env = getenv("SPIDER_CONV_HBITS") ? atoi(getenv("SPIDER_CONV_HBITS")) : 1;
+    a.hbits = (hb_env && a.cin64 && !ups && kh * kw <= 32) ? 1 : 0;
     SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
     a.w_tiled = w_tiled ? 1 : 0;
