@@ -21,7 +21,7 @@ if ks:
     rows = list(csv.DictReader(open(ks)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(f"{P}/{tag}_bench_kernel_stats_top.txt", "w") as f:
-        f.write(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --headline-only (two-stream schedule requested; NOTE: rocprofv3 kernel tracing serialises the two streams -- the step takes the serial sum under the profiler, see r03_bench_under_rocprof.json -- so these are every kernel's durations ALONE on the chip, as in the serial file) : total kernel time {tot / 1e6:.1f} ms\n")
+        f.write(f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --headline-only (two-stream schedule, the two passes enqueued from two host threads: the kernels of both streams overlap under the profiler too -- step time in r03_bench_under_rocprof.json; averages include the serial first response of the warm-up; compare with the serial file for every kernel ALONE on the chip) : total kernel time {tot / 1e6:.1f} ms\n")
         for r in rows[:25]:
             f.write(f"{short(r['Name']):80s} calls {int(float(r['Calls'])):7d} avg_us {float(r['AverageNs']) / 1e3:9.1f} "
                     f"total_ms {float(r['TotalDurationNs']) / 1e6:9.2f} {float(r['Percentage']):5.1f}%\n")
