@@ -37,6 +37,8 @@ class SpiderDecoder:
         # evaluation; the kernels' 32-bit operand offsets allow < 2 GiB per activation tensor, i.e. up to 5 captions at 16 frames)
         self.video_batch = 4
         self.stage_ms: Dict[str, float] = {}     # host wall time per modality of the batched decoders (reset by the caller)
+        self.concurrent_decoders = True          # generate_batch: the video decoder on its own stream / host thread (after the first call)
+        self._batch_warm = False
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -75,10 +77,12 @@ class SpiderDecoder:
         if pipe is None:
             print(f"no input text prompt for {what} generation. or no {what} generation model.")
             return None
-        if self.get_prompt_embed_for_diffusion:   # text -> prompt-embeds control path (spider_decoder.py:104-112)
-            embeds = pipe(samples["llm_text_res"], return_prompts_only=True).detach()
-            return pipe(prompt_embeds=embeds, **call_kwargs)
-        return pipe(prompt=samples["llm_text_res"], **call_kwargs)
+        from . import ops
+        with ops.workspace_scope(modality.lower()):   # every decoder keeps a split-K workspace (and graphs captured with it) of its own
+            if self.get_prompt_embed_for_diffusion:   # text -> prompt-embeds control path (spider_decoder.py:104-112)
+                embeds = pipe(samples["llm_text_res"], return_prompts_only=True).detach()
+                return pipe(prompt_embeds=embeds, **call_kwargs)
+            return pipe(prompt=samples["llm_text_res"], **call_kwargs)
 
     # ------------------------------------------------------------------ decoder side (spider_decoder.py:100-276)
     def decode_image(self, samples, guidance_scale=7.5, num_inference_steps=40):
@@ -132,12 +136,14 @@ class SpiderDecoder:
             print(f"no input text prompt for {what} generation. or no {what} generation model.")
             return None
         import time
+        from . import ops
         t0 = time.perf_counter()
-        if self.get_prompt_embed_for_diffusion:
-            embeds = pipe(list(captions), return_prompts_only=True).detach()
-            out = pipe(prompt_embeds=embeds, **call_kwargs)
-        else:
-            out = pipe(prompt=list(captions), **call_kwargs)
+        with ops.workspace_scope(modality.lower()):   # own workspace per decoder: decoders may run on different streams at once
+            if self.get_prompt_embed_for_diffusion:
+                embeds = pipe(list(captions), return_prompts_only=True).detach()
+                out = pipe(prompt_embeds=embeds, **call_kwargs)
+            else:
+                out = pipe(prompt=list(captions), **call_kwargs)
         # host wall time of the pipeline call (every pipeline ends with a device -> host copy of its output): read by bench.py
         self.stage_ms[modality] = self.stage_ms.get(modality, 0.0) + (time.perf_counter() - t0) * 1e3
         return out
@@ -179,7 +185,13 @@ class SpiderDecoder:
             outputs = [routing.new_outputs() for _ in samples_list]
         assert len(outputs) == len(samples_list)
         batch = dict(IMAGE=self.decode_image_batch, VIDEO=self.decode_video_batch, AUDIO=self.decode_audio_batch)
-        return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch)
+        # The video decoder (by far the longest: 40 UNet3D evaluations per caption chunk) runs on a HIP stream and host thread of
+        # its own beside the image and audio decoders -- independent pipelines, each with its own workspace scope. The first call
+        # stays on one thread: that is where the pipelines capture their hipGraphs (stream capture must not see another thread's
+        # allocations).
+        side = ("VIDEO",) if (self.concurrent_decoders and self._batch_warm and torch.cuda.is_available()) else ()
+        self._batch_warm = True
+        return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch, side=side, device=self.device)
 
 
 class SpiderDecoderInfer:

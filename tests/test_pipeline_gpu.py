@@ -127,3 +127,10 @@ def test_spider_decoder_generate_batch_runs_each_decoder_once(dev):
         assert len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
     # different captions -> different samples (the batch rows are not copies of one another)
     assert not np.array_equal(np.asarray(outs[0][1]["IMAGE"][0]), np.asarray(outs[1][1]["IMAGE"][0]))
+    # second call: the video decoder now runs on its own stream / host thread beside the other two (the first call captured the graphs)
+    outs2 = dec.generate_batch([{"llm_text_all": [t]} for t in texts])
+    assert calls == dict(IMAGE=2, AUDIO=2, VIDEO=2) and len(outs2) == 3
+    for i, (a, p, pt) in enumerate(outs2):
+        assert pt["VIDEO"] == [f"sea {i}"] and len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
+        assert len(p["IMAGE"]) == 1 and p["IMAGE"][0].size == (64, 64) and p["AUDIO"][0].shape == (80000,) and np.isfinite(p["AUDIO"][0]).all()
+        assert all(np.isfinite(np.asarray(f, dtype=np.float32)).all() for f in p["VIDEO"][0])
