@@ -60,7 +60,7 @@ def route(samples: dict, answers: list, predictions: dict, predictions_text: dic
 
 
 def route_batch(samples_list: List[dict], outputs: List[tuple], decode_modality: Dict[str, Optional[Callable]],
-                batch_decoders: Dict[str, Callable], side=(), device=None):
+                batch_decoders: Dict[str, Callable]):
     """The routing loop of SpiderDecoder.generate for SEVERAL independent samples at once (the batched
     entry point offered next to the reference's one-sample contract). Result = calling `route` once per sample with that sample's
     own containers -- same captions in the same order, same None-skip rule -- except that every caption of a diffusion modality
@@ -88,37 +88,8 @@ def route_batch(samples_list: List[dict], outputs: List[tuple], decode_modality:
                         predictions[modality]["label_names"].append(det["outputs_label_names"][0])
                         predictions[modality]["scores"].append(det["outputs_scores"][0])
         answers.append(output_texts)
-    # `side`: modalities whose batched decoder runs on a host thread and HIP stream of its own while the others run here (the
-    # decoders are independent; results land in per-modality containers, so the order of completion does not show)
-    order = [m for m in decode_modality.keys() if m in jobs]       # dict-key order, as the single-sample loop visits them
-    results, threads = {}, []
-    for modality in [m for m in order if m in side]:
-        import threading
-        import torch
-        cur = torch.cuda.current_stream(device)
-        st = torch.cuda.Stream(device=device)
-        st.wait_stream(cur)
-
-        def run(m=modality, st=st):
-            try:
-                if device is not None:
-                    torch.cuda.set_device(device)
-                with torch.cuda.stream(st):
-                    results[m] = batch_decoders[m]([c for _, c in jobs[m]])
-                st.synchronize()
-            except BaseException as e:       # re-raised on the calling thread
-                results[m] = e
-        t = threading.Thread(target=run, name=f"decoder-{modality}")
-        t.start()
-        threads.append(t)
-    for modality in [m for m in order if m not in side]:
-        results[modality] = batch_decoders[modality]([c for _, c in jobs[modality]])
-    for t in threads:
-        t.join()
-    for modality in order:
-        res = results[modality]
-        if isinstance(res, BaseException):
-            raise res
+    for modality in [m for m in decode_modality.keys() if m in jobs]:       # dict-key order, as the single-sample loop visits them
+        res = batch_decoders[modality]([c for _, c in jobs[modality]])
         if res is None:
             continue
         assert len(res) == len(jobs[modality]), f"{modality}: the batched decoder must return one entry per caption"

@@ -37,8 +37,6 @@ class SpiderDecoder:
         # evaluation; the kernels' 32-bit operand offsets allow < 2 GiB per activation tensor, i.e. up to 5 captions at 16 frames)
         self.video_batch = 4
         self.stage_ms: Dict[str, float] = {}     # host wall time per modality of the batched decoders (reset by the caller)
-        self.concurrent_decoders = True          # generate_batch: the video decoder on its own stream / host thread (after the first call)
-        self._batch_warm = False
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -185,13 +183,7 @@ class SpiderDecoder:
             outputs = [routing.new_outputs() for _ in samples_list]
         assert len(outputs) == len(samples_list)
         batch = dict(IMAGE=self.decode_image_batch, VIDEO=self.decode_video_batch, AUDIO=self.decode_audio_batch)
-        # The video decoder (by far the longest: 40 UNet3D evaluations per caption chunk) runs on a HIP stream and host thread of
-        # its own beside the image and audio decoders -- independent pipelines, each with its own workspace scope. The first call
-        # stays on one thread: that is where the pipelines capture their hipGraphs (stream capture must not see another thread's
-        # allocations).
-        side = ("VIDEO",) if (self.concurrent_decoders and self._batch_warm and torch.cuda.is_available()) else ()
-        self._batch_warm = True
-        return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch, side=side, device=self.device)
+        return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch)
 
 
 class SpiderDecoderInfer:

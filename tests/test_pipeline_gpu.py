@@ -127,7 +127,7 @@ def test_spider_decoder_generate_batch_runs_each_decoder_once(dev):
         assert len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
     # different captions -> different samples (the batch rows are not copies of one another)
     assert not np.array_equal(np.asarray(outs[0][1]["IMAGE"][0]), np.asarray(outs[1][1]["IMAGE"][0]))
-    # second call: the video decoder now runs on its own stream / host thread beside the other two (the first call captured the graphs)
+    # second call: the pipelines replay the graphs the first call captured
     outs2 = dec.generate_batch([{"llm_text_all": [t]} for t in texts])
     assert calls == dict(IMAGE=2, AUDIO=2, VIDEO=2) and len(outs2) == 3
     for i, (a, p, pt) in enumerate(outs2):
