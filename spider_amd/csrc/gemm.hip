@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
 
     const int prow = lane >> 3, slot = lane & 7;
     uint32_t a_base[2][2], a_inv[2][2], a_lin[2][2], w_base[2], w_inv[2], gch[2];
+    uint32_t a_hb[2][2];                              // CONV, p.hbits: bit t = tap t of this piece's pixel lies outside the image
     int a_oy[2][2], a_ox[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1272,7 +1273,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
                 a_ox[h][j] = (rem % p.Wout) * p.stride - p.pad_w;
                 a_base[h][j] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
                 a_lin[h][j] = a_base[h][j] + (uint32_t)(a_oy[h][j] * p.Win + a_ox[h][j]) * (uint32_t)p.Cin * 2u;
+                a_hb[h][j] = 0u;
+                if (p.hbits) {
+                    a_lin[h][j] += gch[j] * 16u;         // this lane's 16-byte chunk of the 64-channel block
+                    uint32_t hb = 0u;
+                    for (int ky = 0; ky < p.kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx) {
+                            const int iy = a_oy[h][j] + ky * p.dil, ix = a_ox[h][j] + kx * p.dil;
+                            const uint32_t out = (uint32_t)((iy | ix | (p.lim_h - 1 - iy) | (p.lim_w - 1 - ix)) >> 31) & 1u;
+                            hb |= out << (ky * p.kw + kx);
+                        }
+                    a_hb[h][j] = hb;
+                }
             } else {
+                a_hb[h][j] = 0u;
                 a_base[h][j] = (uint32_t)mc * (uint32_t)p.lda * 2u + gch[j] * 16u;
                 a_oy[h][j] = a_ox[h][j] = 0;
                 a_lin[h][j] = 0;
@@ -1304,6 +1318,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
         char* sb = smem + stg * KT_BYTES + part * HT;
         const uint32_t kbyte = (uint32_t)kt * (BK * 2);
         const uint32_t t_inv = (uint32_t)((kt1 - 1 - kt) >> 31);
+        if (CONV && part < 2 && p.hbits) {       // wave-uniform tap offset + per-piece masks (GemmArgs::hbits)
+            const int tap = t_ky * p.kw + t_kx;
+            const uint32_t tap_off = (uint32_t)((t_ky * p.Win + t_kx) * p.dil) * (uint32_t)p.Cin * 2u + (uint32_t)t_c * 2u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t halo = 0u - ((a_hb[part][j] >> tap) & 1u);
+                const uint32_t off = (a_lin[part][j] + tap_off) | halo | a_inv[part][j] | t_inv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + (j * 8 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t k_inv = (uint32_t)((p.K - 1 - (kt * BK + (int)gch[j] * 8)) >> 31) | t_inv;
@@ -1726,7 +1751,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         const float ln_pass = a.ln_colsum ? 3.f + (float)((double)a.M * a.K * 2.0 / 5.0e6) : 0.f;   // ln_row_stats_kernel: one read of A
         struct Cand { int bm, bn, slots; float t0, tk, pre; bool ok; };
         const Cand cand[4] = {{256, 256, 256, 8.4f + epi, a.conv ? (a.hbits ? 1.47f : 1.67f) : 1.40f, ln_pass, p8_ok},
-                              {256, 128, 256, 7.0f, 0.78f, 0.f, p8_env && p8h_env && !a.conv && !fused},
+                              {256, 128, 256, 7.0f, a.conv ? 0.98f : 0.78f, 0.f, p8_env && p8h_env && !fused && (!a.conv || a.hbits)},
                               {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
                               {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true}};
         int best = -1;
