@@ -202,6 +202,18 @@ class UNetEngine:
         self._graph_key = None
         self.kv: Dict[str, torch.Tensor] = {}
 
+    # ------------------------------------------------------------------ diffusers-style processor registry (attn_processors.py)
+    @property
+    def attn_processors(self):
+        """names -> installed processor (None = native kernels), as `UNet2DConditionModel.attn_processors` (Comic_Generation.py:353)"""
+        from . import attn_processors as ap
+        return ap.attn_processors(self)
+
+    def set_attn_processor(self, processor) -> None:
+        """`UNet2DConditionModel.set_attn_processor(dict | processor)` (Comic_Generation.py:371); see attn_processors.py for the scope"""
+        from . import attn_processors as ap
+        ap.set_attn_processor(self, processor)
+
     def _heads_of(self, layer: str) -> int:
         """attention heads of the transformer block `layer` (diffusers: attention_head_dim per block of the config)"""
         cfg = self.cfg
