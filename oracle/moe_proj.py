@@ -138,3 +138,81 @@ def capture_spans(targets: Sequence[int], begin_id: int, end_id: int, n_modality
 def blend(projected: torch.Tensor, condition_embeds: torch.Tensor, hidden_embeds_scale: float = 0.1) -> torch.Tensor:
     """spider.py:420,432,444: hidden_embeds_scale * proj + (1 - hidden_embeds_scale) * text-encoder embeds."""
     return hidden_embeds_scale * projected + (1 - hidden_embeds_scale) * condition_embeds
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# TextFcLayer, mode 'qformer' (spider/models/layers.py:30-44 init_Qformer, :76-98 constructor, :125-139 forward): fc to 768,
+# then the BLIP-2 style Q-Former of spider/models/Qformer.py driven by learned query tokens ONLY (no text branch: the constructor
+# deletes the word / position embeddings and every layer's text feed-forward), then Linear(768, out_dim).
+#   BertEmbeddings.forward with query_embeds only (Qformer.py:78-108):  h = LayerNorm(query_tokens)
+#   BertLayer.forward with query_length = Q (Qformer.py:402-476), for each layer (cross_attention_freq = 1: every layer):
+#       h = LN(dense(SelfAttn(h)) + h)                         BertSelfAttention :169-275 (scores / sqrt(d), softmax), BertSelfOutput :285-289
+#       h = LN(dense(CrossAttn(h, x)) + h)                     keys / values from the fc output (encoder_width = 768); all-ones mask
+#       h = LN(dense(gelu(dense(h))) + h)                      intermediate_query / output_query :349-375,479-484 (hidden_act gelu)
+# PINNED: tests/golden/make_golden.py::gen_qformer runs the reference's own TextFcLayer (layers.py) and Q-Former classes
+# (Qformer.py) on seeded inputs (textfc_qformer_ref.npz); only `init_Qformer`'s from_pretrained of a local bert-base-uncased
+# directory is replaced by a BertConfig of the same fields. Weights are regenerated from the seed on both sides (10 M parameters).
+# ----------------------------------------------------------------------------------------------------------------------
+QF_HIDDEN, QF_HEADS, QF_LAYERS, QF_EPS = 768, 12, 2, 1e-12      # bert-base-uncased fields + init_Qformer(num_hidden_layers=2)
+
+
+def qformer_param_shapes(in_dim: int, out_dim: int, n_query: int, inter: int = 3072, max_pos: int = 512) -> Dict[str, tuple]:
+    """state-dict keys of the reference module after its constructor has pruned the text branch (layers.py:84-90)"""
+    H = QF_HIDDEN
+    s = {"fc.weight": (H, in_dim), "fc.bias": (H,), "query_tokens": (1, n_query, H), "model.weight": (out_dim, H), "model.bias": (out_dim,),
+         "Qformer.bert.embeddings.LayerNorm.weight": (H,), "Qformer.bert.embeddings.LayerNorm.bias": (H,)}
+    for l in range(QF_LAYERS):
+        p = f"Qformer.bert.encoder.layer.{l}."
+        for att in ("attention", "crossattention"):
+            for n in ("query", "key", "value"):
+                s[p + f"{att}.self.{n}.weight"], s[p + f"{att}.self.{n}.bias"] = (H, H), (H,)
+            s[p + f"{att}.output.dense.weight"], s[p + f"{att}.output.dense.bias"] = (H, H), (H,)
+            s[p + f"{att}.output.LayerNorm.weight"], s[p + f"{att}.output.LayerNorm.bias"] = (H,), (H,)
+        s[p + "intermediate_query.dense.weight"], s[p + "intermediate_query.dense.bias"] = (inter, H), (inter,)
+        s[p + "output_query.dense.weight"], s[p + "output_query.dense.bias"] = (H, inter), (H,)
+        s[p + "output_query.LayerNorm.weight"], s[p + "output_query.LayerNorm.bias"] = (H,), (H,)
+    return s
+
+
+def random_qformer_weights(in_dim: int, out_dim: int, n_query: int, inter: int = 3072, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    for k, shp in qformer_param_shapes(in_dim, out_dim, n_query, inter).items():
+        if k.endswith("LayerNorm.weight"):
+            w[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            w[k] = 0.05 * torch.randn(shp, generator=g)
+        elif k == "query_tokens":
+            w[k] = 0.5 * torch.randn(shp, generator=g)
+        else:
+            w[k] = torch.randn(shp, generator=g) / math.sqrt(shp[-1])
+    return {k: v.bfloat16().float() for k, v in w.items()}       # bf16-representable: the HIP engine holds them in bf16
+
+
+def _qf_attn(w, p, h, kv):
+    B, Q, H = h.shape
+    d = H // QF_HEADS
+    lin = lambda n, t: F.linear(t, w[p + f"self.{n}.weight"], w[p + f"self.{n}.bias"])
+    q = lin("query", h).view(B, Q, QF_HEADS, d).transpose(1, 2)
+    k = lin("key", kv).view(B, -1, QF_HEADS, d).transpose(1, 2)
+    v = lin("value", kv).view(B, -1, QF_HEADS, d).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, Q, H)
+    o = F.linear(a, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
+    return F.layer_norm(o + h, (H,), w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], QF_EPS)
+
+
+def qformer_textfc_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """x [B, T, in_dim] fp32 -> [B, n_query, out_dim] (layers.py:125-139)"""
+    H = QF_HIDDEN
+    x = F.linear(x, w["fc.weight"], w["fc.bias"])
+    h = w["query_tokens"].expand(x.shape[0], -1, -1)
+    h = F.layer_norm(h, (H,), w["Qformer.bert.embeddings.LayerNorm.weight"], w["Qformer.bert.embeddings.LayerNorm.bias"], QF_EPS)
+    for l in range(QF_LAYERS):
+        p = f"Qformer.bert.encoder.layer.{l}."
+        h = _qf_attn(w, p + "attention.", h, h)
+        h = _qf_attn(w, p + "crossattention.", h, x)
+        f = F.gelu(F.linear(h, w[p + "intermediate_query.dense.weight"], w[p + "intermediate_query.dense.bias"]))
+        o = F.linear(f, w[p + "output_query.dense.weight"], w[p + "output_query.dense.bias"])
+        h = F.layer_norm(o + h, (H,), w[p + "output_query.LayerNorm.weight"], w[p + "output_query.LayerNorm.bias"], QF_EPS)
+    return F.linear(h, w["model.weight"], w["model.bias"])

@@ -68,11 +68,15 @@ class TextFcLayer:
     `weights` = the reference module's state dict.
       mode 'linear':       outputs = model(x)                                                  (layers.py:64-65)
       mode 'transformer':  outputs = model(tfm(fc(x), query_embs.repeat(B, 1, 1)))             (layers.py:66-75,113-124)
-      mode 'qformer' needs the pretrained BERT Q-Former and is not on this path (NotImplementedError, like unknown modes)."""
+      mode 'qformer':      outputs = model(Qformer.bert(query_tokens, encoder_hidden_states=fc(x)))  (layers.py:76-98,125-139):
+                           the 2-layer BLIP-2 style Q-Former of spider/models/Qformer.py on its query branch only (embedding
+                           LayerNorm; per layer post-LN self-attention over the queries, cross-attention to fc(x), GELU feed-forward),
+                           hidden 768; `qformer_heads` = the BERT config's num_attention_heads (12 for bert-base-uncased, which
+                           init_Qformer loads; a state dict does not carry it)."""
 
     def __init__(self, in_dim: int, out_dim: int, num_input_tokens: int = 1, num_output_tokens: int = 1, mode: str = "linear",
-                 device="cuda:0", freeze_qformer=False, weights: Dict[str, torch.Tensor] = None):
-        if mode not in ("linear", "transformer"):
+                 device="cuda:0", freeze_qformer=False, weights: Dict[str, torch.Tensor] = None, qformer_heads: int = 12):
+        if mode not in ("linear", "transformer", "qformer"):
             raise NotImplementedError(mode)
         if weights is None:
             raise ValueError("TextFcLayer needs the reference module's state dict (weights=...)")
@@ -81,6 +85,24 @@ class TextFcLayer:
         self.w = {k: v.to(device=self.device, dtype=BF16).contiguous() for k, v in weights.items()}
         if mode == "transformer":
             split_cross_attention(self.w, "tfm.")
+        if mode == "qformer":
+            self.qf_heads = qformer_heads
+            w = self.w
+            self.qf_layers = 0
+            while f"Qformer.bert.encoder.layer.{self.qf_layers}.attention.self.query.weight" in w:
+                p = f"Qformer.bert.encoder.layer.{self.qf_layers}."
+                cat = lambda names, suf: torch.cat([w[p + n + suf] for n in names]).contiguous()
+                # fused projections: self-attention q|k|v of the queries; cross-attention k|v of the encoder states
+                w[p + "self.qkv_w"] = cat([f"attention.self.{n}" for n in ("query", "key", "value")], ".weight")
+                w[p + "self.qkv_b"] = cat([f"attention.self.{n}" for n in ("query", "key", "value")], ".bias")
+                w[p + "cross.kv_w"] = cat([f"crossattention.self.{n}" for n in ("key", "value")], ".weight")
+                w[p + "cross.kv_b"] = cat([f"crossattention.self.{n}" for n in ("key", "value")], ".bias")
+                self.qf_layers += 1
+            if self.qf_layers == 0:
+                raise ValueError("TextFcLayer(mode='qformer'): no Qformer.bert.encoder.layer.* weights in the state dict")
+            H = w["fc.weight"].shape[0]
+            if H % qformer_heads or H // qformer_heads % 8:
+                raise ValueError(f"TextFcLayer(mode='qformer'): hidden {H} / {qformer_heads} heads is not a multiple of 8")
 
     def eval(self):
         return self
@@ -91,6 +113,8 @@ class TextFcLayer:
         x = x.to(device=self.device, dtype=BF16).contiguous()
         if self.mode == "linear":
             outputs = ops.gemm(x, w["model.weight"], bias=w["model.bias"])
+        elif self.mode == "qformer":
+            outputs = self._qformer(x)
         else:
             h = ops.gemm(x, w["fc.weight"], bias=w["fc.bias"])
             tgt = w["query_embs"].expand(x.shape[0], -1, -1).contiguous()
@@ -98,6 +122,28 @@ class TextFcLayer:
         assert outputs.shape[1] == 1 or (outputs.shape[1] * outputs.shape[2] == self.num_output_tokens * self.out_dim), \
             (tuple(outputs.shape), self.num_output_tokens)          # layers.py:141-143
         return outputs
+
+    def _qformer(self, x: torch.Tensor) -> torch.Tensor:
+        """layers.py:125-139 with Qformer.py's BertEmbeddings (query_embeds only, :78-108) and BertLayer (query_length = Q, :402-484)"""
+        w, nh, eps = self.w, self.qf_heads, 1e-12
+        B = x.shape[0]
+        enc = ops.gemm(x, w["fc.weight"], bias=w["fc.bias"])                                   # [B, T, 768]
+        H = enc.shape[-1]
+        ln = lambda n, t: ops.layernorm(t, w[n + ".weight"], w[n + ".bias"], eps)
+        h = ln("Qformer.bert.embeddings.LayerNorm", w["query_tokens"].expand(B, -1, -1).contiguous())
+        for l in range(self.qf_layers):
+            p = f"Qformer.bert.encoder.layer.{l}."
+            qkv = ops.gemm(h, w[p + "self.qkv_w"], bias=w[p + "self.qkv_b"])
+            a = ops.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], nh)
+            h = ln(p + "attention.output.LayerNorm", ops.gemm(a, w[p + "attention.output.dense.weight"], bias=w[p + "attention.output.dense.bias"], res=h))
+            q = ops.gemm(h, w[p + "crossattention.self.query.weight"], bias=w[p + "crossattention.self.query.bias"])
+            kv = ops.gemm(enc, w[p + "cross.kv_w"], bias=w[p + "cross.kv_b"])
+            a = ops.attention(q, kv[..., :H], kv[..., H:], nh)
+            h = ln(p + "crossattention.output.LayerNorm",
+                   ops.gemm(a, w[p + "crossattention.output.dense.weight"], bias=w[p + "crossattention.output.dense.bias"], res=h))
+            f = ops.gemm(h, w[p + "intermediate_query.dense.weight"], bias=w[p + "intermediate_query.dense.bias"], act="gelu")
+            h = ln(p + "output_query.LayerNorm", ops.gemm(f, w[p + "output_query.dense.weight"], bias=w[p + "output_query.dense.bias"], res=h))
+        return ops.gemm(h, w["model.weight"], bias=w["model.bias"])
 
     __call__ = forward
 

@@ -399,6 +399,70 @@ def gen_story():
     print("story fixtures:", len(out), "arrays; final cur_step", ns["cur_step"])
 
 
+def gen_qformer():
+    """TextFcLayer, mode 'qformer' (spider/models/layers.py:76-98,125-139): the reference's own Q-Former building blocks
+    `BertEmbeddings` and `BertLayer` (spider/models/Qformer.py:51-108,378-484, with BertSelfAttention / BertSelfOutput /
+    BertAttention / BertIntermediate / BertOutput) executed on seeded inputs, driven the way `BertModel.forward` drives them for
+    the call TextFcLayer makes (query_embeds only, encoder_hidden_states = fc(x), all-ones masks -> zero additive masks,
+    query_length = number of query tokens; Qformer.py:804-966), between the module's own `fc` and `model` Linear layers.
+    Qformer.py as a whole does not import under this image's transformers (its PreTrainedModel subclasses target v4.15: moved
+    helpers, `init_weights` protocol), so the nn.Module classes that hold the arithmetic are executed and the mask / loop glue of
+    BertModel.forward + BertEncoder.forward (no arithmetic beyond `(1 - mask) * -10000`) is restated in these few lines.
+    `init_Qformer`'s bert-base-uncased config fields are used (hidden 768, 12 heads, gelu, eps 1e-12, 2 layers, cross-attention in
+    every layer) with a narrower feed-forward to keep the run short."""
+    import math
+    from torch import nn
+    from transformers.activations import ACT2FN
+    from transformers.models.bert.configuration_bert import BertConfig
+    from transformers.pytorch_utils import apply_chunking_to_forward, prune_linear_layer
+    from oracle.moe_proj import QF_HIDDEN, QF_HEADS, QF_LAYERS, random_qformer_weights
+    ns = dict(torch=torch, nn=nn, math=math, ACT2FN=ACT2FN, apply_chunking_to_forward=apply_chunking_to_forward,
+              prune_linear_layer=prune_linear_layer, find_pruneable_heads_and_indices=None)     # the last two: prune_heads only, never called
+    extract_defs(f"{REF}/spider/models/Qformer.py",
+                 ["BertEmbeddings", "BertSelfAttention", "BertSelfOutput", "BertAttention", "BertIntermediate", "BertOutput", "BertLayer"], ns)
+    in_dim, out_dim, n_query, inter = 64, 48, 7, 256
+    cfg = BertConfig(hidden_size=QF_HIDDEN, num_attention_heads=QF_HEADS, intermediate_size=inter, hidden_act="gelu",
+                     layer_norm_eps=1e-12, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg.encoder_width, cfg.num_hidden_layers = QF_HIDDEN, QF_LAYERS                 # init_Qformer(num_output_tokens, hidden_dim = 768)
+    cfg.add_cross_attention, cfg.cross_attention_freq, cfg.query_length = True, 1, n_query
+    emb = ns["BertEmbeddings"](cfg).eval()
+    layers = [ns["BertLayer"](cfg, l).eval() for l in range(QF_LAYERS)]
+    fc, model = nn.Linear(in_dim, QF_HIDDEN), nn.Linear(QF_HIDDEN, out_dim)          # layers.py:79,91
+    w = random_qformer_weights(in_dim, out_dim, n_query, inter=inter, seed=41)
+
+    def load(mod, prefix):
+        own = mod.state_dict()
+        take = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)}
+        # everything of the checkpoint under this prefix must exist in the module; what the module has on top is the text branch
+        # the reference's constructor deletes (word / position embeddings, layer.intermediate / layer.output) and buffers
+        assert all(k in own for k in take), [k for k in take if k not in own]
+        extra = [k for k in own if k not in take]
+        assert all(any(t in k for t in ("word_embeddings", "position_embeddings", "position_ids", "intermediate.dense", "output.dense", "output.LayerNorm"))
+                   and "_query" not in k and "attention" not in k for k in extra), extra
+        own.update(take)
+        mod.load_state_dict(own, strict=True)
+    load(emb, "Qformer.bert.embeddings.")
+    for l, lay in enumerate(layers):
+        load(lay, f"Qformer.bert.encoder.layer.{l}.")
+    load(fc, "fc.")
+    load(model, "model.")
+    g = torch.Generator().manual_seed(42)
+    out = dict(in_dim=np.array(in_dim), out_dim=np.array(out_dim), n_query=np.array(n_query), inter=np.array(inter), seed=np.array(41),
+               w_checksum=np.array(float(sum(v.double().abs().sum() for v in w.values()))))
+    with torch.no_grad():
+        for tag, (B, T) in {"a": (1, 1), "b": (2, 5), "c": (1, 9)}.items():
+            x = torch.randn(B, T, in_dim, generator=g).bfloat16().float()
+            enc = fc(x)                                                              # layers.py:126
+            h = emb(query_embeds=w["query_tokens"].expand(B, -1, -1))                # Qformer.py:868-873
+            self_mask = (1.0 - torch.ones(B, 1, 1, n_query)) * -10000.0              # get_extended_attention_mask of an all-ones mask
+            enc_mask = (1.0 - torch.ones(B, 1, 1, T)) * -10000.0                     # invert_attention_mask(image_atts), layers.py:127
+            for lay in layers:                                                       # BertEncoder.forward, Qformer.py:549-560
+                h = lay(h, self_mask, None, enc, enc_mask, None, False, n_query)[0]
+            out[f"{tag}_x"] = x.numpy(); out[f"{tag}_y"] = model(h).numpy()          # layers.py:139
+    np.savez_compressed(os.path.join(OUT, "textfc_qformer_ref.npz"), **out)
+    print("qformer fixture:", {k: v.shape for k, v in out.items() if k.endswith("_y")})
+
+
 def gen_moe():
     """Trained-Spider output side: the reference's own TextFcLayerMoE / Mlp class bodies (spider/models/layers.py) and
     Spider.preparing_output_embeds_infer (spider/models/spider.py:1413-1463) executed here on seeded inputs."""
@@ -469,3 +533,4 @@ if __name__ == "__main__":
     gen_routing()
     gen_story()
     gen_moe()
+    gen_qformer()

@@ -367,6 +367,22 @@ def test_moe_projector_oracle_matches_reference():
         assert torch.allclose(y, torch.from_numpy(z[f"{t}_y"]), atol=2e-5, rtol=1e-4), t
 
 
+def test_qformer_textfc_oracle_matches_reference():
+    """oracle/moe_proj.py:qformer_textfc_forward vs the reference's own Q-Former blocks (BertEmbeddings / BertLayer of
+    spider/models/Qformer.py, executed by tests/golden/make_golden.py::gen_qformer between TextFcLayer's fc and model layers)"""
+    from oracle.moe_proj import qformer_param_shapes, qformer_textfc_forward, random_qformer_weights
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "textfc_qformer_ref.npz"))
+    dims = [int(z[k]) for k in ("in_dim", "out_dim", "n_query")]
+    w = random_qformer_weights(*dims, inter=int(z["inter"]), seed=int(z["seed"]))
+    assert set(w) == set(qformer_param_shapes(*dims, inter=int(z["inter"])))
+    assert abs(float(sum(v.double().abs().sum() for v in w.values())) - float(z["w_checksum"])) < 1e-6 * float(z["w_checksum"])
+    for t in "abc":
+        y = qformer_textfc_forward(w, torch.from_numpy(z[f"{t}_x"]))
+        ref = torch.from_numpy(z[f"{t}_y"])
+        assert y.shape == ref.shape == (z[f"{t}_x"].shape[0], dims[2], dims[1])
+        assert torch.allclose(y, ref, atol=2e-5, rtol=1e-4), t
+
+
 class _FakeLLM:
     device = torch.device("cpu")
 

@@ -148,4 +148,31 @@ def test_text_fc_layer_matches_torch_modules(dev, mode):
     rel = float((got - ref.detach()).norm() / ref.detach().norm())
     assert rel < 2e-2, rel                       # bf16 weights / activations against the fp32 modules (8 pre-LN layers)
     with pytest.raises(NotImplementedError):
-        TextFcLayer(in_dim, out_dim, mode="qformer", device=dev, weights=sd)
+        TextFcLayer(in_dim, out_dim, mode="aligner", device=dev, weights=sd)
+
+
+def test_text_fc_layer_qformer_matches_reference_vectors(dev):
+    """`TextFcLayer(mode='qformer')` (spider/models/layers.py:76-98,125-139: fc -> 2-layer Q-Former on its query branch -> model) on
+    the HIP kernels against the vectors the reference's own Q-Former classes produced (tests/golden/textfc_qformer_ref.npz; weights
+    regenerated from the fixture's seed) and against the fp32 oracle on a second, larger case (77 queries, bert-base feed-forward)."""
+    from oracle.moe_proj import qformer_textfc_forward, random_qformer_weights
+    from spider_amd.moe_proj import TextFcLayer
+    z = np.load(os.path.join(GOLD, "textfc_qformer_ref.npz"))
+    in_dim, out_dim, nq = int(z["in_dim"]), int(z["out_dim"]), int(z["n_query"])
+    w = random_qformer_weights(in_dim, out_dim, nq, inter=int(z["inter"]), seed=int(z["seed"]))
+    w["Qformer.bert.embeddings.position_ids"] = torch.arange(512)[None]      # the buffer a real state dict carries; ignored
+    layer = TextFcLayer(in_dim, out_dim, 1, nq, mode="qformer", device=dev, weights=w)
+    for t in "abc":
+        got = layer(torch.from_numpy(z[f"{t}_x"]).to(dev))
+        ref = torch.from_numpy(z[f"{t}_y"])
+        assert got.shape == ref.shape
+        r = _rel(got, ref)
+        print(f"MEASURED textfc_qformer case={t} rel={r:.5f}")
+        assert r < 1.0e-2, (t, r)                # bf16 weights / activations vs the reference's fp32 run (6 post-LN sub-layers): measured 5.9 - 7.2e-3
+    w2 = random_qformer_weights(256, 768, 77, inter=3072, seed=5)
+    x2 = torch.randn(1, 4, 256, generator=torch.Generator().manual_seed(6)).bfloat16().float()
+    got = TextFcLayer(256, 768, 4, 77, mode="qformer", device=dev, weights=w2)(x2.to(dev))
+    ref = qformer_textfc_forward(w2, x2)
+    assert got.shape == ref.shape == (1, 77, 768) and _rel(got, ref) < 2e-2, _rel(got, ref)
+    with pytest.raises(ValueError):
+        TextFcLayer(in_dim, out_dim, 1, nq, mode="qformer", device=dev, weights=w, qformer_heads=7)
