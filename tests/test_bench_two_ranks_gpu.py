@@ -28,3 +28,24 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dist"] == {"world_size": 2, "backend": "gloo"}
     assert d["gathered"]["tokens"] == [2, 1, 12] and d["gathered"]["out"] == [2, 1, 3, 512, 512] and d["gathered"]["count"] == [2]
     assert d["value"] > 0 and abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-2 * d["value"]   # all ranks' responses / max time
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_under_torchrun():
+    """the driver's launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher), same one-GPU rehearsal as above"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SPIDER_SHARE_GPU="1", SPIDER_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only",
+           "--prompt-len", "192", "--new-tokens", "12", "--denoise-steps", "5"]
+    o = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert o.returncode == 0, o.stderr[-2000:]
+    lines = [l for l in o.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"] == {"world_size": 2, "backend": "gloo"} and d["gathered"]["tokens"] == [2, 1, 12]
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
