@@ -35,6 +35,13 @@ if os.environ.get("SHAPES") == "deep":   # SD-v1.5 UNet, 16^2 / 8^2 maps (CFG ba
         ("u8 out", 128, 1280, 1280, 0, 0), ("u8 ff2", 128, 1280, 5120, 0, 0),
     ]
 
+if os.environ.get("SHAPES") == "vae":    # SD-v1.5 VAE decoder, one 512^2 image (up blocks: 64^2 x 512 ... 512^2 x 128)
+    SHAPES = [
+        ("vae 64 512>512", 4096, 512, 4608, 512, 64), ("vae 128 512>512", 16384, 512, 4608, 512, 128),
+        ("vae 256 512>256", 65536, 256, 4608, 512, 256), ("vae 256 256>256", 65536, 256, 2304, 256, 256),
+        ("vae 512 256>128", 262144, 128, 2304, 256, 512), ("vae 512 128>128", 262144, 128, 1152, 128, 512),
+    ]
+
 if os.environ.get("SHAPES") == "v3d":   # zeroscope UNet3D step, 2 x 16 frames at 40 x 72 (rows = sample, frame, pixel)
     SHAPES = [
         ("v0 out", 92160, 320, 320, 0, 0), ("v0 qkv", 92160, 960, 320, 0, 0), ("v0 ff1", 92160, 2560, 320, 0, 0), ("v0 ff2", 92160, 320, 1280, 0, 0),
