@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--workload", default="text_image", choices=["text_image", "any2many"],
                    help="text_image = BASELINE configs[1] (headline); any2many = configs[4] (text -> text+image+audio+video)")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary timings (SDXL story / UNet3D / audio / Llama-8B)")
+    p.add_argument("--no-any2many", action="store_true", help="skip the one-step any-to-many extra (configs[3]/[4], 8 prompts) of the N=1 line")
     p.add_argument("--prompt-len", type=int, default=1536)
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
@@ -108,267 +109,170 @@ def launch_ranks(args, script=None, argv=None) -> int:
     return rc
 
 
-class Responder:
-    """The hot path for one GPU: LLM generate -> routing -> image decoder (text encoder, UNet loop, VAE)."""
+class _PlainThinker:
+    """`--llm llama3_8b`: a text decoder without multimodal rotary sections behind the thinker's `generate` surface."""
 
-    def __init__(self, args, device):
+    def __init__(self, llm):
+        self.llm = llm
+
+    def generate(self, input_ids, attention_mask=None, **kw):
+        kw.pop("spk", None); kw.pop("use_audio_in_video", None)
+        return self.llm.generate(input_ids=input_ids, attention_mask=attention_mask, **kw)
+
+
+class Responder:
+    """One GPU's responder: a thin caller of the product class `spider_amd.SpiderFreeInfer` (the `predict` flow of
+    qwen2.5omni_spider_web.py:458-521): QwenOmniThinker.generate -> batch_decode -> extract_answer -> SpiderDecoderInfer ->
+    SpiderDecoder.generate -> StableDiffusionPipeline (tokenizer, CLIP text encoder, 41 UNet evaluations, VAE, PIL). Nothing of the
+    hot path lives here: bench.py builds random-init engines of the true shapes, a synthetic processor (no vocabulary files exist;
+    random weights emit no signal tags, so its batch_decode renders one <IMAGE> caption per response), hands requests to the class
+    and packs the results into fixed-shape tensors for the gather. `--schedule overlap` = the class's own two-stream pipelining of
+    consecutive requests (`SpiderFreeInfer.submit`)."""
+    TAGS = ("IMAGE",)
+
+    def __init__(self, args, device, rank=0):
+        from spider_amd import SpiderDecoderInfer, SpiderFreeInfer
+        from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
         from spider_amd.llm import LlamaEngine, LLMConfig
-        from spider_amd.schedulers import PNDMScheduler
+        from spider_amd.pipelines import StableDiffusionPipeline
+        from spider_amd.qwen_omni import QwenOmniThinker
+        from spider_amd.synthetic import FakeTokenizer, SyntheticOmniProcessor
         from spider_amd.unet import UNetConfig, UNetEngine
+        from spider_amd.vae import VAEConfig, VAEDecoderEngine
         self.args, self.dev = args, device
-        cfg = getattr(LLMConfig, args.llm)()
-        self.max_batch = max(args.batch, min(args.throughput_batch, 8))
-        self.llm = LlamaEngine.random_init(cfg, device, max_batch=self.max_batch, max_len=args.prompt_len + args.new_tokens + 8, seed=0)
-        self.unet = UNetEngine.random_init(UNetConfig.sd15(), device, seed=1, dtype=DIFF_DT, stream32=not args.no_stream32)
-        self.sched = PNDMScheduler()
-        self.text_enc = self.vae = None
-        try:
-            from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
-            from spider_amd.vae import VAEConfig, VAEDecoderEngine
-            self.text_enc = CLIPTextEngine.random_init(CLIPTextConfig.sd15(), device, seed=2, dtype=DIFF_DT)
-            self.vae = VAEDecoderEngine.random_init(VAEConfig.sd15(), device, seed=3, dtype=DIFF_DT)
-        except ImportError:
-            pass
-        g = torch.Generator(device=device).manual_seed(2047)  # seed echoes Comic_Generation.py:387
-        mb = self.max_batch
-        self.prompt = torch.randint(3, cfg.vocab, (mb, args.prompt_len), generator=g, device=device)
-        self.latents0 = torch.randn(mb, 4, 64, 64, generator=g, device=device)
-        self.clip_ids_u = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
-        self.clip_ids_c = torch.randint(1000, 40000, (mb, 77), generator=g, device=device, dtype=torch.int32)
-        self.enc_synth = torch.randn(2 * mb, 77, 768, generator=g, device=device).to(DIFF_DT)
-        self._streams, self.overlap_ms = None, None
-        self._pending = {}            # batch size -> (ids on device, ids on host) of the response whose decoder pass comes next
-        self._captured = set()        # batch sizes whose graphs exist
+        a, dev, D = args, device, DIFF_DT
+        cfg = getattr(LLMConfig, a.llm)()
+        self.max_batch = max(a.batch, min(a.throughput_batch, 8)) if self.TAGS == ("IMAGE",) else min(a.batch, 8)
+        self.llm = LlamaEngine.random_init(cfg, dev, max_batch=self.max_batch, max_len=a.prompt_len + a.new_tokens + 8, seed=0)
+        self.unet = UNetEngine.random_init(UNetConfig.sd15(), dev, seed=1, dtype=D, stream32=not a.no_stream32)
+        self.sd = StableDiffusionPipeline(self.unet, VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 3, dtype=D),
+                                          CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 2, dtype=D), FakeTokenizer(40000))
+        self.sched = self.sd.scheduler
+        pipes = {"IMAGE": self.sd, **self.more_pipelines(dev, D)}
+        steps = {m: {"num_inference_steps": a.denoise_steps} for m in pipes}
+        self.decoder_infer = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines=pipes, device=str(dev), decode_kwargs=steps)})
+        self.decoder = self.decoder_infer.spider_decoder
+        thinker = QwenOmniThinker(self.llm) if cfg.mrope_section else _PlainThinker(self.llm)
+        self.processor = SyntheticOmniProcessor(cfg.vocab, tags=self.TAGS, prompt_len=a.prompt_len)
+        # eos_token_id=[]: random-init weights would emit an EOS id at a random step; every response carries exactly new_tokens tokens
+        self.infer = SpiderFreeInfer(thinker, self.processor, self.decoder_infer, device=dev,
+                                     generate_kwargs=dict(max_new_tokens=a.new_tokens, eos_token_id=[], sync_every=a.new_tokens))
+        g = torch.Generator(device=dev).manual_seed(2047 + rank)  # seed echoes Comic_Generation.py:387
+        self.prompt = torch.randint(3, cfg.vocab, (self.max_batch, a.prompt_len), generator=g, device=dev)
+        self.latents0 = torch.randn(self.max_batch, 4, 64, 64, generator=g, device=dev)
+        self.enc_synth = torch.randn(2 * self.max_batch, 77, 768, generator=g, device=dev).to(D)
+        self.overlap_ms, self.stage = None, {}
+        self._B = None
+
+    def more_pipelines(self, dev, D):
+        return {}
+
+    @property
+    def _streams(self):
+        return self.infer._streams
 
     def includes(self):
-        inc = ["llm_prefill", "llm_decode", "routing", "unet_denoise_loop"]
-        if self.text_enc is not None:
-            inc.insert(3, "clip_text_encoder")
-        if self.vae is not None:
-            inc.append("vae_decode")
-        return inc
+        return ["chat_inputs", "llm_prefill", "llm_decode", "batch_decode", "routing", "clip_tokenize", "clip_text_encoder", "unet_denoise_loop",
+                "vae_decode", "pil_conversion"]
 
-    # ---- the two passes of one response -------------------------------------------------------------------------------------
-    def _llm_pass(self, B):
-        """LLM generate for B prompts on the CURRENT stream; ends with the one device->host copy of the generated ids."""
-        from spider_amd import ops
-        a = self.args
-        gen = self._llm_enqueue(B)
-        return gen, gen.cpu()                      # the one device->host sync of the LLM phase
+    def request(self, B):
+        ids = self.prompt[:B].contiguous()
+        return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}     # what the processor emits for a text-only chat
 
-    def _llm_enqueue(self, B):
-        """the LLM pass without its final device->host copy: everything is enqueued on the current stream, the host does not wait"""
-        from spider_amd import ops
+    def pack(self, res, B):
+        """results of one request (B rows) -> fixed-shape device tensors for the gather"""
+        import numpy as np
+        res = res if isinstance(res, list) else [res]
         a = self.args
-        with ops.workspace_scope("llm"):
-            toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)
-        return toks[:, a.prompt_len:]
-
-    def _decoder_pass(self, B, gen_host):
-        """routing of the generated text + the image decoder (text encoder, UNet loop, VAE) on the CURRENT stream, no host sync"""
-        from spider_amd import ops, routing
-        from spider_amd.unet import denoise
-        a = self.args
-        for b in range(B):
-            # synthetic text forced to carry exactly one <IMAGE> tag (random-init weights emit no real tags)
-            text = "Here you go: <IMAGE>tokens " + " ".join(str(int(t)) for t in gen_host[b, :8]) + "</IMAGE>"
-            answers, ptext, calls = routing.route_text(text)
-            assert len(calls) == 1 and calls[0][0] == "IMAGE"
-        with ops.workspace_scope("diffusion"):
-            if self.text_enc is not None:   # CFG layout of _encode_prompt (custom_sd.py:372): [uncond(B) | cond(B)]
-                enc = self.text_enc.encode(torch.cat([self.clip_ids_u[:B], self.clip_ids_c[:B]]))
-            else:
-                enc = torch.cat([self.enc_synth[:B], self.enc_synth[self.max_batch:self.max_batch + B]]).contiguous()
-            lat = denoise(self.unet, self.sched, self.latents0[:B].contiguous(), enc, 7.5, a.denoise_steps)
-            if self.vae is not None:
-                img = self.vae.decode(lat)                          # [B, 3, 512, 512] fp32 in [0,1]
-                return (img * 255.0).round().to(torch.uint8)
-            return lat
+        toks = torch.stack([r.text_ids[a.prompt_len:] for r in res]).to(torch.int32)
+        out = {"tokens": toks.to(self.dev)}
+        for r in res:
+            assert all(len(r.predictions[m]) == 1 for m in self.TAGS), "every response carries one output per requested modality"
+        out["out" if self.TAGS == ("IMAGE",) else "image"] = torch.from_numpy(np.stack([np.asarray(r.predictions["IMAGE"][0], dtype=np.uint8) for r in res])).permute(0, 3, 1, 2).contiguous().to(self.dev)
+        if "AUDIO" in self.TAGS:
+            out["audio"] = torch.from_numpy(np.stack([np.asarray(r.predictions["AUDIO"][0], dtype=np.float32).reshape(-1) for r in res])).to(self.dev)
+        if "VIDEO" in self.TAGS:
+            out["video"] = torch.from_numpy(np.stack([np.stack([np.asarray(f, dtype=np.uint8) for f in r.predictions["VIDEO"][0]]) for r in res])).to(self.dev)
+        return out
 
     def respond_serial(self, batch=None):
-        """One response start to finish on one stream: LLM pass, then its decoder pass (the latency of ONE request)."""
+        """One request start to finish on one stream (the latency of ONE request; the reference's schedule)."""
         B = batch or self.args.batch
-        gen, gen_host = self._llm_pass(B)
-        return gen.to(torch.int32), self._decoder_pass(B, gen_host)
+        self.decoder.stage_events = {}
+        out = self.pack(self.infer.predict(inputs=self.request(B)), B)
+        self.stage = self.decoder.stage_ms_device()
+        return out
 
     def respond(self, batch=None):
-        """One step = one LLM pass + one decoder pass. Default schedule (`--schedule overlap`): the decoder pass of response k
-        (MFMA / latency-bound UNet loop) runs on one HIP stream while the LLM pass of response k+1 (HBM-bound weight streaming)
-        runs on another -- the two halves of the hot path load different parts of the chip, and consecutive requests are
-        independent (spider_decoder.py:311 reads one sample per call). Every step still performs exactly one LLM pass and one
-        decoder pass and returns the finished response k; the LLM output that response k+1 needs was produced one step earlier.
-        `--schedule serial` runs the two passes of the same response back to back on one stream."""
+        """One step = one LLM pass + one decoder pass (`--schedule overlap`, default: `SpiderFreeInfer.submit` -- the decoder pass of
+        request k on one HIP stream beside the LLM pass of request k+1 on another; the step returns the finished request k.
+        `--schedule serial`: `SpiderFreeInfer.predict`, the two passes of the same request back to back on one stream)."""
         B = batch or self.args.batch
         if self.args.schedule == "serial":
             return self.respond_serial(B)
-        if B not in self._captured:
-            # the very first response runs start to finish on one stream and one host thread: every engine captures its hipGraphs
-            # there (stream capture must not see another thread's allocations), the two-stream pipeline starts with the second call
-            self._captured.add(B)
-            first = self.respond_serial(B)
-            self._pending[B] = self._llm_pass(B)      # ... already primed with the next response's LLM pass (untimed warm-up work)
-            return first
-        dev = self.dev
-        if self._streams is None:
-            # the decoder pass is a dependent chain of ~370 short kernels per UNet evaluation: its stream gets the higher priority, so
-            # its workgroups are dispatched as soon as a CU frees up; the LLM's long weight-streaming grids fill the rest of the chip
-            prio = os.environ.get("SPIDER_BENCH_PRIO", "u")
-            sL_ = torch.cuda.Stream(device=dev, priority=-1 if prio == "l" else 0)
-            # tuning aid: HIP hands out its hardware queues round-robin; skipping n of them changes which queue / pipe the pair shares
-            self._skipped = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("SPIDER_BENCH_STREAM_SKIP", "0")))]
-            self._streams = (sL_, torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0))
-            # tuning aid: CU-masked streams (hipExtStreamCreateWithCUMask): SPIDER_BENCH_CUMASK_U / _L = "<n>[:stride]" enables n CUs
-            # (every stride-th bit from 0) for the decoder / LLM stream
-            def _masked(spec):
-                import ctypes
-                n, _, stride = spec.partition(":")
-                n, stride = int(n), int(stride or 1)
-                bits = [0] * 8
-                i = c = 0
-                while c < n and i < 256:
-                    bits[i // 32] |= 1 << (i % 32)
-                    i += stride
-                    c += 1
-                hip = ctypes.CDLL("libamdhip64.so")
-                st = ctypes.c_void_p()
-                arr = (ctypes.c_uint32 * 8)(*bits)
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, arr)
-                assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
-                return torch.cuda.ExternalStream(st.value, device=dev)
-            if os.environ.get("SPIDER_BENCH_CUMASK_U"):
-                self._streams = (self._streams[0], _masked(os.environ["SPIDER_BENCH_CUMASK_U"]))
-            if os.environ.get("SPIDER_BENCH_CUMASK_L"):
-                self._streams = (_masked(os.environ["SPIDER_BENCH_CUMASK_L"]), self._streams[1])
-        sL, sU = self._streams
-        cur = torch.cuda.current_stream(dev)
-        if B not in self._pending:                  # pipeline empty: this response's own LLM pass comes first
-            sL.wait_stream(cur)
-            with torch.cuda.stream(sL):
-                self._pending[B] = self._llm_pass(B)
-        gen, gen_host = self._pending[B]
-        sU.wait_stream(cur)
-        sL.wait_stream(cur)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        # The host enqueues the two passes from two threads: the LLM pass (the longer one: 22 k launches that fill its hardware queue,
-        # so its enqueue blocks for most of the pass) from this thread, the decoder pass of THIS response from a helper thread --
-        # neither stream waits for the other's host-side launch work (the current stream / workspace scope are per thread).
-        box = {}
-
-        def _dec():
-            try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(sU):
-                    ev[0].record(sU)
-                    box["out"] = self._decoder_pass(B, gen_host)
-                    ev[1].record(sU)
-            except BaseException as e:          # surfaced on the main thread below
-                box["err"] = e
-
-        th = None
-        if os.environ.get("SPIDER_BENCH_ENQUEUE_THREAD", "1") != "0":
-            import threading
-            th = threading.Thread(target=_dec, name="decoder-enqueue")
-            th.start()
-        else:
-            _dec()
-        with torch.cuda.stream(sL):                 # LLM pass of the NEXT response, concurrently (blocks the host at its end)
-            ev[2].record(sL)
-            self._pending[B] = self._llm_pass(B)
-            ev[3].record(sL)
-        if th is not None:
-            th.join()
-        if "err" in box:
-            raise box["err"]
-        out = box["out"]
-        sU.synchronize()
-        sL.synchronize()
-        self.overlap_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
-        return gen.to(torch.int32), out
+        if self._B != B:                            # another request geometry: drain the pipeline first
+            self.infer.flush()
+            self._B = B
+        self.decoder.stage_events = {}
+        res = self.infer.submit(inputs=self.request(B))
+        while res is None:                          # empty pipeline (first call): prime it; untimed warm-up work
+            res = self.infer.submit(inputs=self.request(B))
+        self.overlap_ms = self.infer.last_pass_ms or None
+        self.stage = self.decoder.stage_ms_device()
+        return self.pack(res, B)
 
 
-class AnyToManyResponder:
-    """BASELINE configs[4]: text -> {text + image + audio + video}. The LLM answers the rank's `batch` prompts in one batched
-    generate; every response then goes through the real Decoders-Controller (SpiderDecoder.generate: routing + decode_image /
-    decode_audio / decode_video, spider_decoder.py:100-166,309-348), one response per call like the reference (only sample 0
-    is read, :311). Random-init weights of the true shapes: SD-v1.5, AudioLDM-L (train_configs/spider_decoder_cfg.py:37),
-    zeroscope_v2_576w."""
+class AnyToManyResponder(Responder):
+    """BASELINE configs[3]/[4]: text -> {text + image + audio + video}: the same product path with a response that carries one
+    caption per modality; the rank's `batch` prompts are answered by ONE batched generate and ONE SpiderDecoder.generate_batch
+    (`--serial-decoders`: one SpiderDecoder.generate per response, the reference's contract, spider_decoder.py:311). Random-init
+    weights of the true shapes: SD-v1.5, AudioLDM-L (train_configs/spider_decoder_cfg.py:37), zeroscope_v2_576w."""
+    TAGS = ("IMAGE", "AUDIO", "VIDEO")
 
-    def __init__(self, args, device, rank=0):
+    def more_pipelines(self, dev, D):
         from spider_amd.clap import ClapTextConfig, ClapTextEngine
         from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
-        from spider_amd.llm import LlamaEngine, LLMConfig
-        from spider_amd.pipelines import AudioLDMPipeline, StableDiffusionPipeline, TextToVideoSDPipeline
+        from spider_amd.pipelines import AudioLDMPipeline, TextToVideoSDPipeline
         from spider_amd.schedulers import DDIMScheduler
-        from spider_amd.spider_decoder import SpiderDecoder
         from spider_amd.synthetic import FakeRobertaTokenizer, FakeTokenizer
         from spider_amd.unet import UNetConfig, UNetEngine
         from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
         from spider_amd.vae import VAEConfig, VAEDecoderEngine
         from spider_amd.vocoder import HifiGanConfig, HifiGanEngine
-        self.args, self.dev = args, device
-        dev = device
-        cfg = getattr(LLMConfig, args.llm)()
-        self.llm = LlamaEngine.random_init(cfg, dev, max_batch=min(args.batch, 8), max_len=args.prompt_len + args.new_tokens + 8, seed=0)
-        D = DIFF_DT
-        sd = StableDiffusionPipeline(UNetEngine.random_init(UNetConfig.sd15(), dev, 1, dtype=D, stream32=not args.no_stream32), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 2, dtype=D),
-                                     CLIPTextEngine.random_init(CLIPTextConfig.sd15(), dev, 3, dtype=D), FakeTokenizer(40000))
+        s32 = not self.args.no_stream32
         ad = AudioLDMPipeline(VAEDecoderEngine.random_init(VAEConfig.audioldm(), dev, 4, dtype=D), ClapTextEngine.random_init(ClapTextConfig(), dev, 5, dtype=D),
-                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6, dtype=D, stream32=not args.no_stream32),
+                              FakeRobertaTokenizer(40000), UNetEngine.random_init(UNetConfig.audioldm_l(), dev, 6, dtype=D, stream32=s32),
                               DDIMScheduler(beta_start=0.0015, beta_end=0.0195), HifiGanEngine.random_init(HifiGanConfig.audioldm(), dev, 7, dtype=D))
-        vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8, dtype=D), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9, dtype=D),
+        vd = TextToVideoSDPipeline(UNet3DEngine.random_init(UNet3DConfig.zeroscope(), dev, 8, dtype=D, stream32=s32), VAEDecoderEngine.random_init(VAEConfig.sd15(), dev, 9, dtype=D),
                                    CLIPTextEngine.random_init(CLIPTextConfig(49408, 1024, 23, 16, 4096, 77, 1e-5, "gelu"), dev, 10, dtype=D),
                                    FakeTokenizer(40000))
-        self.decoder = SpiderDecoder(pipelines={"IMAGE": sd, "AUDIO": ad, "VIDEO": vd}, device=str(dev))
-        g = torch.Generator(device=dev).manual_seed(2047 + rank)
-        self.prompt = torch.randint(3, cfg.vocab, (args.batch, args.prompt_len), generator=g, device=dev)
-        self.stage = {}
+        return {"AUDIO": ad, "VIDEO": vd}
 
     def includes(self):
-        return ["llm_prefill", "llm_decode", "routing", "clip_text_encoder", "sd15_unet_loop", "vae_decode", "clap_text_encoder",
-                "audioldm_l_unet_loop", "mel_vae_decode", "hifigan_vocoder", "zeroscope_unet3d_loop", "vae_decode_16_frames"]
+        return ["chat_inputs", "llm_prefill", "llm_decode", "batch_decode", "routing", "clip_text_encoder", "sd15_unet_loop", "vae_decode",
+                "clap_text_encoder", "audioldm_l_unet_loop", "mel_vae_decode", "hifigan_vocoder", "zeroscope_unet3d_loop", "vae_decode_16_frames"]
+
+    def respond_serial(self, batch=None):
+        if not self.args.serial_decoders:
+            return super().respond_serial(batch)
+        B = batch or self.args.batch                # one SpiderFreeInfer.predict per response: batch 1 everywhere
+        outs = [self.pack(self.infer.predict(inputs={k: v[b:b + 1] for k, v in self.request(B).items()}), 1) for b in range(B)]
+        return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
 
     def respond(self, batch=None):
-        import numpy as np
-        from spider_amd import routing
-        a, dev = self.args, self.dev
-        B = batch or a.batch
-        t0 = time.perf_counter()
-        toks = self.llm.generate(input_ids=self.prompt[:B].contiguous(), max_new_tokens=a.new_tokens, sync_every=a.new_tokens)[:, a.prompt_len:]
-        host = toks.cpu()
-        t1 = time.perf_counter()
-        imgs, auds, vids = [], [], []
-        samples = []
-        for b in range(B):
-            head = " ".join(str(int(t)) for t in host[b, :6])
-            # random-init weights emit no tags: the synthetic response carries exactly one caption per modality
-            samples.append({"llm_text_all": [f"Sure. <IMAGE>scene {head}</IMAGE> <AUDIO>sound {head}</AUDIO> <VIDEO>clip {head}</VIDEO>"]})
-        # Decoders-Controller, batched entry point: the rank's B responses are routed together and every diffusion decoder runs
-        # ONCE at CFG batch 2 x B (SpiderDecoder.generate_batch; per-sample containers as in the reference's generate)
-        self.decoder.stage_ms = {}
-        if a.serial_decoders:
-            outs = [self.decoder.generate(s, *routing.new_outputs()) for s in samples]
-        else:
-            outs = self.decoder.generate_batch(samples)
-        for answers, preds, ptext in outs:
-            assert len(preds["IMAGE"]) == 1 and len(preds["AUDIO"]) == 1 and len(preds["VIDEO"]) == 1
-            imgs.append(torch.from_numpy(np.asarray(preds["IMAGE"][0], dtype=np.uint8)))                         # [512, 512, 3]
-            auds.append(torch.from_numpy(np.asarray(preds["AUDIO"][0], dtype=np.float32).reshape(-1)))           # [80000]
-            vids.append(torch.from_numpy(np.stack([np.asarray(f, dtype=np.uint8) for f in preds["VIDEO"][0]])))  # [16, 320, 576, 3]
-        torch.cuda.synchronize(dev)
-        self.stage = dict(llm_ms=round((t1 - t0) * 1e3, 1), decoders_ms=round((time.perf_counter() - t1) * 1e3, 1),
-                          **{f"{m.lower()}_decoder_ms": round(v, 1) for m, v in self.decoder.stage_ms.items()})
-        return {"tokens": toks.to(torch.int32), "image": torch.stack(imgs).to(dev), "audio": torch.stack(auds).to(dev),
-                "video": torch.stack(vids).to(dev)}
+        if self.args.serial_decoders:
+            return self.respond_serial(batch)
+        return super().respond(batch)
 
 
 def measure_roofline(resp, device):
-    """Dominant kernel: gemv_kernel<1,1,GATEUP> (fused gate/up projection + SwiGLU of one decoded token), the
-    largest weight stream of the decode step. Algorithmic bytes per launch = 2*I*H*2 (weights) + H*2 + I*2.
-    Timed live with HIP events around back-to-back launches on the stream they are launched on (`achieved`, `frac`: the kernel's
-    own duration -- rocprofv3 reports the same average for it in BOTH schedules, profiles/r03_bench_kernel_stats_top.txt and
-    r03_bench_serial_kernel_stats_top.txt: 41.5 us). Under the two-stream schedule the same loop is timed a second time while UNet
-    evaluations replay on the decoder stream (`co_run`): the kernels do not run longer there, but each dependent launch starts
-    later (the interval per launch grows from 41.6 to ~50 us), which is where the LLM pass loses time when it shares the chip."""
+    """Dominant kernel: gemv_kernel<1,1,GATEUP> (fused gate/up projection + SwiGLU of one decoded token), the largest weight stream of
+    the decode step. Algorithmic bytes per launch = 2*I*H*2 (weights) + H*2 + I*2. Timed live with HIP events around back-to-back
+    launches on the stream they are launched on, cycling through all layers' weights.
+    `achieved` / `frac` are taken IN THE CONDITION OF THE TIMED REGION: under `--schedule overlap` the loop runs on the LLM stream while
+    UNet evaluations replay on the decoder stream, exactly as the two passes of a step share the chip (the kernel runs longer there and
+    its launches start later: profiles/r0N_bench_kernel_stats_top.txt holds rocprofv3's average for the same kernel in the same
+    condition); `standalone` is the same loop with the chip to itself. Under `--schedule serial` the two are the same measurement."""
     from spider_amd import ops
     llm = resp.llm
     c = llm.cfg
@@ -402,7 +306,7 @@ def measure_roofline(resp, device):
         sL, sU = resp._streams
         x2 = ops.latent_to_nhwc(resp.latents0[:1].contiguous(), reps=2, dtype=DIFF_DT)
         sU.wait_stream(cur); sL.wait_stream(cur)
-        with torch.cuda.stream(sU), ops.workspace_scope("diffusion"):
+        with torch.cuda.stream(sU), ops.workspace_scope("image"):
             for i in range(6):                       # >= 30 ms of UNet evaluations: covers the ~6 ms GEMV loop below
                 resp.unet.step(x2, i)
         e0, e1 = timed_loop(sL)
@@ -410,12 +314,12 @@ def measure_roofline(resp, device):
         sU.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
     bytes_alg = 2 * c.inter * c.hidden * 2 + c.hidden * 2 + c.hidden * 2 + c.inter * 2
-    us_corun, us = us, us_alone
     achieved = bytes_alg / (us * 1e-6) / 1e9
+    alone = bytes_alg / (us_alone * 1e-6) / 1e9
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode_hbm.json")
         if os.path.exists(pm) and bytes_alg == 271633408:
             try:
@@ -428,16 +332,16 @@ def measure_roofline(resp, device):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2),
             "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": n,
-            "co_run": ({"launch_interval_us": round(us_corun, 2), "effective_GBps": round(bytes_alg / (us_corun * 1e-6) / 1e9, 1),
-                        "note": "same loop while UNet evaluations replay on the decoder stream (two-stream schedule): launch-to-launch interval "
-                                "of the dependent chain (kernel + the dispatch gap between dependent launches; rocprofv3 serialises the two "
-                                "streams, so the split between the two is not observable with it)"} if corun else None)}
+            "condition": ("two-stream schedule of the timed region: loop on the LLM stream while UNet evaluations replay on the decoder "
+                          "stream; avg_launch_us is the launch-to-launch interval of back-to-back launches (kernel + dispatch gap)"
+                          if corun else "one stream (the schedule of the timed region)"),
+            "standalone": {"avg_launch_us": round(us_alone, 2), "achieved": round(alone, 1), "frac": round(alone / HBM_PEAK_GBS, 4)}}
 
 
 def _unet_pmc_traffic(kernel_prefix):
     """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r0N_pmc_unet_hbm.json:
     averages over every launch of that kernel in the UNet step, not only the roofline shape -- stated in `traffic_source`)."""
-    for tag in ("r03", "r02"):          # newest committed counter pass first
+    for tag in ("r04", "r03", "r02"):          # newest committed counter pass first
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_unet_hbm.json")
         try:
             for k in json.load(open(pm))["kernels"]:
@@ -542,7 +446,7 @@ def measure_attention_roofline(device):
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "kernel": "attn_flash_pipe_kernel<64> (UNet self-attention, 64x64 latent: 4096 tokens, 8 heads, d=40, batch 2)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true>")[0], "traffic_source": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true>")[1],
+            "traffic": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true,")[0], "traffic_source": _unet_pmc_traffic("attn_flash_pipe_kernel<64, true,")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
@@ -701,7 +605,7 @@ def other_decoders(device):
     torch.cuda.empty_cache()
     # ---- zeroscope UNet3D step: CFG batch 2 x 16 frames at 40x72
     from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
-    u3 = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), device, seed=12, dtype=DIFF_DT)
+    u3 = UNet3DEngine.random_init(UNet3DConfig.zeroscope(), device, seed=12, dtype=DIFF_DT, stream32=True)
     enc = torch.randn(2, 77, 1024, generator=g, device=device).to(DIFF_DT)
     ts = DDIMScheduler().set_timesteps(40)
     u3.prepare(ts, enc, frames=16)
@@ -770,7 +674,6 @@ def run_timed(resp, args, rank, world, device):
     a step = this rank's responses + the ONE gather of their padded outputs to rank 0; time = MAX over ranks. Afterwards every
     rank leaves the process group, BEFORE rank 0's secondary timings and CPU baseline (tens of seconds), so that no rank waits in a
     collective on a slow host. Returns (seconds, rank 0's last gathered payload | None, {"world_size", "backend"})."""
-    a2m = args.workload == "any2many"
     is_cuda = getattr(device, "type", "cpu") == "cuda"
 
     def sync():
@@ -778,10 +681,7 @@ def run_timed(resp, args, rank, world, device):
             torch.cuda.synchronize(device)
 
     def one_step():
-        if a2m:
-            return dp_mod().gather_padded(resp.respond(), args.batch, rank, world, dst=0)
-        toks, out = resp.respond()
-        return dp_mod().gather_padded({"tokens": toks, "out": out}, args.batch, rank, world, dst=0)
+        return dp_mod().gather_padded(resp.respond(), args.batch, rank, world, dst=0)
 
     g = None
     for _ in range(args.warmup):
@@ -826,7 +726,7 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     a2m = args.workload == "any2many"
-    resp = AnyToManyResponder(args, device, rank) if a2m else Responder(args, device)
+    resp = AnyToManyResponder(args, device, rank) if a2m else Responder(args, device, rank)
 
     dt, g, dist_info = run_timed(resp, args, rank, world, device)
 
@@ -842,13 +742,14 @@ def main():
             base["gather_bytes_per_rank"] = int(sum(v[0].numel() * v[0].element_size() for v in g.values()))
         if a2m:
             line = {"metric": "multimodal responses/sec (text->text+image+audio+video)", **base,
-                    "config": {"workload": f"any-to-many (BASELINE configs[4]): {a.llm} text-decoder shapes, prompt {a.prompt_len} + {a.new_tokens} "
-                                           "greedy tokens, routing of IMAGE+AUDIO+VIDEO tags through SpiderDecoder.generate: SD-v1.5 512^2 "
+                    "config": {"workload": f"any-to-many (BASELINE configs[4]) through spider_amd.SpiderFreeInfer: {a.llm} text-decoder shapes, prompt {a.prompt_len} + {a.new_tokens} "
+                                           "greedy tokens, routing of IMAGE+AUDIO+VIDEO tags through SpiderDecoder.generate_batch: SD-v1.5 512^2 "
                                            "(41 UNet calls), AudioLDM-L 5 s (40 steps + mel VAE + HiFi-GAN), zeroscope 16x320x576 (40 steps + VAE); "
                                            "one gather of the padded outputs to rank 0 per step",
+                               "product_class": "spider_amd.SpiderFreeInfer", "schedule": a.schedule,
                                "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": resp.includes(),
                                "weights": "random-init of the true shapes"},
-                    "rank0_stage_ms_last_step": resp.stage, "roofline": None, "cpu_baseline": None}
+                    "rank0_stage_ms_last_step": {**resp.stage, **(resp.overlap_ms or {})}, "roofline": None, "cpu_baseline": None}
             print(json.dumps(line), flush=True)
         else:
             roof = measure_roofline(resp, device)
@@ -858,20 +759,51 @@ def main():
                 torch.cuda.empty_cache()
                 extra.update(other_decoders(device))
                 extra["llama3_8b"] = llama8b_numbers(device)
+                if not args.no_any2many:
+                    extra["any2many"] = any2many_extra(args, device)
             cpu = None if (args.no_cpu_baseline or args.headline_only or world > 1) else cpu_baseline(args)   # reported at N=1 only
             extra["roofline_response"] = response_roofline(args, extra, base["ms_per_step"])
             line = {"metric": "multimodal responses/sec (text->text+image)", **base,
-                    "config": {"workload": f"SpiderFree text->text+1x512^2 image: {args.llm} text-decoder shapes, prompt {a.prompt_len} + "
-                                           f"{a.new_tokens} greedy tokens, routing, SD-v1.5 UNet 64x64 latent, PNDM {a.denoise_steps} steps "
-                                           f"({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5",
+                    "config": {"workload": f"SpiderFree text->text+1x512^2 image through spider_amd.SpiderFreeInfer (qwen2.5omni_spider_web.py:458-521): "
+                                           f"{args.llm} text-decoder shapes, prompt {a.prompt_len} + {a.new_tokens} greedy tokens, batch_decode, "
+                                           f"extract_answer, SpiderDecoderInfer -> SpiderDecoder.generate -> StableDiffusionPipeline: CLIP text encoder, SD-v1.5 UNet "
+                                           f"64x64 latent, PNDM {a.denoise_steps} steps ({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5, VAE decode, PIL",
+                               "product_class": "spider_amd.SpiderFreeInfer",
                                "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": extra.pop("_includes"),
-                               "schedule": ("overlap: every step = ONE LLM pass + ONE decoder pass; the decoder pass of response k runs on one HIP "
-                                            "stream beside the LLM pass of response k+1 on another (independent consecutive requests); "
-                                            "serial_ms_per_response is the one-stream latency of a single request"
-                                            if a.schedule == "overlap" else "serial: the two passes of a response back to back on one stream"),
+                               "schedule": ("overlap (SpiderFreeInfer.submit): every step = ONE LLM pass + ONE decoder pass; the decoder pass of request k runs on one "
+                                            "HIP stream beside the LLM pass of request k+1 on another (independent consecutive requests), so a step returns "
+                                            "the request submitted one step earlier: the first timed step consumes an LLM pass made during warm-up and the "
+                                            "last one produces an LLM pass nobody reads -- balanced, K LLM passes + K decoder passes in K timed steps; "
+                                            "serial_ms_per_response is the one-stream latency of a single request (SpiderFreeInfer.predict)"
+                                            if a.schedule == "overlap" else "serial (SpiderFreeInfer.predict): the two passes of a request back to back on one stream"),
                                "weights": "random-init of the true shapes"},
                     "roofline": roof, "cpu_baseline": cpu, **extra}
             print(json.dumps(line), flush=True)
+
+
+def any2many_extra(args, device):
+    """BASELINE configs[3]/[4] on this GPU, outside the timed region: ONE timed step (after one warm-up step) of the any-to-many
+    workload at 8 prompts per GPU -- text + 512^2 image + 5 s audio + 16-frame video per response through the same product class --
+    so that the driver's N=1 line carries a number for it. Stage times are device-event times of the pipeline calls (SpiderDecoder.
+    stage_ms_device) and of the two passes, not host walls."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.batch, a.throughput_batch = "any2many", 8, 0
+    resp = AnyToManyResponder(a, device, 0)
+    resp.respond()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = resp.respond()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    res = {"responses_per_s": round(a.batch / dt, 4), "ms_per_step": round(dt * 1e3, 1), "prompts_per_gpu": a.batch, "steps_timed": 1,
+           "schedule": a.schedule, "outputs": {k: list(v.shape) for k, v in out.items()},
+           "rank0_stage_ms": {**resp.stage, **(resp.overlap_ms or {})},
+           "workload": "text -> text + 512^2 image (SD-v1.5, 41 UNet calls) + 5 s audio (AudioLDM-L, 40 steps, mel VAE, HiFi-GAN) + 16x320x576 video "
+                       "(zeroscope, 40 steps, VAE) per response; spider_amd.SpiderFreeInfer -> SpiderDecoder.generate_batch"}
+    del resp
+    torch.cuda.empty_cache()
+    return res
 
 
 def response_roofline(args, extra, ms_per_step):

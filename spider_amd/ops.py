@@ -111,12 +111,27 @@ def _tiled(W: torch.Tensor, M: int):
     if M > WTILED_MAX_M or not getattr(W, "_spider_weight", False):
         return None
     t = getattr(W, "_spider_tiled", None)
-    if t is None:
+    tag = (W._version, W.data_ptr())           # an in-place update of the weight (copy_, merge) invalidates the copy
+    if t is None or getattr(W, "_spider_tiled_tag", None) != tag:
         if torch.cuda.is_current_stream_capturing():
+            if t is not None:
+                raise RuntimeError("a marked weight was modified in place and is first used again under stream capture: call "
+                                   "ops.prebuild_tiled() (or run one eager pass) before capturing")
             return None
         t = tile_weight64(W.reshape(W.shape[0], -1))
-        W._spider_tiled = t
+        W._spider_tiled, W._spider_tiled_tag = t, tag
     return t
+
+
+def prebuild_tiled(weights, max_rows: int = 64 << 20) -> int:
+    """Build the tile-major copies of every marked weight in `weights` now (engine constructors: no lazy first-use build, nothing
+    left for a stream capture to miss). Returns the bytes the copies occupy (INTEGRATION.md states them per model)."""
+    n = 0
+    for W in weights:
+        if getattr(W, "_spider_weight", False) and W.ndim >= 2 and W.numel() <= max_rows:
+            t = _tiled(W, 1)
+            n += 0 if t is None else t.numel() * t.element_size()
+    return n
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -428,9 +443,9 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
 
 
 def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1, up_size=None, act=None, act_param=0.0,
-            out_scale=1.0, out=None):
+            out_scale=1.0, out=None, res32=None, want32=False):
     """General NHWC conv. x [B,H,W,Cin] bf16, w [Cout,kh,kw,Cin] bf16 -> [B,Ho,Wo,Cout]. up_size=(uh,uw): x is read through
-    a nearest upsample to that size (each in (in, 2*in]) before the conv."""
+    a nearest upsample to that size (each in (in, 2*in]) before the conv. res32 / want32: fp32 residual stream as in gemm()."""
     dt, sfx = _h16(x)
     _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
@@ -443,10 +458,13 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
         out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
     uh, uw = up_size if up_size is not None else (0, 0)
     wt = _tiled(w, B * Ho * Wo)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
+    if res32 is not None:
+        _chk(res32, torch.float32, "res32")
     _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
               Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
-              None, None, _p(_workspace(x.device)), WS_BYTES, _stream())
-    return out
+              _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES, _stream())
+    return (out, o32) if want32 else out
 
 
 def conv1d(x, w, bias=None, res=None, pad=0, dil=1, act=None, act_param=0.0, out=None):

@@ -35,7 +35,13 @@ from .vocoder import HifiGanEngine
 def engine_dtype(torch_dtype):
     """The 16-bit engine format for a `from_pretrained(..., torch_dtype=...)` request. The reference always passes
     torch.float16 (spider_decoder.py:109,114,130,136,153,159; base_model.py:211); bfloat16 is honoured; None / float32
-    (diffusers: keep the checkpoint precision) maps to float16, the closest format the MFMA engines have."""
+    (diffusers: keep the checkpoint precision) maps to float16, the closest format the MFMA engines have -- with a warning for
+    an explicit float32 request: the f16 engines saturate above 65504 where fp32 (and bf16) would not; pass torch.bfloat16 for
+    range instead of precision."""
+    if torch_dtype == torch.float32:
+        import warnings
+        warnings.warn("spider_amd diffusion engines compute on 16-bit MFMA operands: torch_dtype=float32 runs as float16 (+ fp32 "
+                      "residual stream); pass torch.bfloat16 if the checkpoint needs fp32's range", stacklevel=3)
     return torch.bfloat16 if torch_dtype == torch.bfloat16 else torch.float16
 
 
@@ -359,7 +365,7 @@ class TextToVideoSDPipeline(StableDiffusionPipeline):
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         dt = engine_dtype(torch_dtype)
-        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt),
+        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True),
                    VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, dtype=dt),       # scaling_factor from the config (:382)
                    CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 32))

@@ -30,13 +30,19 @@ class SpiderDecoder:
                  diffusion_modules=None, system_prompt_image="", system_prompt_video="", system_prompt_audio="",
                  mask_decoder_modules=None, system_prompt_mask="", box_decoder_modules=None, system_prompt_box="",
                  story_generation=None, system_prompt_story="", max_context_len=4096, reload_per_call=False,
-                 device="cuda:0", pipelines: Optional[Dict[str, object]] = None, diffusion_dtype=torch.float16):
+                 device="cuda:0", pipelines: Optional[Dict[str, object]] = None, diffusion_dtype=torch.float16,
+                 decode_kwargs: Optional[Dict[str, dict]] = None):
         diffusion_modules = diffusion_modules or {}
+        # per-modality overrides of the decoders' call defaults (the reference hard-codes them in the signatures of decode_image /
+        # decode_video / decode_audio, spider_decoder.py:100,122,145), e.g. {"IMAGE": {"num_inference_steps": 20}}
+        self.decode_kwargs = {m: dict(k) for m, k in (decode_kwargs or {}).items()}
         self.diffusion_dtype = diffusion_dtype   # the reference hard-codes torch.float16 (spider_decoder.py:109,114,130,136,153,159)
         # generate_batch: captions per video pipeline call (4 x CFG 2 x 16 frames of 40 x 72 = 368,640 token rows per UNet3D
         # evaluation; the kernels' 32-bit operand offsets allow < 2 GiB per activation tensor, i.e. up to 5 captions at 16 frames)
         self.video_batch = 4
-        self.stage_ms: Dict[str, float] = {}     # host wall time per modality of the batched decoders (reset by the caller)
+        # (start, end) device events around every pipeline call, per modality, on the stream the call ran on (reset by the caller;
+        # summed by stage_ms_device: device time, not overlapping host walls)
+        self.stage_events: Dict[str, list] = {}
         self.model_name = name
         self.max_context_len = max_context_len
         self.device = device
@@ -50,9 +56,11 @@ class SpiderDecoder:
         self.ad_ckpt_path = diffusion_modules.get("AUDIO", {}).get("ckpt")
         self.diffusion_types = {m: d.get("type") for m, d in diffusion_modules.items()}
         self._pipes: Dict[str, object] = dict(pipelines or {})   # injected or lazily built, cached
+        from functools import partial
+        kw = lambda m: self.decode_kwargs.get(m, {})
         self.decode_modality: Dict[str, Optional[Callable]] = dict(
-            IMAGE=self.decode_image, VIDEO=self.decode_video, AUDIO=self.decode_audio, MASK=self.decode_mask,
-            BOX=self.decode_box, IMAGESTORY=None)
+            IMAGE=partial(self.decode_image, **kw("IMAGE")), VIDEO=partial(self.decode_video, **kw("VIDEO")),
+            AUDIO=partial(self.decode_audio, **kw("AUDIO")), MASK=self.decode_mask, BOX=self.decode_box, IMAGESTORY=None)
 
     def eval(self):
         return self
@@ -76,11 +84,38 @@ class SpiderDecoder:
             print(f"no input text prompt for {what} generation. or no {what} generation model.")
             return None
         from . import ops
-        with ops.workspace_scope(modality.lower()):   # every decoder keeps a split-K workspace (and graphs captured with it) of its own
+        with ops.workspace_scope(modality.lower()), self._timed(modality):   # every decoder keeps a split-K workspace (and graphs captured with it) of its own
             if self.get_prompt_embed_for_diffusion:   # text -> prompt-embeds control path (spider_decoder.py:104-112)
                 embeds = pipe(samples["llm_text_res"], return_prompts_only=True).detach()
                 return pipe(prompt_embeds=embeds, **call_kwargs)
             return pipe(prompt=samples["llm_text_res"], **call_kwargs)
+
+    def _timed(self, modality):
+        """context manager: device events around one pipeline call on the current stream"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if not torch.cuda.is_available():
+                yield
+                return
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                yield
+            finally:
+                e1.record()
+                self.stage_events.setdefault(modality, []).append((e0, e1))
+        return cm()
+
+    def stage_ms_device(self) -> Dict[str, float]:
+        """device milliseconds per modality of the pipeline calls since `stage_events` was last reset"""
+        out = {}
+        for m, evs in self.stage_events.items():
+            for _, e1 in evs:
+                e1.synchronize()
+            out[f"{m.lower()}_decoder_ms"] = round(sum(e0.elapsed_time(e1) for e0, e1 in evs), 1)
+        return out
 
     # ------------------------------------------------------------------ decoder side (spider_decoder.py:100-276)
     def decode_image(self, samples, guidance_scale=7.5, num_inference_steps=40):
@@ -133,17 +168,13 @@ class SpiderDecoder:
         if pipe is None:
             print(f"no input text prompt for {what} generation. or no {what} generation model.")
             return None
-        import time
         from . import ops
-        t0 = time.perf_counter()
-        with ops.workspace_scope(modality.lower()):   # own workspace per decoder: decoders may run on different streams at once
+        with ops.workspace_scope(modality.lower()), self._timed(modality):   # own workspace per decoder: decoders may run on different streams at once
             if self.get_prompt_embed_for_diffusion:
                 embeds = pipe(list(captions), return_prompts_only=True).detach()
                 out = pipe(prompt_embeds=embeds, **call_kwargs)
             else:
                 out = pipe(prompt=list(captions), **call_kwargs)
-        # host wall time of the pipeline call (every pipeline ends with a device -> host copy of its output): read by bench.py
-        self.stage_ms[modality] = self.stage_ms.get(modality, 0.0) + (time.perf_counter() - t0) * 1e3
         return out
 
     def decode_image_batch(self, captions, guidance_scale=7.5, num_inference_steps=40):
@@ -182,7 +213,9 @@ class SpiderDecoder:
         if outputs is None:
             outputs = [routing.new_outputs() for _ in samples_list]
         assert len(outputs) == len(samples_list)
-        batch = dict(IMAGE=self.decode_image_batch, VIDEO=self.decode_video_batch, AUDIO=self.decode_audio_batch)
+        from functools import partial
+        batch = {m: partial(f, **self.decode_kwargs.get(m, {})) for m, f in
+                 dict(IMAGE=self.decode_image_batch, VIDEO=self.decode_video_batch, AUDIO=self.decode_audio_batch).items()}
         return routing.route_batch(list(samples_list), list(outputs), self.decode_modality, batch)
 
 

@@ -50,3 +50,36 @@ class FakeRobertaTokenizer(FakeTokenizer):
         return o
 
 
+
+
+class SyntheticOmniProcessor:
+    """Stand-in for the checkpoint's Qwen2_5OmniProcessor (qwen2.5omni_spider_web.py:461-471) where no vocabulary files exist
+    (bench.py, tests): same three methods `SpiderFreeInfer` calls. Random-init weights emit no signal tags, so `batch_decode` renders a
+    row as one response line that carries exactly one caption per modality in `tags`, the caption built from the row's first
+    GENERATED ids (the prompt length is remembered from the last `__call__`, or given as `prompt_len`)."""
+
+    def __init__(self, vocab=152064, tags=("IMAGE",), prompt_len=None, head=8):
+        self.vocab, self.tags, self.prompt_len, self.head = vocab, tuple(tags), prompt_len, head
+        self._tok = FakeTokenizer(vocab)
+
+    def apply_chat_template(self, messages, add_generation_prompt=True, tokenize=False):
+        parts = []
+        for m in messages:
+            c = m["content"]
+            c = c if isinstance(c, str) else " ".join(str(p.get("text", "")) for p in c)
+            parts.append(f"<|im_start|>{m['role']}\n{c}<|im_end|>")
+        return "\n".join(parts) + ("\n<|im_start|>assistant\n" if add_generation_prompt else "")
+
+    def __call__(self, text=None, audios=None, images=None, videos=None, return_tensors="pt", padding=True):
+        ids = self._tok([text] if isinstance(text, str) else list(text), padding="longest").input_ids
+        self.prompt_len = ids.shape[1]
+        return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+
+    def batch_decode(self, text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+        S = self.prompt_len or 0
+        names = {"IMAGE": "scene", "AUDIO": "sound", "VIDEO": "clip"}
+        out = []
+        for row in text_ids:
+            head = " ".join(str(int(t)) for t in row[S:S + self.head])
+            out.append("system\nuser\nassistant\nSure. " + " ".join(f"<{m}>{names.get(m, 'item')} {head}</{m}>" for m in self.tags))
+        return out

@@ -96,17 +96,19 @@ def _param_shapes3d(c: UNet3DConfig) -> dict:
 
 
 class UNet3DEngine(UNetEngine):
-    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16):
+    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False):
+        """stream32: fp32 master of the residual stream beside its 16-bit shadow, as UNetEngine (the spatial resnets / transformers
+        are the base class's; the temporal convs and temporal transformers below carry the master through their own residual adds)."""
         self.cfg3 = cfg
         # Conv3d (3,1,1) weights [O,I,3,1,1] -> [O,I,3,1]; the base class turns 4-D conv weights into OHWI = [O,3,1,I]
         w = {n: (t[..., 0] if t.ndim == 5 else t) for n, t in weights.items()}
-        super().__init__(cfg.as2d(), w, device, dtype=dtype)
+        super().__init__(cfg.as2d(), w, device, dtype=dtype, stream32=stream32)
         is_temporal = lambda l: ".temp_attentions." in l or l.startswith("transformer_in")
         self.cross_layers = [l for l in self.cross_layers if not is_temporal(l)]
         self.frames = 1
 
     @classmethod
-    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0, dtype=BF16):
+    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _param_shapes3d(cfg).items():
@@ -117,10 +119,10 @@ class UNet3DEngine(UNetEngine):
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(BF16)
-        return cls(cfg, w, device, dtype=dtype)
+        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
         import glob, json, os
         from safetensors import safe_open
         cfg = UNet3DConfig.from_diffusers_dict(json.load(open(os.path.join(path, "config.json"))))
@@ -129,7 +131,7 @@ class UNet3DEngine(UNetEngine):
             with safe_open(f, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype)
+        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
 
     def prepare(self, timesteps, enc, added=None, class_labels=None, frames: int = 1):
         """enc [B2, 77, cross]; the UNet input of step() is [B2*frames, h, w, C] (sample-major, frame-minor)."""
@@ -146,6 +148,14 @@ class UNet3DEngine(UNetEngine):
         h = x
         for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
             a = ops.groupnorm(h.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups, 1e-5, True)
+            if i == 4 and self.stream32:     # x + conv4(...): the identity is added in fp32 and the new master handed on
+                x32 = getattr(x, "_s32", None)
+                h, h32 = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
+                                     res=None if x32 is not None else x.view(B, F_, H * W_, C),
+                                     res32=None if x32 is None else x32.view(B, F_, H * W_, C), want32=True)
+                out = h.view(BF, H, W_, C)
+                out._s32 = h32.view(BF, H, W_, C)
+                return out
             h = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
                             res=x.view(B, F_, H * W_, C) if i == 4 else None)
         return h.view(BF, H, W_, C)
@@ -165,7 +175,13 @@ class UNet3DEngine(UNetEngine):
         BF, H, W_, C = x.shape
         B, HW = BF // F_, H * W_
         a = ops.groupnorm(x.view(B, F_ * HW, C), w[n + ".norm.weight"], w[n + ".norm.bias"], self.cfg.groups, 1e-6, False)
-        h = ops.gemm(a.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
+        s32, h32 = self.stream32, None
+        if s32:
+            h, h32 = ops.gemm(a.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+        else:
+            h = ops.gemm(a.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
+        rg = (lambda A_, W_w, bias, h_, h32_: ops.gemm(A_, W_w, bias=bias, res32=h32_, want32=True)) if s32 else \
+             (lambda A_, W_w, bias, h_, h32_: (ops.gemm(A_, W_w, bias=bias, res=h_), None))
         inner = h.shape[-1]
         b = n + ".transformer_blocks.0"
         for at, nm in (("attn1", "norm1"), ("attn2", "norm2")):     # double_self_attention: both attend over the frames
@@ -174,13 +190,21 @@ class UNet3DEngine(UNetEngine):
             else:
                 qkv = ops.gemm(ops.layernorm(h, w[f"{b}.{nm}.weight"], w[f"{b}.{nm}.bias"]), w[f"{b}.{at}.qkv"])
             o = self._frame_attention(qkv, inner, heads, B, HW)
-            h = ops.gemm(o, w[f"{b}.{at}.to_out.0.weight"], bias=w[f"{b}.{at}.to_out.0.bias"], res=h)
+            h, h32 = rg(o, w[f"{b}.{at}.to_out.0.weight"], w[f"{b}.{at}.to_out.0.bias"], h, h32)
         if self.fuse_ln:
             g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
         else:
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
             g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")
-        h = ops.gemm(g, w[b + ".ff.net.2.weight"], bias=w[b + ".ff.net.2.bias"], res=h)
+        h, h32 = rg(g, w[b + ".ff.net.2.weight"], w[b + ".ff.net.2.bias"], h, h32)
+        if s32:
+            x32 = getattr(x, "_s32", None)
+            out, out32 = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], want32=True,
+                                  res=None if x32 is not None else x.view(BF * HW, C),
+                                  res32=None if x32 is None else x32.view(BF * HW, C))
+            outv = out.view(BF, H, W_, C)
+            outv._s32 = out32.view(BF, H, W_, C)
+            return outv
         out = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res=x.view(BF * HW, C))
         return out.view(BF, H, W_, C)
 

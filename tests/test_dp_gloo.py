@@ -124,7 +124,7 @@ def _bench_worker(rank, world, port, workload, q):
             if workload == "any2many":      # the payload keys and shapes of AnyToManyResponder.respond (smaller tensors)
                 return {"tokens": toks, "image": torch.full((B, 4, 4, 3), rank, dtype=torch.uint8),
                         "audio": torch.full((B, 7), rank + 0.25, dtype=torch.float32), "video": torch.full((B, 2, 3, 3, 3), rank, dtype=torch.uint8)}
-            return toks, torch.full((B, 3, 4, 4), rank, dtype=torch.uint8)      # Responder.respond: (tokens, images)
+            return {"tokens": toks, "out": torch.full((B, 3, 4, 4), rank, dtype=torch.uint8)}      # Responder.respond
 
     args = argparse.Namespace(workload=workload, batch=B, warmup=1, steps=2)
     dt, g, info = bench.run_timed(Stub(), args, rank, world, torch.device("cpu"))

@@ -1,0 +1,126 @@
+"""CPU: host logic of spider_amd.SpiderFreeInfer (the `predict` flow of qwen2.5omni_spider_web.py:458-521) with stand-in engines:
+call order, the last-line / extract_answer rules, ask_info keys, batched rows, and the request pipelining state machine (results in
+request order, every request exactly one LLM pass and one decoder pass, passes of a new geometry never overlapped)."""
+import threading
+
+import pytest
+import torch
+
+from spider_amd import SpiderDecoderInfer, SpiderFreeInfer
+from spider_amd.synthetic import SyntheticOmniProcessor
+
+
+class FakeThinker:
+    def __init__(self):
+        self.calls = []
+
+    def generate(self, input_ids, attention_mask=None, **kw):
+        self.calls.append((threading.current_thread().name, tuple(input_ids.shape), dict(kw)))
+        new = (input_ids[:, :1] + torch.arange(1, 5)[None]) % 97
+        return torch.cat([input_ids, new], 1)
+
+
+class FakePipe:
+    """StableDiffusionPipeline surface as SpiderDecoder uses it: pipe(prompt=[...], **kwargs).images"""
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, prompt=None, **kw):
+        self.calls.append((threading.current_thread().name, list(prompt), kw))
+        class O:
+            images = [f"img:{p}" for p in prompt]
+        return O()
+
+
+def make(tags=("IMAGE",), **kw):
+    pipe, thinker = FakePipe(), FakeThinker()
+    dinf = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": pipe}, device="cpu",
+                                             decode_kwargs={"IMAGE": {"num_inference_steps": 7}})})
+    proc = SyntheticOmniProcessor(vocab=500, tags=tags, head=3)
+    return SpiderFreeInfer(thinker, proc, dinf, device="cpu", generate_kwargs=dict(spk="Chelsie", use_audio_in_video=True), **kw), pipe, thinker
+
+
+def test_predict_flow_matches_reference_order():
+    infer, pipe, thinker = make()
+    res = infer([{"role": "user", "content": "draw a cat"}])
+    S = infer.processor.prompt_len
+    head = " ".join(str(int(t)) for t in res.text_ids[S:S + 3])
+    assert res.response == f"Sure. <IMAGE>scene {head}</IMAGE>"              # last line of the decoded text (:471)
+    assert res.answers == [res.response] and res.predictions_text["IMAGE"] == [f"scene {head}"]
+    assert res.predictions["IMAGE"] == [f"img:scene {head}"]
+    assert thinker.calls[0][2] == {"spk": "Chelsie", "use_audio_in_video": True}   # generate(**inputs, spk=..., use_audio_in_video=True) (:468)
+    assert pipe.calls[0][2]["num_inference_steps"] == 7 and pipe.calls[0][2]["guidance_scale"] == 7.5
+    a, p, pt = res
+    assert (a, p, pt) == (res.answers, res.predictions, res.predictions_text)
+
+
+def test_extract_answer_and_image_inputs():
+    infer, pipe, _ = make()
+
+    class Proc(SyntheticOmniProcessor):
+        def batch_decode(self, ids, **kw):
+            return ["user\nassistant\n<think><IMAGE>not this</IMAGE></think>ok <IMAGE>this one</IMAGE>"]
+    infer.processor = Proc(vocab=500)
+    infer.process_mm_info = lambda messages, use_audio_in_video: (None, [[[1, 2, 3]]], None)
+    seen = {}
+    orig = infer.spider_decoder_infer.spider_decoder.generate
+
+    def spy(samples, *a):
+        seen.update(samples)
+        return orig(samples, *a)
+    infer.spider_decoder_infer.spider_decoder.generate = spy
+    res = infer([{"role": "user", "content": "x"}])
+    assert res.predictions_text["IMAGE"] == ["this one"]                   # only the text after </think> is routed (:341-347)
+    assert seen["llm_text_all"] == ["ok <IMAGE>this one</IMAGE>"] and seen["Image_ori_array"][0].tolist() == [[1, 2, 3]]
+
+
+def test_batched_rows_use_generate_batch():
+    infer, pipe, _ = make()
+    ids = torch.arange(12).view(2, 6) + 3
+    infer.processor.prompt_len = 6
+    res = infer(inputs={"input_ids": ids, "attention_mask": torch.ones_like(ids)})
+    assert isinstance(res, list) and len(res) == 2 and len(pipe.calls) == 1 and len(pipe.calls[0][1]) == 2   # ONE pipeline call for both rows
+    assert [r.predictions["IMAGE"] for r in res] == [[f"img:{c}"] for c in pipe.calls[0][1]]
+
+
+def test_pipelining_state_machine():
+    infer, pipe, thinker = make()
+    infer.processor.prompt_len = 4
+    reqs = [{"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)} for i in range(5)]
+    serial = [infer.predict(inputs=r).response for r in reqs]
+    infer2, pipe2, thinker2 = make()
+    infer2.processor.prompt_len = 4
+    outs = []
+    for r in reqs:
+        o = infer2.submit(inputs=r)
+        outs.append(o)
+    outs.append(infer2.flush())
+    assert outs[0] is None and [o.response for o in outs[1:]] == serial      # request order, one step late
+    assert len(thinker2.calls) == 5 and len(pipe2.calls) == 5                 # exactly one LLM pass and one decoder pass per request
+    main = threading.current_thread().name
+    # request 1's LLM pass and request 0's decoder pass: geometry not seen before -> both on the calling thread; from then on the
+    # decoder pass has the helper thread
+    assert [c[0] for c in thinker2.calls] == [main] * 5
+    assert [c[0] for c in pipe2.calls] == [main, "spider-decoder-enqueue", "spider-decoder-enqueue", "spider-decoder-enqueue", main]
+    assert infer2.flush() is None
+    assert [r.response for r in infer2.pipelined(reqs)] == serial
+    # a new LLM geometry (2 rows) drains through the non-overlapped path
+    two = {"input_ids": torch.full((2, 4), 50), "attention_mask": torch.ones(2, 4, dtype=torch.long)}
+    assert infer2.submit(inputs=reqs[0]) is None
+    n = len(pipe2.calls)
+    r0 = infer2.submit(inputs=two)
+    assert r0.response == serial[0] and pipe2.calls[n][0] == main
+    assert len(infer2.flush()) == 2
+
+
+def test_errors():
+    infer, _, _ = make()
+    with pytest.raises(ValueError):
+        infer()
+    with pytest.raises(ValueError):
+        SpiderFreeInfer(FakeThinker(), SyntheticOmniProcessor())
+    infer.spider_decoder_infer.spider_decoder._pipes["IMAGE"] = lambda **kw: (_ for _ in ()).throw(RuntimeError("decoder failed"))
+    infer.submit(inputs={"input_ids": torch.ones(1, 4, dtype=torch.long)})
+    infer.submit(inputs={"input_ids": torch.ones(1, 4, dtype=torch.long)}) if False else None
+    with pytest.raises(RuntimeError, match="decoder failed"):
+        infer.flush()
