@@ -24,7 +24,8 @@ DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 BOUND = {
     "sd15": {"bf16": 1.6e-2, "f16": 2.0e-3},             # measured 1.305e-2 / 1.64e-3
     "sd15_s32": {"bf16": 1.2e-2, "f16": 1.45e-3},        # fp32 residual stream: measured 0.977e-2 / 1.21e-3 (a fall-back to the 16-bit stream, 1.64e-3, fails)
-    "sdxl_s32": {"bf16": 2.0e-2, "f16": 2.4e-3},         # SDXL with the fp32 stream, as story.py loads it (round 4; tightened once measured)
+    "sdxl_s32": {"bf16": 1.65e-2, "f16": 1.9e-3},        # SDXL with the fp32 stream, as story.py loads it: measured 1.362e-2 / 1.56e-3
+    "zeroscope_s32": {"bf16": 1.3e-2, "f16": 1.6e-3},    # fp32 stream (TextToVideoSDPipeline.from_pretrained's mode): measured 1.064e-2 / 1.34e-3
     "sdxl": {"bf16": 2.0e-2, "f16": 2.4e-3},             # 1.637e-2 / 1.97e-3
     "audioldm_l": {"bf16": 1.4e-2, "f16": 1.75e-3},      # 1.154e-2 / 1.43e-3
     "zeroscope": {"bf16": 1.9e-2, "f16": 2.3e-3},        # 1.541e-2 / 1.92e-3
@@ -79,7 +80,7 @@ def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype, stream32)
 # latents after the FULL denoising loop of configs[1] -- the quantity north_star names ("bf16 UNet latents agree within 1e-3
 # relative"): 40 PNDM steps = 41 UNet evaluations at CFG batch 2, guidance 7.5, [1,4,64,64] (custom_sd.py:627-652), engine in the
 # pipelines' default mode (f16 + fp32 residual stream) against the fp32 oracle loop (41 x 2.3 s of oracle on the box's host cores).
-LOOP41_BOUND = 6.0e-3          # round 4: first measurement pending; tightened to measured + 20 % below once known
+LOOP41_BOUND = 1.55e-3         # measured on MI355X (round 4): 1.26e-3 -- the loop does not amplify the per-evaluation 1.21e-3
 
 
 @pytest.mark.timeout(900)
@@ -177,7 +178,7 @@ def test_zeroscope_unet3d_step_fullsize_matches_oracle(dev, dtype, stream32):
     got = y.view(B, F_, H, W, -1).permute(0, 4, 1, 2, 3)
     r = _rel(got, ref)
     print(f"MEASURED fullsize zeroscope unet3d_step dtype={dtype} stream32={stream32} rel={r:.5f}")
-    assert r < BOUND["zeroscope"][dtype], r        # fp32 stream (what TextToVideoSDPipeline.from_pretrained loads): must not exceed the 16-bit-stream bound
+    assert r < BOUND["zeroscope_s32" if stream32 else "zeroscope"][dtype], r
     del eng, w
     _free()
 
