@@ -15,7 +15,8 @@
  */
 #ifndef SPIDER_HIP_H
 #define SPIDER_HIP_H
-#define SPIDER_ABI_VERSION 2   /* 2: w_tiled argument of the GEMM / conv entry points; *_f16 instantiations */
+#define SPIDER_ABI_VERSION 3   /* 2: w_tiled argument of the GEMM / conv entry points; *_f16 instantiations
+                                * 3: producer-side GroupNorm statistics (spider_conv_nhwc_gn, spider_groupnorm_stats / _apply, spider_gemm_gn_in) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -207,6 +208,29 @@ int spider_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* bet
  * cat [B,HW,C1+C2] receives the concatenated input (the resnet's 1x1 conv_shortcut reads it). C1, C2 multiples of 8. */
 int spider_groupnorm_cat_nhwc_bf16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
                                    void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream);
+/* GroupNorm with the statistics taken from the PRODUCER of its input (round 4; diffusers ResnetBlock2D: conv1 -> norm2, conv2 ->
+ * the next block's norm; Transformer2DModel: norm -> proj_in). The reference runs torch.nn.GroupNorm as its own pass over the
+ * tensor (custom_sd.py:634-639 -> UNet2DConditionModel.forward); here the conv that writes the tensor also writes, per chunk of
+ * `chunk_rows` consecutive output pixels and per group, (sum, sum of squares) of the 16-bit values it stores -- the [B, nchunk, G, 2]
+ * fp32 partial array every consumer reduces in a fixed order (no atomics: hipGraph replay stays bit-identical to eager launches).
+ *   spider_conv_nhwc_gn_*: spider_conv_nhwc_ex_* + gn_part (room for B * HW / 16 * gn_groups * 2 floats) / gn_groups; *produced =
+ *       rows per chunk of the statistics written, nchunk = HW / *produced: 64 (LDS-DMA conv epilogue), 16 (split-K reduce), or 0
+ *       when this shape's kernel cannot write them (run spider_groupnorm_stats_* instead). HW must be a multiple of 16.
+ *   spider_groupnorm_stats_nhwc_*: the statistics pass alone (any nchunk).
+ *   spider_groupnorm_apply_nhwc_*: normalise (+ SiLU) with given partials.
+ *   spider_gemm_gn_in_*: C = GroupNorm(A) W^T + bias with the normalisation applied to A on its way into LDS (norm + proj_in in
+ *       one launch); c32d optional fp32 copy of C (fp32 residual stream). */
+int spider_conv_nhwc_gn_bf16(const void* x, const void* w, void* y, const void* bias, const void* res, const void* rowbias,
+                             int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w,
+                             int dil, int up_h, int up_w, int act, float act_param, float out_scale, int w_tiled,
+                             const float* res32, float* c32d, void* ws, long ws_bytes, void* stream,
+                             float* gn_part, int gn_groups, int* produced);
+int spider_groupnorm_stats_nhwc_bf16(const void* x, void* partial, int B, int HW, int C, int G, int nchunk, void* stream);
+int spider_groupnorm_apply_nhwc_bf16(const void* x, const void* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                     int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_gemm_gn_in_bf16(const void* A, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                           const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                           float* c32d, void* stream);
 int spider_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                           void* stream);
 /* GEGLU (diffusers FeedForward): y[m,n] = x[m,n] * gelu(x[m,inner+n]) */
@@ -291,6 +315,17 @@ int spider_attn_varlen_f16(const void* q, const void* k, const void* v, void* o,
                             int total_rows, int Hq, int Hkv, int d, float scale, const int* tiles, int n_tiles, void* stream);
 int spider_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW,
                                int C, int G, float eps, int silu, void* stream);
+int spider_conv_nhwc_gn_f16(const void* x, const void* w, void* y, const void* bias, const void* res, const void* rowbias,
+                            int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w,
+                            int dil, int up_h, int up_w, int act, float act_param, float out_scale, int w_tiled,
+                            const float* res32, float* c32d, void* ws, long ws_bytes, void* stream,
+                            float* gn_part, int gn_groups, int* produced);
+int spider_groupnorm_stats_nhwc_f16(const void* x, void* partial, int B, int HW, int C, int G, int nchunk, void* stream);
+int spider_groupnorm_apply_nhwc_f16(const void* x, const void* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                    int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_gemm_gn_in_f16(const void* A, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                          const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                          float* c32d, void* stream);
 int spider_groupnorm_cat_nhwc_f16(const void* x1, const void* x2, const void* gamma, const void* beta, void* y, void* cat,
                                    void* ws, int B, int HW, int C1, int C2, int G, float eps, int silu, void* stream);
 int spider_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,

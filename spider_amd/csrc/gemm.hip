@@ -85,6 +85,21 @@ struct GemmArgs {
     // the 256^2 LDS-DMA kernel never sees A in registers: its LN form reads {mean, rstd} per row from this array, filled by
     // ln_row_stats_kernel just before the launch (padded to a multiple of 256 rows)
     const float2* ln_rows;
+    // GroupNorm statistics of the OUTPUT, written by the producer (round 4): gn_part [M / gn_cr, gn_G, 2] fp32 holds, per chunk of
+    // gn_cr consecutive output rows (a chunk never straddles two images: HW % gn_cr == 0) and per group of gn_cpg = N / gn_G
+    // channels, (sum, sum of squares) of the 16-bit values C receives -- the `partial` array gn_apply_kernel reduces in fixed order,
+    // so the consumer GroupNorm needs no statistics pass of its own (deterministic: no atomics, graph replay == eager).
+    float* gn_part;
+    int gn_G, gn_cpg, gn_cr;
+    // GroupNorm applied to the A operand on its way into LDS (register-staged kernel, plain linear): A is the UN-normalised
+    // [M, K] tensor, gna_part [M / HW, gna_nchunk, gna_G, 2] its partial statistics, and the block computes a_c = rstd_g gamma_c,
+    // b_c = beta_c - mean_g a_c for its image once and stores round16(fma(x, a_c, b_c)) -- the values gn_apply_kernel would have
+    // written (Transformer2DModel.norm + proj_in in one launch).
+    const float* gna_part;
+    const h16_t* gna_gamma;
+    const h16_t* gna_beta;
+    int gna_nchunk, gna_G, gna_hw;
+    float gna_eps;
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -385,11 +400,37 @@ __device__ __forceinline__ void geglu_out(const GemmArgs& p, f32x4 (&acc)[MT][2 
     }
 }
 
-template <int MT, int NT, int EPI, bool LN = false>
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane: four row rotations
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+// GN (producer statistics, GemmArgs::gn_part): gn_cols points at this wave's [NT * 16] float2 array in LDS; the wave leaves there,
+// per output column of its tile, (sum, sum of squares) over its MT * 16 rows of the 16-bit values it stored.
+template <int MT, int NT, int EPI, bool LN = false, bool GN = false>
 __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT], int mb, int nb, int split, int lane,
-                                          const float2* ln_stat = nullptr, int m_blk = 0) {
+                                          const float2* ln_stat = nullptr, int m_blk = 0, float2* gn_cols = nullptr) {
     if (EPI <= 1 && p.splits == 1) {
         const EpiRsrc er = make_epi_rsrc(p);
+        float gs[GN ? NT : 1][4], gq[GN ? NT : 1][4];     // GN: column sums of this lane's row (slot j = tile j's 4 columns of this lane)
+        if (GN) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gs[j][e] = 0.f; gq[j][e] = 0.f; }
+        }
+        auto gn_add = [&](int j, const float* v, float rowok) {     // v: the 4 final fp32 values of slot j, before the 16-bit rounding
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = h16_to_f32(f32_to_h16(v[e])) * rowok;
+                gs[j][e] += r;
+                gq[j][e] = fmaf(r, r, gq[j][e]);
+            }
+        };
         // Wide form (N, ldc multiples of 8): the 4 lane groups g = lane >> 4 of a row hold 4 columns each of tile j and of tile
         // j + 1. One v_permlane16_swap per accumulator register exchanges [tile j, odd g] <-> [tile j + 1, even g]: afterwards
         // a lane of an even group owns columns 4g .. 4g+7 of tile j and a lane of an odd group columns 4(g-1) .. 4(g-1)+7 of tile
@@ -433,6 +474,7 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
                         ln_fix(lms, lcs[j + 1], lcb[j + 1], v + 4);
                     }
                     epilogue_fast8<EPI == 1>(p, er, m, n, rb_row, v);
+                    if (GN) { const float ok = m < p.M ? 1.f : 0.f; gn_add(j, v, ok); gn_add(j + 1, v + 4, ok); }
                 }
                 if (NT & 1) {
                     const int j = NT - 1;
@@ -440,6 +482,7 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if (LN) ln_fix(lms, lcs[j], lcb[j], v);
                     epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
+                    if (GN) gn_add(j, v, m < p.M ? 1.f : 0.f);
                 }
                 continue;
             }
@@ -449,6 +492,30 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (LN) ln_fix(lms, lcs[j], lcb[j], v);
                 epilogue_fast<EPI == 1>(p, er, m, n, rb_row, v);
+                if (GN) gn_add(j, v, m < p.M ? 1.f : 0.f);
+            }
+        }
+        if (GN) {
+            // sum over the 16 rows (lane & 15) of the tile rows, then the lanes of row 0 publish their columns: slot j holds, in the
+            // wide form, the pair exchange's columns (see above), else tile j's own 4 columns of lane group g
+            const int g = lane >> 4;
+            // (DPP row rotations: one VALU add each; __shfl_xor would be 160 ds_bpermute round trips per wave -- measured +10 us on the
+            // 8192 x 320 x 2880 conv)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gs[j][e] = row16_sum(gs[j][e]);
+                    gq[j][e] = row16_sum(gq[j][e]);
+                }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bool paired = wide && ((j | 1) < NT);
+                    const int c0 = paired ? ((j & ~1) + (g & 1)) * 16 + 4 * (g & 2) + 4 * (j & 1) : j * 16 + g * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gn_cols[c0 + e] = float2{gs[j][e], gq[j][e]};
+                }
             }
         }
         return;
@@ -486,7 +553,8 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
     }
 }
 
-template <int BM, int BN, bool CONV, int EPI, bool LN = false>
+// GNA (GemmArgs::gna_part): GroupNorm applied to the A operand between its global load and its LDS image (plain linears only).
+template <int BM, int BN, bool CONV, int EPI, bool LN = false, bool GNA = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool GEGLU = EPI == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -644,8 +712,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     float ln_s[AC], ln_q[AC];     // LN: this thread's share (8 of every 64 k) of sum x and sum x^2 of rows lrow + 32*i
 #pragma unroll
     for (int i = 0; i < AC; ++i) ln_s[i] = ln_q[i] = 0.f;
-    auto store_tile = [&](int buf, const u32x4 (&ra)[AC], const u32x4 (&rw)[WC]) {
+    // GNA: per-channel (scale, shift) of this tile's image, behind the two tile buffers (K float2; the tile lies in ONE image:
+    // host-checked gna_hw % BM == 0). Group statistics are reduced from the producer's partials exactly like gn_apply_kernel does.
+    float2* gna_tab = reinterpret_cast<float2*>(smem + (size_t)2 * TILE_ELEMS * sizeof(h16_t));
+    auto store_tile = [&](int buf, const u32x4 (&ra_)[AC], const u32x4 (&rw)[WC], int kt_ = 0) {
         h16_t* base = lds + buf * TILE_ELEMS;
+        u32x4 ra[AC];
+#pragma unroll
+        for (int i = 0; i < AC; ++i) ra[i] = ra_[i];
+        if (GNA) {   // y = round16(fma(x, a_c, b_c)): the value gn_apply_kernel writes for the same element
+            int k0 = kt_ * BK + chunk * 8;
+            k0 = k0 + 8 <= p.K ? k0 : p.K - 8;         // tiles past K carry zero weights: any finite A value will do
+            float ca[8], cb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float2 t = gna_tab[k0 + j]; ca[j] = t.x; cb[j] = t.y; }
+#pragma unroll
+            for (int i = 0; i < AC; ++i) {
+                uint32_t w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float lo = fmaf(h16lo_to_f32(w4[d]), ca[2 * d], cb[2 * d]);
+                    const float hi = fmaf(h16hi_to_f32(w4[d]), ca[2 * d + 1], cb[2 * d + 1]);
+                    w4[d] = pack_h16x2(lo, hi);
+                }
+                ra[i] = u32x4{w4[0], w4[1], w4[2], w4[3]};
+            }
+        }
         if (LN) {   // every K tile passes through here exactly once (masked tiles are zeros)
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
@@ -694,7 +786,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     u32x4 a0[AC], w0[WC], a1[AC], w1[WC];
     load_tile(kt0, a0, w0);
     load_tile(kt0 + 1, a1, w1);
-    store_tile(0, a0, w0);
+    // (GNA: the statistics prologue runs with the first two K tiles already in flight)
+    if (GNA) {
+        float* g_mean = reinterpret_cast<float*>(gna_tab + p.K);          // [G], [G] behind the table
+        float* g_rstd = g_mean + p.gna_G;
+        float* ps = g_rstd + p.gna_G;                                     // [256], [256]
+        float* pq = ps + 256;
+        const int G = p.gna_G, parts = 256 / G, cpg = p.K / G;
+        const int b_img = m0 / p.gna_hw;
+        const int g = tid % G, part = tid / G;
+        float sum = 0.f, sq = 0.f;
+        if (part < parts) {
+            for (int c0 = part; c0 < p.gna_nchunk; c0 += 8 * parts) {
+                float2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u * parts;
+                    t[u] = c < p.gna_nchunk ? *reinterpret_cast<const float2*>(p.gna_part + (((size_t)b_img * p.gna_nchunk + c) * G + g) * 2)
+                                            : float2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sum += t[u].x; sq += t[u].y; }
+            }
+        }
+        ps[tid] = sum;
+        pq[tid] = sq;
+        __syncthreads();
+        if (tid < G) {
+            sum = 0.f; sq = 0.f;
+            for (int k = 0; k < parts; ++k) { sum += ps[k * G + tid]; sq += pq[k * G + tid]; }
+            const float cnt = (float)p.gna_hw * (float)cpg;
+            const float mu = sum / cnt;
+            const float var = fmaxf(sq / cnt - mu * mu, 0.f);
+            g_mean[tid] = mu;
+            g_rstd[tid] = rsqrtf(var + p.gna_eps);
+        }
+        __syncthreads();
+        for (int c = tid; c < p.K; c += 256) {
+            const int gg = c / cpg;
+            const float ca = g_rstd[gg] * h16_to_f32(p.gna_gamma[c]);
+            gna_tab[c] = float2{ca, h16_to_f32(p.gna_beta[c]) - g_mean[gg] * ca};
+        }
+        __syncthreads();
+    }
+    store_tile(0, a0, w0, kt0);
     load_tile(kt0 + 2, a0, w0);
     __syncthreads();
     // invariant at loop top: LDS buf0 = tile kt; R1 = tile kt+1 (in flight); R0 = tile kt+2 (in flight).
@@ -703,12 +838,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // a full compute phase before they are needed (left alone, hipcc sinks both load groups to the end of the body).
     for (int kt = kt0; kt < kt1; kt += 2) {
         compute(0);
-        store_tile(1, a1, w1);
+        store_tile(1, a1, w1, kt + 1);
         __syncthreads();
         load_tile(kt + 3, a1, w1);
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
-        store_tile(0, a0, w0);
+        store_tile(0, a0, w0, kt + 2);
         __syncthreads();
         load_tile(kt + 4, a0, w0);
         __builtin_amdgcn_sched_barrier(0);
@@ -764,7 +899,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int NS, bool CONV, int EPI, int BM = 128>
+template <int BN, int NS, bool CONV, int EPI, int BM = 128, bool GN = false>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     // BM = 128: wave tile 32 x BN/2. BM = 64 (wave tile 16 x BN/2): twice the row tiles for problems whose 128-row tiling leaves
     // the chip half empty -- the UNet's 3x3 convs at 8192 rows then need no split-K, i.e. no fp32 slab round trip through HBM
@@ -962,7 +1097,36 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     }
     wait_vmcnt<0>();                            // the masked tail DMAs must not outlive the workgroup's LDS allocation
 
-    write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane);
+    if (!GN) {
+        write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane);
+        return;
+    }
+    // ---- producer-side GroupNorm statistics (GemmArgs::gn_part; host-checked: splits == 1, gn_cr == 64, (BN / 2) % gn_cpg == 0,
+    // N % gn_cpg == 0): every wave leaves the column sums of its BM/4 x BN/2 tile in LDS; per 64-row chunk and group the two (BM = 128)
+    // or four (BM = 64) row waves and the group's gn_cpg columns are then summed in a fixed order and written to gn_part.
+    __syncthreads();                            // the ring is free: every wave has finished its last fragment reads
+    float2* cols = reinterpret_cast<float2*>(smem);                 // [8 waves][BN / 2]
+    write_out<MT, NT, EPI, false, true>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane, nullptr, 0, cols + wave * (BN / 2));
+    __syncthreads();
+    {
+        constexpr int NCH = BM / 64, WPC = 4 / NCH;                  // 64-row chunks per tile, row waves per chunk
+        const int cpg = p.gn_cpg, gpt = BN / cpg;                   // groups per tile (BN % cpg == 0)
+        for (int t = tid; t < NCH * gpt; t += 512) {
+            const int c = t / gpt, gi = t - c * gpt;
+            const int col0 = gi * cpg, ncol = n0 + col0;
+            const int mrow = m0 + c * 64;
+            if (ncol >= p.N || mrow >= p.M) continue;
+            const int wn_ = col0 / (BN / 2), cw = col0 - wn_ * (BN / 2);   // the group lies inside one column wave ((BN/2) % cpg == 0)
+            float ss = 0.f, qq = 0.f;
+            for (int w = 0; w < WPC; ++w) {
+                const float2* src = cols + ((c * WPC + w) * 2 + wn_) * (BN / 2) + cw;
+                for (int k = 0; k < cpg; ++k) { ss += src[k].x; qq += src[k].y; }
+            }
+            float* dst = p.gn_part + ((size_t)(mrow >> 6) * p.gn_G + (ncol / cpg)) * 2;
+            dst[0] = ss;
+            dst[1] = qq;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1504,6 +1668,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
     }
 }
 
+// split-K reduce + epilogue + producer-side GroupNorm statistics (GemmArgs::gn_part): one block per (16 output rows, slab of `cs`
+// columns = whole groups); thread -> (row r of 16, column quad q). All slab loads of a thread are in flight at once (<= 16 splits),
+// then the 16 rows of a column and the columns of a group are summed through LDS in a fixed order. A chunk of gn_cr = 16 rows is one
+// block; with gn_cr = 64 four row blocks would share a chunk, so this kernel is launched with gn_cr == 16 only (host-checked).
+template <int EPI>
+__global__ void splitk_reduce_gn_kernel(GemmArgs p, int cs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_r[];
+    float2* sm = reinterpret_cast<float2*>(smem_r);          // [16][cs], then [cs] column totals
+    float2* colsum = sm + 16 * cs;
+    const int nq = cs / 4;
+    const int q = threadIdx.x % nq, r = threadIdx.x / nq;    // r < 16
+    const int n_slabs = (p.N + cs - 1) / cs;
+    const int chunk = blockIdx.x / n_slabs, slab = blockIdx.x - chunk * n_slabs;
+    const int n = slab * cs + q * 4, m = chunk * 16 + r;
+    const size_t slab_elems = (size_t)p.M * p.N;
+    float2 o[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
+    if (n < p.N && m < p.M) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* src = p.ws + (size_t)m * p.N + n;
+        f32x4 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(u, p.splits - 1) * slab_elems);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float w = u < p.splits ? 1.f : 0.f;
+            v[0] += w * t[u][0]; v[1] += w * t[u][1]; v[2] += w * t[u][2]; v[3] += w * t[u][3];
+        }
+        epilogue_store<EPI>(p, m, n, v);          // leaves the final fp32 values in v
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float rv = h16_to_f32(f32_to_h16(v[e]));
+            o[e] = float2{rv, rv * rv};
+        }
+    }
+    if (n < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[r * cs + q * 4 + e] = o[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cs; c += blockDim.x) {
+        float ss = 0.f, qq = 0.f;
+        if (slab * cs + c < p.N) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float2 t2 = sm[k * cs + c]; ss += t2.x; qq += t2.y; }
+        }
+        colsum[c] = float2{ss, qq};
+    }
+    __syncthreads();
+    const int cpg = p.gn_cpg, gps = cs / cpg;
+    for (int gi = threadIdx.x; gi < gps; gi += blockDim.x) {
+        const int ncol = slab * cs + gi * cpg;
+        if (ncol >= p.N) continue;
+        float ss = 0.f, qq = 0.f;
+        for (int c = 0; c < cpg; ++c) { const float2 t2 = colsum[gi * cpg + c]; ss += t2.x; qq += t2.y; }
+        float* dst = p.gn_part + ((size_t)chunk * p.gn_G + ncol / cpg) * 2;
+        dst[0] = ss;
+        dst[1] = qq;
+    }
+}
+
 template <int BM, int BN>
 void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
@@ -1511,6 +1735,13 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = a.geglu ? 2 : (!fast_ok ? 3 : (a.act ? 1 : 0));
+    if (a.gna_part) {      // GroupNorm applied to A on the way into LDS (host-checked: plain linear, 64^2 tiles, epilogue 0, no split-K)
+        if constexpr (BM == 64 && BN == 64) {
+            const size_t extra = (size_t)a.K * sizeof(float2) + (size_t)2 * a.gna_G * sizeof(float) + 2 * 256 * sizeof(float);
+            gemm_kernel<64, 64, false, 0, false, true><<<grid, 256, smem + extra, st>>>(a);
+        }
+        return;
+    }
     if (a.ln_colsum) {     // LayerNorm-folded linears (checked by the caller: bf16 out, N % 4 == 0, no activation, no split-K)
         if (epi == 2) gemm_kernel<BM, BN, false, 2, true><<<grid, 256, smem, st>>>(a);
         else gemm_kernel<BM, BN, false, 0, true><<<grid, 256, smem, st>>>(a);
@@ -1591,11 +1822,29 @@ void launch_p8h(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+template <int BN, int NS, int BM>
+void launch_dma_gn(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int smem = NS * (BM + BN) * 128;
+    static unsigned done = 0;
+    raise_dynamic_lds(&gemm_dma_kernel<BN, NS, true, 0, BM, true>, smem, done);
+    gemm_dma_kernel<BN, NS, true, 0, BM, true><<<grid, 512, smem, st>>>(a);
+}
+
+// can this launch of the 128/64 x 160 LDS-DMA kernel write the GroupNorm partials of its output in its epilogue?
+bool dma_gn_ok(const GemmArgs& a) {
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    return a.gn_part && a.conv && a.splits == 1 && fast_ok && !a.act && a.gn_cr == 64 && a.gn_cpg > 0 && 80 % a.gn_cpg == 0 &&
+           a.N % a.gn_cpg == 0 && a.M % 64 == 0 && a.rows_per_group % 64 == 0;
+}
+
 template <int BN, int NS, int BM = 128>
 void launch_dma(const GemmArgs& a, int tiles, hipStream_t st) {
     dim3 grid(tiles, a.splits);
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
+    if constexpr (BN == 160 && (NS == 3 || (NS == 4 && BM == 64))) {
+        if (dma_gn_ok(a)) { launch_dma_gn<BN, NS, BM>(a, grid, st); return; }
+    }
     if (a.conv) {
         if (epi == 3) launch_dma_inst<BN, NS, true, 3, BM>(a, grid, st);
         else if (epi == 1) launch_dma_inst<BN, NS, true, 1, BM>(a, grid, st);
@@ -1626,8 +1875,19 @@ uint32_t tiled_bytes(int N, int K) {
     return (uint32_t)((size_t)((N + 63) / 64) * ((K + BK - 1) / BK) * 8192);
 }
 
-int launch(GemmArgs a, long ws_bytes, void* stream) {
+// column slab of the statistics-producing split-K reduce: whole groups, a multiple of 4 columns, about 160 wide (0: not possible)
+int gn_reduce_slab(int cpg, int target) {
+    int k = target / cpg;
+    if (k < 1) k = 1;
+    while (k > 1 && (cpg * k) % 4 != 0) --k;
+    const int cs = cpg * k;
+    return (cs % 4 == 0 && cs / 4 <= 64) ? cs : 0;       // 16 rows x (cs / 4) column quads <= 1024 threads
+}
+
+// gn_done (optional): set to true when the launch wrote GemmArgs::gn_part (the caller otherwise runs a statistics pass)
+int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     hipStream_t st = (hipStream_t)stream;
+    if (gn_done) *gn_done = 0;
     static const int force_tile = env_int("SPIDER_GEMM_TILE"), force_splits = env_int("SPIDER_GEMM_SPLITS");  // tuning aid
     const int nk = (a.K + BK - 1) / BK;
     const int ncols = a.geglu ? 2 * a.N : a.N;
@@ -1766,6 +2026,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         dma_bn = best == 2 ? 160 : 0; dma_bm = 128;
         small = false; splits = 1; p8_splits = 1;
     }
+    if (a.gna_part) { use_p8 = use_p8h = false; dma_bn = 0; small = true; splits = 1; }   // GroupNorm-on-A exists on the 64^2 register-staged kernel
     if (use_p8h) { use_p8 = false; splits = 1; dma_bn = 0; }
     if (use_p8) { splits = p8_splits; dma_bn = 0; }
     if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)
@@ -1789,6 +2050,10 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
         launch_p8(a, st);
     } else if (dma_bn && !a.geglu) {
         const int tdma = ((a.M + dma_bm - 1) / dma_bm) * ((a.N + dma_bn - 1) / dma_bn);
+        // producer-side GroupNorm partials in the epilogue: chunks of 64 rows (GemmArgs::gn_cr is an OUTPUT of launch: the caller
+        // learns the chunking from it); otherwise, with split-K, the reduce below writes 16-row chunks
+        if (a.gn_part && a.splits == 1) { a.gn_cr = 64; if (!(dma_bn == 160 && force_tile != 161 && dma_gn_ok(a))) a.gn_part = nullptr; }
+        if (gn_done && a.gn_part && a.splits == 1) *gn_done = 64;     // launch_dma takes the GN instantiation
         if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
         else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
         else if (dma_bn == 160 && dma_bm == 64) launch_dma<160, 4, 64>(a, tdma, st);
@@ -1798,6 +2063,20 @@ int launch(GemmArgs a, long ws_bytes, void* stream) {
     else launch_tile<128, 128>(a, tiles, st);
     SPIDER_LAUNCH_OK();
     if (a.splits > 1) {
+        const int cs = (a.gn_part && a.splits <= 16 && a.gn_cpg > 0 && a.N % a.gn_cpg == 0 && a.N % 4 == 0 && a.M % 16 == 0 && !a.C32 &&
+                        (!a.conv || a.rows_per_group % 16 == 0))
+                           ? gn_reduce_slab(a.gn_cpg, a.M >= 1024 ? 160 : 80) : 0;
+        a.gn_cr = 16;
+        if (cs) {      // reduce + epilogue + GroupNorm partials of the output in one launch
+            const int nq = cs / 4;
+            const int blocks = (a.M / 16) * ((a.N + cs - 1) / cs);
+            const size_t sm = (size_t)17 * cs * sizeof(float2);
+            if (a.act) splitk_reduce_gn_kernel<1><<<blocks, nq * 16, sm, st>>>(a, cs);
+            else splitk_reduce_gn_kernel<0><<<blocks, nq * 16, sm, st>>>(a, cs);
+            SPIDER_LAUNCH_OK();
+            if (gn_done) *gn_done = 16;
+            return 0;
+        }
         const size_t total = (size_t)a.M * ((a.N + 3) / 4);
         size_t g = (total + 255) / 256;
         if (g > 2048) g = 2048;
@@ -1883,10 +2162,12 @@ int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const floa
 // up_h x up_w (Upsample2D with an explicit output size, then the conv). 1-D convs are Hin = kh = 1; the
 // (3,1,1) temporal conv of UNet3D is Hin = frames, Win = H*W, kh = 3, kw = 1.
 // rowbias [B, Cout] is the per-image time-embedding add of ResnetBlock2D; res is [B,Hout,Wout,Cout].
-int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const void* bias, const void* res,
-                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
-                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
-                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
+static int conv_impl(const void* x, const void* w, void* y, const void* bias, const void* res,
+                     const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                     int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                     float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream,
+                     float* gn_part, int gn_groups, int* produced) {
+    if (produced) *produced = 0;
     SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv: empty problem");
     SPIDER_CHECK(kh >= 1 && kw >= 1 && kh * kw <= 64 && dil >= 1, "conv: kernel taps must be 1..64, dilation >= 1");
     SPIDER_CHECK(stride == 1 || stride == 2, "conv: stride must be 1 or 2");
@@ -1924,7 +2205,63 @@ int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const 
     a.w_tiled = w_tiled ? 1 : 0;
     a.w_bytes = w_tiled ? tiled_bytes(Cout, a.K) : (uint32_t)((size_t)Cout * a.K * 2);
     set_epilogue_ranges(a);
-    return launch(a, ws ? ws_bytes : 0, stream);
+    if (gn_part) {
+        SPIDER_CHECK(gn_groups > 0 && Cout % gn_groups == 0, "conv_gn: Cout must be a multiple of the groups");
+        a.gn_part = gn_part; a.gn_G = gn_groups; a.gn_cpg = Cout / gn_groups; a.gn_cr = 0;
+    }
+    int done = 0;
+    const int rc = launch(a, ws ? ws_bytes : 0, stream, &done);
+    if (produced) *produced = done;
+    return rc;
+}
+
+int SPIDER_FN(spider_conv_nhwc_ex)(const void* x, const void* w, void* y, const void* bias, const void* res,
+                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
+    return conv_impl(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, up_h, up_w, act, act_param,
+                     out_scale, w_tiled, res32, c32d, ws, ws_bytes, stream, nullptr, 0, nullptr);
+}
+
+// The same conv that ALSO leaves the GroupNorm partial statistics of its output (ResnetBlock2D: conv1 -> norm2, conv2 -> the next
+// block's GroupNorm): gn_part (room for B * Hout * Wout / 16 * gn_groups * 2 floats) receives [B * Hout * Wout / cr, gn_groups, 2]
+// fp32 = per chunk of cr consecutive output pixels and per group (sum, sum of squares) of the 16-bit values written to y, in the
+// layout spider_groupnorm_apply_nhwc and spider_gemm_gn_in consume with nchunk = Hout * Wout / cr. *produced = cr: 64 when the
+// LDS-DMA kernel's epilogue wrote them, 16 when the split-K reduce did, 0 when this shape's kernel cannot (the caller then runs
+// spider_groupnorm_stats_nhwc).
+int SPIDER_FN(spider_conv_nhwc_gn)(const void* x, const void* w, void* y, const void* bias, const void* res,
+                             const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
+                             int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
+                             float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream,
+                             float* gn_part, int gn_groups, int* produced) {
+    SPIDER_CHECK(gn_part && produced, "conv_gn: gn_part and produced are required");
+    return conv_impl(x, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, up_h, up_w, act, act_param,
+                     out_scale, w_tiled, res32, c32d, ws, ws_bytes, stream, gn_part, gn_groups, produced);
+}
+
+// C = GroupNorm(A) . W^T + bias for a plain linear whose input is a GroupNorm output (Transformer2DModel: norm -> proj_in) without
+// materialising the normalised tensor: A [M, K] is the UN-normalised NHWC tensor ([B, HW, K]), gn_part [B, nchunk, G, 2] its partial
+// statistics (spider_conv_nhwc_gn / spider_groupnorm_stats_nhwc), gamma / beta [K]; the kernel stores round16(fma(x, a_c, b_c)) into
+// its LDS image of A -- the values spider_groupnorm_nhwc(silu = 0) writes. c32d (optional): fp32 copy of the result (fp32 stream).
+int SPIDER_FN(spider_gemm_gn_in)(const void* A, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                           const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                           float* c32d, void* stream) {
+    SPIDER_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_gn_in: K % 64, N % 4, ldc % 4");
+    SPIDER_CHECK(gn_part && gamma && beta && C && nchunk > 0, "gemm_gn_in: statistics, gamma, beta and C are required");
+    SPIDER_CHECK(G > 0 && G <= 64 && 256 % G == 0 && K % G == 0 && HW % 64 == 0 && M % HW == 0, "gemm_gn_in: G must divide 256 and K; HW % 64 == 0");
+    SPIDER_CHECK((size_t)M * K * 2 < ((size_t)1 << 31) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 4 < ((size_t)1 << 31),
+                 "gemm_gn_in: operands must be < 2 GiB");
+    GemmArgs a{};
+    a.A = (const h16_t*)A; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.bias = (const h16_t*)bias; a.c32d = c32d;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.out_scale = 1.f;
+    a.a_bytes = (uint32_t)((size_t)M * K * 2);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
+    a.gna_part = gn_part; a.gna_nchunk = nchunk; a.gna_G = G; a.gna_hw = HW; a.gna_eps = eps;
+    a.gna_gamma = (const h16_t*)gamma; a.gna_beta = (const h16_t*)beta;
+    set_epilogue_ranges(a);
+    SPIDER_CHECK(a.c_bytes != 0, "gemm_gn_in: output must be < 2 GiB");
+    return launch(a, 0, stream);
 }
 
 // Square-kernel form used by the SD / SDXL UNet and the VAE (ResnetBlock2D convs, Down/Upsample2D, shortcuts).

@@ -785,6 +785,42 @@ extern "C" {
 int spider_groupnorm_nchunk(int HW) { return gn_nchunk(HW); }
 #endif
 
+// Pass 1 of GroupNorm alone: partial [B, nchunk, G, 2] fp32 = (sum, sum of squares) per chunk of ceil(HW / nchunk) pixels and group.
+int SPIDER_FN(spider_groupnorm_stats_nhwc)(const void* x, void* partial, int B, int HW, int C, int G, int nchunk, void* stream) {
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && nchunk > 0 && C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm_stats: bad shape");
+    const int cv = C / 8;
+    int KP = 256 / cv;
+    if (KP < 1) KP = 1;
+    const int threads = cv * KP;
+    SPIDER_CHECK(threads <= 1024, "groupnorm_stats: C too large");
+    gn_stats_kernel<<<dim3(nchunk, B), threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>(
+        (const h16_t*)x, (float*)partial, HW, C, G, nchunk, KP, nullptr, C, nullptr);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// Pass 2 of GroupNorm alone, on partial statistics someone else produced (the producing conv's epilogue, spider_conv_nhwc_gn, or
+// spider_groupnorm_stats_nhwc): y = GroupNorm(x) (+ SiLU), partial [B, nchunk, G, 2] reduced in a fixed order by every block.
+int SPIDER_FN(spider_groupnorm_apply_nhwc)(const void* x, const void* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                     int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0 && nchunk > 0, "groupnorm_apply: G must divide 256 and be <= 64");
+    SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192, "groupnorm_apply: C must be a multiple of 8 and of G");
+    const int cv = C / 8;
+    int KP = 256 / cv;
+    if (KP < 1) KP = 1;
+    const int threads = cv * KP;
+    SPIDER_CHECK(threads <= 1024 && (threads >= 128 || threads >= 2 * G), "groupnorm_apply: unsupported channel count for the block layout");
+    int ppb = 4 * KP;
+    while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;
+    dim3 g2((HW + ppb - 1) / ppb, B);
+    if (silu) gn_apply_kernel<true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x, (const float*)partial, (const h16_t*)gamma,
+                                                                       (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    else gn_apply_kernel<false><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x, (const float*)partial, (const h16_t*)gamma,
+                                                                    (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
 // GroupNorm of the channel concatenation [x1 | x2] (UpBlock2D / UpBlock3D: cat([hidden, skip]) -> ResnetBlock.norm1) without a
 // concat launch: x1 [B, HW, C1], x2 [B, HW, C2] are read in place, y [B, HW, C1 + C2] is the normalised result and `cat`
 // (same shape) receives the concatenated input for the resnet's 1x1 shortcut. x2 == nullptr: plain GroupNorm of x1 (C2 = 0).

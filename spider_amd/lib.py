@@ -55,6 +55,10 @@ SIGNATURES = {
     "spider_groupnorm_nchunk": (_i, [_i]),
     "spider_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_groupnorm_cat_nhwc_bf16": (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
+    "spider_conv_nhwc_gn_bf16": (_i, [_vp] * 6 + [_i] * 14 + [_f, _f, _i, _vp, _vp, _vp, _l, _vp] + [_vp, _i, _vp]),
+    "spider_groupnorm_stats_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "spider_groupnorm_apply_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "spider_gemm_gn_in_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "spider_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "spider_geglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "spider_swiglu_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -82,6 +86,7 @@ SIGNATURES = {
 # IEEE-half instantiations with the same signatures: spider_<op>_f16 (include/spider_hip.h, last section)
 F16_OPS = (
     "spider_gemm", "spider_gemm_ln", "spider_xattn_fused", "spider_conv2d_nhwc", "spider_conv_nhwc_ex", "spider_attn",
+    "spider_conv_nhwc_gn", "spider_groupnorm_stats_nhwc", "spider_groupnorm_apply_nhwc", "spider_gemm_gn_in",
     "spider_attn_keylist", "spider_attn_varlen", "spider_groupnorm_nhwc", "spider_groupnorm_cat_nhwc", "spider_layernorm",
     "spider_geglu", "spider_swiglu", "spider_concat_channels", "spider_act", "spider_add", "spider_act_ex", "spider_add_scaled",
     "spider_axpby", "spider_mean_tokens", "spider_moe_combine", "spider_col2im1d_f32", "spider_l2_normalize_rows",
@@ -113,7 +118,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.spider_abi_version() != 2:
+        if lib.spider_abi_version() != 3:
             raise SpiderHipError("libspider_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -420,8 +420,15 @@ def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps
     return (out, o32) if want32 else out
 
 
-def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None, res32=None, want32=False):
-    """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]. res32 / want32: fp32 residual stream as in gemm()."""
+def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=False, out_scale=1.0, out=None, res32=None, want32=False,
+           gn_groups=None):
+    """NHWC conv. x [B,H,W,Cin] bf16, w [Cout,ks,ks,Cin] bf16 -> [B,Ho,Wo,Cout]. res32 / want32: fp32 residual stream as in gemm().
+    gn_groups: see conv_ex (GroupNorm partial statistics of the output as the last element of the result)."""
+    if gn_groups and not ups:
+        ks_ = w.shape[1]
+        pd = ks_ // 2 if pad is None else pad
+        return conv_ex(x, w, bias=bias, res=res, rowbias=rowbias, stride=stride, pad=(pd, pd), out_scale=out_scale, out=out,
+                       res32=res32, want32=want32, gn_groups=gn_groups)
     dt, sfx = _h16(x)
     _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
@@ -442,10 +449,34 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     return (out, o32) if want32 else out
 
 
+class GnPartial:
+    """GroupNorm partial statistics of a [B, HW, C] tensor: t [B, nchunk, G, 2] fp32 = (sum, sum of squares) per pixel chunk and group
+    (include/spider_hip.h: spider_conv_nhwc_gn). Produced by `conv_ex(..., gn_groups=G)` for its own output, consumed by
+    `groupnorm(..., partial=...)` and `gemm_gn_in`."""
+    __slots__ = ("t", "nchunk", "groups")
+
+    def __init__(self, t, nchunk, groups):
+        self.t, self.nchunk, self.groups = t, nchunk, groups
+
+
+def groupnorm_stats(x, groups: int, nchunk: int) -> GnPartial:
+    """pass 1 of GroupNorm alone (x [B, ..., C] NHWC) with `nchunk` pixel chunks per image"""
+    dt, sfx = _h16(x)
+    _chk(x, dt, "x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    part = torch.empty(B, nchunk, groups, 2, dtype=torch.float32, device=x.device)
+    _lib.call(f"spider_groupnorm_stats_nhwc_{sfx}", _p(x), _p(part), B, HW, C, groups, nchunk, _stream())
+    return GnPartial(part, nchunk, groups)
+
+
 def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1, up_size=None, act=None, act_param=0.0,
-            out_scale=1.0, out=None, res32=None, want32=False):
+            out_scale=1.0, out=None, res32=None, want32=False, gn_groups=None):
     """General NHWC conv. x [B,H,W,Cin] bf16, w [Cout,kh,kw,Cin] bf16 -> [B,Ho,Wo,Cout]. up_size=(uh,uw): x is read through
-    a nearest upsample to that size (each in (in, 2*in]) before the conv. res32 / want32: fp32 residual stream as in gemm()."""
+    a nearest upsample to that size (each in (in, 2*in]) before the conv. res32 / want32: fp32 residual stream as in gemm().
+    gn_groups=G: also return the GroupNorm partial statistics of the OUTPUT as the last element of the result (a GnPartial):
+    written by the conv's own epilogue / split-K reduce where that kernel can, else by one statistics pass -- either way the
+    consumer GroupNorm needs none of its own. None is returned in their place when the map is not a multiple of the chunk rows."""
     dt, sfx = _h16(x)
     _chk(x, dt, "x"); _chk(w, dt, "w")
     B, H, Wd, Cin = x.shape
@@ -461,9 +492,45 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
     if res32 is not None:
         _chk(res32, torch.float32, "res32")
-    _lib.call(f"spider_conv_nhwc_ex_{sfx}", _p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
-              Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
-              _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES, _stream())
+    args = (_p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
+            Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
+            _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES, _stream())
+    part = None
+    HWo = Ho * Wo
+    # (every block of the consuming GroupNorm reduces the partials of its image: beyond ~256 chunks -- the UNet3D's temporal norms
+    # over 16 frames x 2880 pixels would be 720 -- that prologue costs more than the statistics pass it replaces: measured +0.8 %)
+    if gn_groups and GN_PRODUCER and HWo % 16 == 0 and HWo <= 16384:
+        buf = torch.empty(B * (HWo // 16) * gn_groups * 2, dtype=torch.float32, device=x.device)
+        produced = C.c_int(0)
+        _lib.call(f"spider_conv_nhwc_gn_{sfx}", *args, _p(buf), int(gn_groups), C.byref(produced))
+        cr = produced.value          # rows per chunk the producing kernel used (64: conv epilogue, 16: split-K reduce), 0: none
+        if not cr:                   # this shape's kernel cannot write them: one statistics pass (what the GroupNorm would have run)
+            cr = 64 if HWo % 64 == 0 and HWo >= 1024 else 16
+            _lib.call(f"spider_groupnorm_stats_nhwc_{sfx}", _p(out), _p(buf), B, HWo, Cout, int(gn_groups), HWo // cr, _stream())
+        nchunk = HWo // cr
+        part = GnPartial(buf[:B * nchunk * gn_groups * 2].view(B, nchunk, gn_groups, 2), nchunk, gn_groups)
+    else:
+        _lib.call(f"spider_conv_nhwc_ex_{sfx}", *args)
+    if gn_groups:         # part is None where no statistics were made: the consumer runs its own pass
+        return (out, o32, part) if want32 else (out, part)
+    return (out, o32) if want32 else out
+
+
+GN_PRODUCER = _os.environ.get("SPIDER_GN_PRODUCER", "1") != "0"     # tuning aid: 0 = every GroupNorm runs its own statistics pass
+
+
+def gemm_gn_in(A, W, part: GnPartial, gamma, beta, HW: int, eps: float, bias=None, want32=False):
+    """C = GroupNorm(A) @ W^T + bias with the normalisation applied inside the GEMM (Transformer2DModel.norm + proj_in in one launch).
+    A [B, HW, K] un-normalised, part = its partial statistics."""
+    dt, sfx = _h16(A)
+    _chk(A, dt, "A"); _chk(W, dt, "W")
+    N, K = W.shape
+    M = A.numel() // K
+    out = torch.empty(*A.shape[:-1], N, dtype=dt, device=A.device)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=A.device) if want32 else None
+    wt = _tiled(W, M)
+    _lib.call(f"spider_gemm_gn_in_{sfx}", _p(A), _p(W if wt is None else wt), _p(out), _p(bias), M, N, K, N, int(wt is not None),
+              _p(part.t), part.nchunk, _p(gamma), _p(beta), part.groups, float(eps), HW, _p(o32), _stream())
     return (out, o32) if want32 else out
 
 
@@ -611,7 +678,7 @@ def groupnorm_nchunk(HW: int) -> int:
     return _lib.load().spider_groupnorm_nchunk(HW)
 
 
-def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None):
+def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None, partial: Optional["GnPartial"] = None):
     """x [B, ..., C] NHWC bf16."""
     dt, sfx = _h16(x)
     _chk(x, dt, "x"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
@@ -619,6 +686,11 @@ def groupnorm(x, gamma, beta, groups=32, eps=1e-5, silu=False, out=None, ws=None
     HW = x.numel() // (B * Cn)
     if out is None:
         out = torch.empty_like(x)
+    if partial is not None:      # statistics from the producer of x (conv_ex(..., gn_groups=...)): the apply pass alone
+        assert partial.groups == groups and tuple(partial.t.shape) == (B, partial.nchunk, groups, 2)
+        _lib.call(f"spider_groupnorm_apply_nhwc_{sfx}", _p(x), _p(partial.t), partial.nchunk, _p(gamma), _p(beta), _p(out), B, HW, Cn,
+                  groups, float(eps), int(silu), _stream())
+        return out
     if ws is None:
         ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x.device)
     _lib.call(f"spider_groupnorm_nhwc_{sfx}", _p(x), _p(gamma), _p(beta), _p(out), _p(ws), B, HW, Cn, groups, float(eps),

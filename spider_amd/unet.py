@@ -158,6 +158,10 @@ class UNetEngine:
         # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
         self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
         self.gn_cat = os.environ.get("SPIDER_GN_CAT", "1") != "0"     # up-block norm1 reads (hidden, skip) in place (tuning aid)
+        # GroupNorm statistics from the producing conv's epilogue / split-K reduce, and Transformer2DModel.norm folded into proj_in's
+        # A operand (round 4; tuning aids: SPIDER_GN_PRODUCER=0 / SPIDER_GN_FUSE_IN=0 restore the stand-alone GroupNorm passes)
+        self.gn_producer = ops.GN_PRODUCER
+        self.gn_fuse_in = os.environ.get("SPIDER_GN_FUSE_IN", "1") != "0"
         self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
         self.xw: Dict[str, dict] = {}
         for b in list(self.ln):
@@ -355,33 +359,50 @@ class UNetEngine:
         f["mo_fm"].copy_(ops.repack_fm16(f["mo"]))
 
     # ------------------------------------------------------------------ blocks
-    def _gn(self, n, x, silu, eps=1e-5):
-        return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu)
+    def _gn(self, n, x, silu, eps=1e-5, partial=None):
+        """GroupNorm `n` of x; `partial` (or x._gnp): statistics its producing conv left behind (ops.conv_ex(gn_groups=...))"""
+        if partial is None:
+            partial = getattr(x, "_gnp", None)
+        return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu, partial=partial)
 
-    def _resnet(self, n, x):
+    def _resnet(self, n, x, out_gn: bool = False):
         """x: the block input, or a (hidden, skip) pair of an up block: norm1 then reads the two tensors in place and hands back
-        their concatenation for the shortcut (no concat launch)."""
+        their concatenation for the shortcut (no concat launch). GroupNorm statistics come from the PRODUCER of each normalised
+        tensor where one exists (SPIDER_GN_PRODUCER, default on): conv1 leaves those of norm2's input, the block's input may carry
+        its own (x._gnp), and with out_gn conv2 leaves those of the block's output for the GroupNorm that consumes it next."""
         w = self.w
+        G = self.cfg.groups if self.gn_producer else None
         if isinstance(x, tuple) and not self.gn_cat:
             x = ops.concat_channels(x[0], x[1])
         if isinstance(x, tuple):
             a, x = ops.groupnorm_cat(x[0], x[1], w[n + ".norm1.weight"], w[n + ".norm1.bias"], self.cfg.groups, 1e-5, True)
         else:
             a = self._gn(n + ".norm1", x, True)
-        h = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n])
-        a = self._gn(n + ".norm2", h, True)
+        if G:
+            h, hp = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n], gn_groups=G)
+        else:
+            h, hp = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n]), None
+        a = self._gn(n + ".norm2", h, True, partial=hp)
         sc = x
+        og = G if out_gn else None
         if not self.stream32:
             if n + ".conv_shortcut.weight" in w:
                 sc = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0)
-            return ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=sc)
+            out = ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=sc, gn_groups=og)
+            if og:
+                out, op_ = out
+                out._gnp = op_
+            return out
         # fp32 residual stream: the shortcut (identity: the block input's master; 1x1 conv: its unrounded output) is added in fp32
         sc32 = getattr(x, "_s32", None)
         if n + ".conv_shortcut.weight" in w:
             sc, sc32 = ops.conv2d(x, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], pad=0, want32=True)
-        out, out32 = ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=None if sc32 is not None else sc,
-                                res32=sc32, want32=True)
+        r = ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res=None if sc32 is not None else sc,
+                       res32=sc32, want32=True, gn_groups=og)
+        out, out32 = r[0], r[1]
         out._s32 = out32
+        if og:
+            out._gnp = r[2]
         return out
 
     def _self_attn(self, b, y, heads):
@@ -415,16 +436,24 @@ class UNetEngine:
     def _transformer(self, n, x, heads, depth):
         w = self.w
         B, H, W_, C = x.shape
-        a = self._gn(n + ".norm", x, False, eps=1e-6)
         s32 = self.stream32
         h32 = None
         # stream32: every residual GEMM below takes the stream's fp32 master (res32) and returns the new master beside the shadow
         rg = (lambda A_, W_w, bias, h_, h32_: ops.gemm(A_, W_w, bias=bias, res32=h32_, want32=True)) if s32 else \
              (lambda A_, W_w, bias, h_, h32_: (ops.gemm(A_, W_w, bias=bias, res=h_), None))
-        if s32:
-            h, h32 = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+        xp = getattr(x, "_gnp", None)
+        if xp is not None and self.gn_fuse_in and (H * W_) % 64 == 0 and C % 64 == 0 and B * H * W_ < 16384 and w[n + ".proj_in.weight"].shape[0] % 4 == 0:
+            # norm + proj_in in ONE launch: the statistics came with x (its producing conv), the normalisation is applied to the GEMM's
+            # A operand on its way into LDS -- no statistics pass, no apply pass, no normalised copy of x
+            r = ops.gemm_gn_in(x.view(B, H * W_, C), w[n + ".proj_in.weight"], xp, w[n + ".norm.weight"], w[n + ".norm.bias"], H * W_, 1e-6,
+                               bias=w[n + ".proj_in.bias"], want32=s32)
+            h, h32 = r if s32 else (r, None)
         else:
-            h = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
+            a = self._gn(n + ".norm", x, False, eps=1e-6)
+            if s32:
+                h, h32 = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+            else:
+                h = ops.gemm(a.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
         for d in range(depth):
             b = f"{n}.transformer_blocks.{d}"
             fuse = self.fuse_ln
@@ -478,15 +507,21 @@ class UNetEngine:
         nb = len(cfg.block_out)
         for i in range(nb):
             for j in range(cfg.layers_per_block):
-                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                # the block's output is normalised next by its transformer, or (no transformer) by the following resnet's norm1
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, out_gn=cfg.down_attn[i] or j + 1 < cfg.layers_per_block or i == nb - 1)
                 if cfg.down_attn[i]:
                     h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cfg.heads[i], cfg.depth[i])
                 skips.append(h)
             if i != nb - 1:
-                h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
-                               stride=2, pad=1)
+                if self.gn_producer:     # the next block's first norm1 normalises this conv's output
+                    h, hp = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
+                                       stride=2, pad=1, gn_groups=cfg.groups)
+                    h._gnp = hp
+                else:
+                    h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
+                                   stride=2, pad=1)
                 skips.append(h)
-        h = self._resnet("mid_block.resnets.0", h)
+        h = self._resnet("mid_block.resnets.0", h, out_gn=True)
         h = self._transformer("mid_block.attentions.0", h, cfg.heads[-1], cfg.mid_depth if cfg.mid_depth is not None else cfg.depth[-1])
         h = self._resnet("mid_block.resnets.1", h)
         rheads, rdepth = list(reversed(cfg.heads)), list(reversed(cfg.depth))
@@ -496,7 +531,7 @@ class UNetEngine:
                 hh = h
                 if self.freeu is not None and i < 2:
                     hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (hh, skip))
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (hh, skip), out_gn=cfg.up_attn[i])
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], rdepth[i])
             if i != nb - 1:

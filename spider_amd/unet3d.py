@@ -146,8 +146,15 @@ class UNet3DEngine(UNetEngine):
         BF, H, W_, C = x.shape
         B = BF // F_
         h = x
+        hp = getattr(x, "_gnp", None)
+        if hp is not None:       # statistics left by the producer of x, chunked over the same rows: re-viewed per SAMPLE (F * HW rows)
+            cr = (x.shape[0] * H * W_) // (hp.t.shape[0] * hp.nchunk)
+            hp = ops.GnPartial(hp.t.view(B, F_ * H * W_ // cr, hp.groups, 2), F_ * H * W_ // cr, hp.groups) if (F_ * H * W_) % cr == 0 else None
+        G = self.cfg.groups if self.gn_producer else None
         for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
-            a = ops.groupnorm(h.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups, 1e-5, True)
+            a = ops.groupnorm(h.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups, 1e-5, True,
+                              partial=hp)
+            hp = None
             if i == 4 and self.stream32:     # x + conv4(...): the identity is added in fp32 and the new master handed on
                 x32 = getattr(x, "_s32", None)
                 h, h32 = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
@@ -156,6 +163,10 @@ class UNet3DEngine(UNetEngine):
                 out = h.view(BF, H, W_, C)
                 out._s32 = h32.view(BF, H, W_, C)
                 return out
+            if G and i < 4:      # conv1..3 feed the next GroupNorm of this layer: its statistics come from the conv's epilogue
+                h, hp = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
+                                    gn_groups=G)
+                continue
             h = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
                             res=x.view(B, F_, H * W_, C) if i == 4 else None)
         return h.view(BF, H, W_, C)
@@ -226,7 +237,7 @@ class UNet3DEngine(UNetEngine):
         nb = len(cfg.block_out)
         for i in range(nb):
             for j in range(cfg.layers_per_block):
-                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, out_gn=True)
                 h = self._temp_conv(f"down_blocks.{i}.temp_convs.{j}", h)
                 if cfg.down_attn[i]:
                     h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cfg.heads[i], 1)
@@ -236,16 +247,16 @@ class UNet3DEngine(UNetEngine):
                 h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
                                stride=2, pad=1)
                 skips.append(h)
-        h = self._resnet("mid_block.resnets.0", h)
+        h = self._resnet("mid_block.resnets.0", h, out_gn=True)
         h = self._temp_conv("mid_block.temp_convs.0", h)
         h = self._transformer("mid_block.attentions.0", h, cfg.heads[-1], 1)
         h = self._temp_transformer("mid_block.temp_attentions.0", h, cfg.heads[-1])
-        h = self._resnet("mid_block.resnets.1", h)
+        h = self._resnet("mid_block.resnets.1", h, out_gn=True)
         h = self._temp_conv("mid_block.temp_convs.1", h)
         rheads = list(reversed(cfg.heads))
         for i in range(nb):
             for j in range(cfg.layers_per_block + 1):
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (h, skips.pop()))
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (h, skips.pop()), out_gn=True)
                 h = self._temp_conv(f"up_blocks.{i}.temp_convs.{j}", h)
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], 1)

@@ -725,3 +725,72 @@ def test_xattn_fused(ops, dev, B2, n_tok, C, n_keys):
                           bo.to(dev), B2, H, n_keys, eps=1e-5)
     close(got, ref, 2e-2, 1e-2, "xattn_fused", rel_to_std=True)
     assert float((got.float().cpu() - ref).norm() / ref.norm()) < 6e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: GroupNorm statistics from the producer of the normalised tensor (include/spider_hip.h: spider_conv_nhwc_gn,
+# spider_groupnorm_apply_nhwc, spider_gemm_gn_in). Replaces diffusers' stand-alone torch.nn.GroupNorm pass between
+# ResnetBlock2D.conv1 and norm2 / conv2 and the next norm / Transformer2DModel.norm and proj_in (custom_sd.py:634-639).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _group_sums(y, groups, cr):
+    """fp64 reference of the partials: y [B, H, W, C] (16-bit values as stored) -> [B, HW / cr, G, 2]"""
+    B, H, W, C = y.shape
+    v = y.double().reshape(B, H * W // cr, cr, groups, C // groups)
+    return torch.stack([v.sum((2, 4)), (v * v).sum((2, 4))], -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 320, 320, 1),      # 8192 rows, K = 2880: LDS-DMA kernel, 64-row tiles, no split-K -> epilogue statistics
+    (2, 32, 32, 640, 640, 1),      # 2048 rows, K = 5760: LDS-DMA kernel + split-K -> statistics from the reduce
+    (2, 32, 32, 320, 640, 1),      # channel change (conv1 of a down block)
+    (2, 16, 16, 1280, 1280, 1),    # 512 rows: split-K, 16-row chunks
+    (2, 8, 8, 1280, 1280, 1),      # 128 rows
+    (2, 64, 64, 320, 320, 2),      # stride-2 downsampler -> 32 x 32 output
+    (1, 24, 24, 640, 640, 1),      # 576 rows: 9 chunks of 64... below 2048 rows: 16-row chunks
+])
+def test_conv_gn_partials_match_output(dev, shape, dtype):
+    from spider_amd import ops
+    B, H, W, Cin, Cout, stride = shape
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(B, H, W, Cin, generator=g, device=dev).to(dtype)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g, device=dev) * (1.0 / (3 * Cin ** 0.5))).to(dtype)
+    bias = (torch.randn(Cout, generator=g, device=dev) * 0.1).to(dtype)
+    rb = (torch.randn(B, Cout, generator=g, device=dev) * 0.1).to(dtype)
+    res = torch.randn(B, (H - 1) // stride + 1, (W - 1) // stride + 1, Cout, generator=g, device=dev).to(dtype)
+    ref = ops.conv2d(x, w, bias=bias, rowbias=rb, res=res, stride=stride, pad=1)
+    out, part = ops.conv2d(x, w, bias=bias, rowbias=rb, res=res, stride=stride, pad=1, gn_groups=32)
+    assert torch.equal(out, ref), "the statistics-producing conv must write the same output"
+    HW = out.shape[1] * out.shape[2]
+    cr = HW // part.nchunk
+    assert cr in (16, 64) and part.nchunk * cr == HW and tuple(part.t.shape) == (B, HW // cr, 32, 2)
+    want = _group_sums(out.cpu(), 32, cr)
+    got = part.t.double().cpu()
+    err = (got - want).abs().max() / want.abs().max()
+    assert float(err) < 1e-5, float(err)            # fp32 sums of up to 64 x 40 values against fp64
+    # consumer 1: apply-only GroupNorm on the producer's partials == the two-pass GroupNorm (same values up to the fp32 sum order)
+    gam = (1 + 0.1 * torch.randn(Cout, generator=g, device=dev)).to(dtype)
+    bet = (0.1 * torch.randn(Cout, generator=g, device=dev)).to(dtype)
+    y_ref = ops.groupnorm(out, gam, bet, 32, 1e-5, True)
+    y = ops.groupnorm(out, gam, bet, 32, 1e-5, True, partial=part)
+    d = (y.float() - y_ref.float()).abs().max() / y_ref.float().abs().max()
+    assert float(d) < 4e-3, float(d)                      # at most a 16-bit rounding flip
+    assert float((y.float() - y_ref.float()).norm() / y_ref.float().norm()) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,HW,C,N", [(2, 4096, 320, 320), (2, 1024, 640, 640), (2, 256, 1280, 1280), (2, 64, 1280, 1280)])
+def test_gemm_with_groupnorm_on_A_matches_groupnorm_then_gemm(dev, B, HW, C, N, dtype):
+    from spider_amd import ops
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = (torch.randn(B, HW, C, generator=g, device=dev) * 1.5 + 0.3).to(dtype)
+    W = (torch.randn(N, C, generator=g, device=dev) / C ** 0.5).to(dtype)
+    bias = (torch.randn(N, generator=g, device=dev) * 0.1).to(dtype)
+    gam = (1 + 0.1 * torch.randn(C, generator=g, device=dev)).to(dtype)
+    bet = (0.1 * torch.randn(C, generator=g, device=dev)).to(dtype)
+    part = ops.groupnorm_stats(x, 32, HW // 16)
+    ref = ops.gemm(ops.groupnorm(x, gam, bet, 32, 1e-6, False), W, bias=bias)
+    got, got32 = ops.gemm_gn_in(x, W, part, gam, bet, HW, 1e-6, bias=bias, want32=True)
+    r = float((got.float() - ref.float()).norm() / ref.float().norm())
+    assert r < 3e-4, r                                    # same math; the group mean / rstd differ in their last fp32 bits
+    assert torch.equal(got, got32.to(dtype)), "the fp32 copy rounds to the 16-bit output"
