@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--no-extras", action="store_true", help="skip the secondary timings (SDXL story / UNet3D / audio / Llama-8B)")
     p.add_argument("--no-any2many", action="store_true", help="skip the one-step any-to-many extra (configs[3]/[4], 8 prompts) of the N=1 line")
     p.add_argument("--prompt-len", type=int, default=1536)
+    p.add_argument("--prompt-len-jitter", type=int, default=0,
+                   help="synthetic prompts of different lengths (prompt_len - 0..J tokens, left-padded in a batch): exercises the "
+                        "length-sorted sharding (dp.order_by_length) the data-parallel path uses; 0 = every prompt prompt_len tokens")
     p.add_argument("--new-tokens", type=int, default=128)
     p.add_argument("--denoise-steps", type=int, default=40)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,6 +112,30 @@ def launch_ranks(args, script=None, argv=None) -> int:
     return rc
 
 
+def _masked_streams(dev):
+    """Tuning aid: CU-masked HIP streams for the two passes of the pipelined schedule (hipExtStreamCreateWithCUMask).
+    SPIDER_BENCH_CUMASK_L / SPIDER_BENCH_CUMASK_U = "<n>[:<first>]": n consecutive CUs starting at `first` for the LLM / decoder stream."""
+    specs = os.environ.get("SPIDER_BENCH_CUMASK_L"), os.environ.get("SPIDER_BENCH_CUMASK_U")
+    if not any(specs):
+        return None
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def make(spec, prio):
+        if not spec:
+            return torch.cuda.Stream(device=dev, priority=prio)
+        n, _, first = spec.partition(":")
+        n, first = int(n), int(first or 0)
+        bits = [0] * 8
+        for i in range(first, min(256, first + n)):
+            bits[i // 32] |= 1 << (i % 32)
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, (ctypes.c_uint32 * 8)(*bits))
+        assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
+        return torch.cuda.ExternalStream(st.value, device=dev)
+    return make(specs[0], 0), make(specs[1], -1)
+
+
 class _PlainThinker:
     """`--llm llama3_8b`: a text decoder without multimodal rotary sections behind the thinker's `generate` surface."""
 
@@ -157,8 +184,23 @@ class Responder:
         # eos_token_id=[]: random-init weights would emit an EOS id at a random step; every response carries exactly new_tokens tokens
         self.infer = SpiderFreeInfer(thinker, self.processor, self.decoder_infer, device=dev,
                                      generate_kwargs=dict(max_new_tokens=a.new_tokens, eos_token_id=[], sync_every=a.new_tokens))
+        self.infer._streams = _masked_streams(dev)       # tuning aid (SPIDER_BENCH_CUMASK_L / _U); None = the class's own two streams
         g = torch.Generator(device=dev).manual_seed(2047 + rank)  # seed echoes Comic_Generation.py:387
-        self.prompt = torch.randint(3, cfg.vocab, (self.max_batch, a.prompt_len), generator=g, device=dev)
+        # This rank's prompts of the global request list: the world x rows synthetic prompts are sorted by expected
+        # length (dp.order_by_length: variable token counts are the main load-imbalance source), then dealt out strided, prompt i to
+        # rank i mod world; every prompt has a seed of its own (its global index), shorter ones are LEFT-padded like a processor batch.
+        from spider_amd import dp
+        world, mb, J = max(1, getattr(a, "gpus", 1)), self.max_batch, max(0, getattr(a, "prompt_len_jitter", 0))
+        lengths = [a.prompt_len - ((i * 2654435761) >> 7) % (J + 1) for i in range(world * mb)]
+        order = dp.order_by_length(lengths)
+        self.prompt_ids = [order[i] for i in dp.shard_indices(world * mb, rank, world)]
+        self.prompt_lens = [lengths[i] for i in self.prompt_ids]
+        self.prompt = torch.zeros(mb, a.prompt_len, dtype=torch.long, device=dev)
+        self.prompt_mask = torch.zeros(mb, a.prompt_len, dtype=torch.long, device=dev)
+        for b, (gid, n) in enumerate(zip(self.prompt_ids, self.prompt_lens)):
+            gg = torch.Generator(device=dev).manual_seed(2047 + gid)
+            self.prompt[b, a.prompt_len - n:] = torch.randint(3, cfg.vocab, (n,), generator=gg, device=dev)
+            self.prompt_mask[b, a.prompt_len - n:] = 1
         self.latents0 = torch.randn(self.max_batch, 4, 64, 64, generator=g, device=dev)
         self.enc_synth = torch.randn(2 * self.max_batch, 77, 768, generator=g, device=dev).to(D)
         self.overlap_ms, self.stage = None, {}
@@ -176,8 +218,8 @@ class Responder:
                 "vae_decode", "pil_conversion"]
 
     def request(self, B):
-        ids = self.prompt[:B].contiguous()
-        return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}     # what the processor emits for a text-only chat
+        # what the processor emits for a (left-padded) batch of text-only chats
+        return {"input_ids": self.prompt[:B].contiguous(), "attention_mask": self.prompt_mask[:B].contiguous()}
 
     def pack(self, res, B):
         """results of one request (B rows) -> fixed-shape device tensors for the gather"""
@@ -360,8 +402,10 @@ def measure_mfma_roofline(device):
     from spider_amd import ops
     x = torch.randn(2, 64, 64, 320, device=device).to(DIFF_DT)
     w = (torch.randn(320, 3, 3, 320, device=device) * 0.02).to(DIFF_DT)
+    # gn_groups=32: the instantiation the UNet step runs (ResnetBlock2D conv1 / conv2 leave the GroupNorm partials of their output
+    # in the epilogue, round 4)
     for _ in range(5):
-        ops.conv2d(x, w)
+        ops.conv2d(x, w, gn_groups=32)
     torch.cuda.synchronize(device)
     stream = torch.cuda.current_stream(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -369,7 +413,7 @@ def measure_mfma_roofline(device):
     g = torch.cuda.CUDAGraph()      # graph replay: the ~10 us of Python/ctypes launch overhead would otherwise be in the figure
     with torch.cuda.graph(g):
         for _ in range(n):
-            ops.conv2d(x, w)
+            ops.conv2d(x, w, gn_groups=32)
     g.replay()
     torch.cuda.synchronize(device)
     e0.record(stream)
@@ -379,9 +423,10 @@ def measure_mfma_roofline(device):
     us = e0.elapsed_time(e1) * 1e3 / n
     flops = 2 * 8192 * 320 * 2880
     tf = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,4,CONV,BM=64> (UNet 3x3 conv, 64x64 latent, 320->320, batch 2; 256 tiles of 64 x 160, no split-K)",
+    return {"bound": "mfma", "kernel": "gemm_dma_kernel<160,4,CONV,BM=64,GN> (UNet 3x3 conv, 64x64 latent, 320->320, batch 2; 256 tiles of 64 x 160, no split-K; "
+                                       "GroupNorm partial statistics of the output written by the epilogue)",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "traffic": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64>")[0], "traffic_source": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64>")[1],
+            "traffic": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64, true>")[0], "traffic_source": _unet_pmc_traffic("gemm_dma_kernel<160, 4, true, 0, 64, true>")[1],
             "avg_call_us": round(us, 2), "algorithmic_flops_per_call": flops, "calls_timed": n}
 
 
@@ -769,6 +814,7 @@ def main():
                                            f"extract_answer, SpiderDecoderInfer -> SpiderDecoder.generate -> StableDiffusionPipeline: CLIP text encoder, SD-v1.5 UNet "
                                            f"64x64 latent, PNDM {a.denoise_steps} steps ({a.denoise_steps + 1} UNet calls), CFG batch 2, guidance 7.5, VAE decode, PIL",
                                "product_class": "spider_amd.SpiderFreeInfer",
+                               "prompt_sharding": "global list sorted by expected length (dp.order_by_length), then strided over the ranks",
                                "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": extra.pop("_includes"),
                                "schedule": ("overlap (SpiderFreeInfer.submit): every step = ONE LLM pass + ONE decoder pass; the decoder pass of request k runs on one "
                                             "HIP stream beside the LLM pass of request k+1 on another (independent consecutive requests), so a step returns "

@@ -48,7 +48,7 @@ class SpiderFreeResult:
 
 class SpiderFreeInfer:
     def __init__(self, thinker, processor, decoder_infer=None, cfg=None, device="cuda:0", generate_kwargs: Optional[dict] = None,
-                 pipelined: bool = False, process_mm_info=None):
+                 pipelined: bool = False, process_mm_info=None, streams=None):
         """thinker: QwenOmniThinker (`model` of the reference); processor: the checkpoint's Qwen2_5OmniProcessor or an object with its
         three methods (apply_chat_template / __call__ / batch_decode); decoder_infer: SpiderDecoderInfer (built from `cfg` when
         omitted); generate_kwargs: extra arguments of every `thinker.generate` call (the reference passes spk / use_audio_in_video);
@@ -64,7 +64,7 @@ class SpiderFreeInfer:
         self.generate_kwargs = dict(generate_kwargs or {})
         self.process_mm_info = process_mm_info
         self.is_pipelined = bool(pipelined)
-        self._streams = None
+        self._streams = streams          # optional (LLM stream, decoder stream) of the pipelined schedule, e.g. CU-masked ones (tuning aid)
         self._pending = None             # (text_ids on host, responses, images) of the request whose decoder pass comes next
         self._warm = set()               # pass geometries that have run (and captured their hipGraphs) on one thread already
         self.last_pass_ms: Dict[str, float] = {}
