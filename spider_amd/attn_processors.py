@@ -83,8 +83,15 @@ class AttnShim:
 
 
 def processor_names(unet) -> list:
-    """the keys of diffusers' `unet.attn_processors` for this topology, in module order"""
-    blocks = sorted(k[: -len(".attn1.qkv")] for k in unet.w if k.endswith(".attn1.qkv"))
+    """the keys of diffusers' `unet.attn_processors` for this topology in ITS order: `named_children()` of UNet2DConditionModel
+    registers down_blocks, up_blocks, mid_block (Comic_Generation.py:355 walks the dict in that order and counts the up-block
+    processors it installs); inside a block family by block / attention / transformer-block index."""
+    import re
+    fam = {"down_blocks": 0, "up_blocks": 1, "mid_block": 2}
+
+    def key(b):
+        return (fam.get(b.split(".")[0], 3), [int(t) for t in re.findall(r"\d+", b)])
+    blocks = sorted((k[: -len(".attn1.qkv")] for k in unet.w if k.endswith(".attn1.qkv")), key=key)
     return [f"{b}.{a}.processor" for b in blocks for a in ("attn1", "attn2")]
 
 

@@ -1257,8 +1257,12 @@ static int gemv_env_r() {
 template <int NB, bool GU>
 static int gemv_dispatch(const void* W, const void* x, void* out, const void* bias, const void* res,
                          const void* norm_w, float eps, int N, int K, void* stream) {
-    const bool xlds = (size_t)NB * K * 2 <= 64 * 1024;
+    // tuning aid: SPIDER_GEMV_XLDS_MAX = largest activation footprint (bytes) staged in LDS; beyond it the waves read x through L2
+    // (a 38 KB LDS block -- the down projection -- cannot share a CU with a 110-147 KB workgroup of the diffusion stream)
+    static const size_t xlds_max = [] { const char* e = getenv("SPIDER_GEMV_XLDS_MAX"); return e ? (size_t)atol(e) : (size_t)64 * 1024; }();
+    const bool xlds = (size_t)NB * K * 2 <= xlds_max || norm_w != nullptr;
     if (!xlds) SPIDER_CHECK(norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
+    SPIDER_CHECK((size_t)NB * K * 2 <= 64 * 1024 || norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
     // rows per wave: 1 for the fused gate/up form (2 weight rows per output) and for small matrices (more blocks in
     // flight hide the per-block activation prologue), 2 otherwise
     static const int hoist = [] { const char* e = getenv("SPIDER_GEMV_HOIST"); return e ? atoi(e) : 1; }();
