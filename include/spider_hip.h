@@ -87,6 +87,10 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
                                   const int* kv_beg, const int* kv_end, void* out, void* ws_o, void* ws_ml,
                                   int* counters, int B, int n_q, int n_kv, int d, int T_max, float scale, int nsplit,
                                   void* stream);
+/* Tuning / test aid: 1 = the split-KV combine of spider_attn_decode_fused_bf16 runs inside the attention launch (last-arriving block,
+ * ticket + acq_rel hand-off), 0 = in the separate combine launch (default; SPIDER_ATTN_INLINE is read once, at the first call).
+ * Returns the previous setting. */
+int spider_set_attn_inline(int on);
 
 /* Batched-decode forms on a FRAGMENT-MAJOR weight copy (5..16 sequences share one weight stream; also valid for 1..4).
  * Wfm = the weight W [N, K] repacked once at load time so that every wave instruction of the kernel reads 1 KiB of contiguous

@@ -917,12 +917,12 @@ __global__ __launch_bounds__(NWV * 64) void attn_decode_fused_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int ticket = __hip_atomic_fetch_add(cnt + (size_t)b * n_kv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // acq_rel at agent scope: the compiler emits the write-back of this block's partials in front of the ticket and the
+            // invalidate behind it (the partials were also stored write-through and drained above; the fence pair is the
+            // placement-independent part of the hand-off, MI355X_MICROARCH.md "Valid forms")
+            const int ticket = __hip_atomic_fetch_add(cnt + (size_t)b * n_kv + hk, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sm_last = (ticket == nsplit - 1) ? 1 : 0;
-            if (sm_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
         }
         __syncthreads();
         if (!sm_last) return;
@@ -1316,11 +1316,21 @@ static int gemv_batch(const void* W, const void* x, void* out, const void* bias,
 
 
 #define SPIDER_ATTN_INLINE_DEFAULT 0
+// split-KV combine form of the fused decode attention: -1 = not chosen yet (SPIDER_ATTN_INLINE is read once, at the first call)
+static int g_attn_inline = -1;
 
 // ==============================================================================================
 // C ABI
 // ==============================================================================================
 extern "C" {
+
+// 1: the split-KV combine of spider_attn_decode_fused_bf16 is done by the last-arriving block of the attention launch itself; 0: by
+// the separate combine launch (default, faster on MI355X); returns the previous setting (-1: environment not read yet)
+int spider_set_attn_inline(int on) {
+    const int prev = g_attn_inline;
+    g_attn_inline = on ? 1 : 0;
+    return prev;
+}
 
 int spider_embed_bf16(const void* table, const int* ids, void* out, int rows, int H, int V, void* stream) {
     SPIDER_CHECK(rows > 0 && H > 0 && H % 8 == 0 && V > 0, "embed: bad shape (H must be a multiple of 8)");
@@ -1537,8 +1547,9 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
     // combine inline (ticket + last-arriver reduce) or by the separate combine kernel (SPIDER_ATTN_INLINE=0/1)
     // split-KV combine by the last-arriving block of the same launch (1) or by attn_combine_kernel (0); read per call so that
     // tests can exercise both forms in one process
-    const char* inl_e = getenv("SPIDER_ATTN_INLINE");
-    const int inline_combine = inl_e ? atoi(inl_e) : SPIDER_ATTN_INLINE_DEFAULT;
+    // (the environment is read once per process; spider_set_attn_inline() switches the form afterwards: tests, tuning)
+    if (g_attn_inline < 0) { const char* e = getenv("SPIDER_ATTN_INLINE"); g_attn_inline = e ? (atoi(e) != 0) : SPIDER_ATTN_INLINE_DEFAULT; }
+    const int inline_combine = g_attn_inline;
     static const int wide_env = [] { const char* e = getenv("SPIDER_ATTN_WIDE"); return e ? atoi(e) : -1; }();
     const bool wide = wide_env >= 0 ? wide_env != 0 : (T_max / nsplit >= 96);
     switch (G) {

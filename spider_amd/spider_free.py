@@ -66,7 +66,8 @@ class SpiderFreeInfer:
         self.is_pipelined = bool(pipelined)
         self._streams = streams          # optional (LLM stream, decoder stream) of the pipelined schedule, e.g. CU-masked ones (tuning aid)
         self._pending = None             # (text_ids on host, responses, images) of the request whose decoder pass comes next
-        self._warm = set()               # pass geometries that have run (and captured their hipGraphs) on one thread already
+        self._warm = set()               # LLM-pass geometries that have run (and captured their hipGraphs) on one thread already
+        self._last_dec = None            # geometry of the most recent decoder pass (the one the decoders' graphs are captured for)
         self.last_pass_ms: Dict[str, float] = {}
 
     # ------------------------------------------------------------------ request -> processor output (:461-466)
@@ -118,7 +119,9 @@ class SpiderFreeInfer:
     # ------------------------------------------------------------------ hipGraph capture needs a quiet process
     # Every engine captures its hipGraphs on first use of a geometry (decode step per batch size, UNet evaluation per latent shape,
     # tower per input grid); stream capture must not see another host thread's allocations. A pass whose geometry has not run yet is
-    # therefore executed alone, on the calling thread; only passes of known geometry are overlapped.
+    # therefore executed alone, on the calling thread; only passes of known geometry are overlapped. The diffusion engines keep ONE
+    # graph (their static buffers are sized for one CFG batch): a decoder pass is "known" only if it has the geometry of the decoder
+    # pass that ran LAST -- any other one re-captures.
     @staticmethod
     def _llm_key(inputs: dict):
         ids = inputs["input_ids"]
@@ -138,7 +141,7 @@ class SpiderFreeInfer:
         pending = self.llm_pass(inputs)
         out = self.decoder_pass(*pending)
         self._warm.add(("llm", self._llm_key(inputs)))
-        self._warm.add(("dec", self._dec_key(pending)))
+        self._last_dec = self._dec_key(pending)
         return self._unbatch(out)
 
     def __call__(self, messages=None, inputs: Optional[dict] = None):
@@ -168,11 +171,12 @@ class SpiderFreeInfer:
             self._warm.add(lkey)
             return None
         pending = self._pending
-        dkey = ("dec", self._dec_key(pending))
-        if lkey not in self._warm or dkey not in self._warm:
+        dkey = self._dec_key(pending)
+        if lkey not in self._warm or dkey != self._last_dec:
             out = self.decoder_pass(*pending)
+            self._last_dec = dkey
             self._pending = self.llm_pass(inputs)
-            self._warm.update((lkey, dkey))
+            self._warm.add(lkey)
             self.last_pass_ms = {}
             return self._unbatch(out)
         gpu = dev.type == "cuda"                    # (on a CPU device the two passes are simply two host threads: host-logic tests)
@@ -225,7 +229,7 @@ class SpiderFreeInfer:
             return None
         pending, self._pending = self._pending, None
         out = self.decoder_pass(*pending)
-        self._warm.add(("dec", self._dec_key(pending)))
+        self._last_dec = self._dec_key(pending)
         return self._unbatch(out)
 
     def pipelined(self, requests: Iterable) -> Iterator:

@@ -410,7 +410,8 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg, inline, monke
     ticket counters the way hipGraph replays do. inline = 1: the combine by the last-arriving block of the same launch
     (write-through partial stores + ticket); 0: by attn_combine_kernel."""
     from oracle.llama import LlamaCfg, rope_table
-    monkeypatch.setenv("SPIDER_ATTN_INLINE", inline)
+    from spider_amd import lib as slib
+    prev = slib.load().spider_set_attn_inline(int(inline))
     d, Tmax = 128, T + 5
     cs = rope_table(LlamaCfg(head_dim=d, rope_theta=1e6), Tmax + 8).to(dev)
     kc0, vc0 = rnd(B, n_kv, Tmax, d, seed=2).to(dev), rnd(B, n_kv, Tmax, d, seed=3).to(dev)
@@ -436,6 +437,7 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg, inline, monke
         out2 = torch.empty_like(out)
         ops.attn_decode_fused(qkv, pos, cs, kc0.clone(), vc0.clone(), kv_end, kv_beg, cnt, n_q, nsplit, ws, out2)
         assert torch.equal(out, out2), "the merge order is fixed: repeats are bit-identical whichever block arrives last"
+    slib.load().spider_set_attn_inline(0 if prev < 0 else prev)
 
 
 def test_gemm_256_tile_repeatable_under_load(ops, dev):

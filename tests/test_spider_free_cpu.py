@@ -111,6 +111,12 @@ def test_pipelining_state_machine():
     r0 = infer2.submit(inputs=two)
     assert r0.response == serial[0] and pipe2.calls[n][0] == main
     assert len(infer2.flush()) == 2
+    # the decoders keep ONE captured geometry: after the 2-row decoder pass a 1-row one runs alone again, the one after it overlaps
+    assert infer2.submit(inputs=reqs[0]) is None
+    n = len(pipe2.calls)
+    assert infer2.submit(inputs=reqs[1]).response == serial[0] and pipe2.calls[n][0] == main
+    assert infer2.submit(inputs=reqs[2]).response == serial[1] and pipe2.calls[n + 1][0] == "spider-decoder-enqueue"
+    assert infer2.flush().response == serial[2]
 
 
 def test_errors():
