@@ -295,3 +295,63 @@ def test_thinker_left_padded_batch_equals_single_prompts(dev):
     one_b = th.generate(torch.tensor([b]), torch.ones(1, len(b), dtype=torch.long), max_new_tokens=6)
     assert torch.equal(both[0], one_a[0])
     assert torch.equal(both[1, pad:], one_b[0])
+
+
+@pytest.mark.gpu
+def test_spider_free_infer_with_an_image_in_the_request(dev):
+    """configs[3] ("image + text in"): the `predict` flow (qwen2.5omni_spider_web.py:458-521) through spider_amd.SpiderFreeInfer with
+    a request that carries an image -- processor output with pixel_values / image_grid_thw -> vision tower -> mRoPE positions -> generate ->
+    batch_decode -> Decoders-Controller; the request's image reaches `ask_info['Image_ori_array']` (:494-499) and pipelined requests of
+    the same geometry give the serial result."""
+    import numpy as np
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd import SpiderDecoderInfer, SpiderFreeInfer
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    from spider_amd.qwen_omni import OmniTokenIds, QwenOmniThinker, VisionTowerConfig, VisionTowerEngine
+    from spider_amd.synthetic import SyntheticOmniProcessor
+    H = 256
+    lcfg = LlamaCfg(H, 2, 4, 2, 128, 512, 400, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
+    lw = LlamaOracle.random_weights(lcfg, seed=27, std=0.08)
+    vc = oq.VisionCfg(depth=2, hidden=64, heads=2, inter=88, in_channels=3, patch=4, temporal_patch=2, merge=2, window=16,
+                      out_hidden=H, fullatt=(1,), eps=1e-6)
+    vw = oq.random_weights(oq.vision_param_shapes(vc), seed=28)
+    tok = OmniTokenIds(image=390, video=391, audio=392, vision_start=393, audio_start=394)
+    th = QwenOmniThinker(LlamaEngine(LLMConfig(**lcfg.__dict__), lw, dev, max_batch=1, max_len=128),
+                         VisionTowerEngine(VisionTowerConfig(**vc.__dict__), vw, dev), None, tok)
+    px = torch.randn(24, vc.patch_dim, generator=torch.Generator().manual_seed(6)).bfloat16().float()
+    image = np.arange(8 * 12 * 3, dtype=np.uint8).reshape(8, 12, 3)
+
+    class Proc(SyntheticOmniProcessor):          # what Qwen2_5OmniProcessor emits for one image: placeholder tokens + patches + grid
+        def __call__(self, text=None, audios=None, images=None, videos=None, return_tensors="pt", padding=True):
+            ids = torch.tensor([[5, 6, 393] + [390] * 6 + [396, 8, 9]])
+            self.prompt_len = ids.shape[1]
+            out = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+            if images is not None:
+                out.update(pixel_values=px, image_grid_thw=torch.tensor([[1, 4, 6]]))
+            return out
+
+    seen = []
+
+    class Pipe:                                   # image decoder stand-in: records the captions it is asked for
+        def __call__(self, prompt=None, **kw):
+            seen.append(list(prompt))
+            class O:
+                images = [f"img:{p}" for p in prompt]
+            return O()
+
+    dinf = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": Pipe()}, device=str(dev))})
+    asks = []
+    gen = dinf.spider_decoder.generate
+    dinf.spider_decoder.generate = lambda samples, *a: (asks.append(dict(samples)), gen(samples, *a))[1]
+    infer = SpiderFreeInfer(th, Proc(vocab=400), dinf, device=dev, generate_kwargs=dict(max_new_tokens=6, eos_token_id=[], spk="Chelsie",
+                                                                                       use_audio_in_video=True),
+                            process_mm_info=lambda messages, use_audio_in_video: (None, [image], None))
+    msgs = [{"role": "user", "content": [{"type": "image", "image": "x.png"}, {"type": "text", "text": "what is this?"}]}]
+    res = infer(msgs)
+    direct = th.generate(torch.tensor([[5, 6, 393] + [390] * 6 + [396, 8, 9]]), None, max_new_tokens=6, eos_token_id=[], pixel_values=px,
+                         image_grid_thw=torch.tensor([[1, 4, 6]]))
+    assert torch.equal(res.text_ids, direct[0].cpu()), "the class generates exactly what the thinker generates for the processor output"
+    assert np.array_equal(asks[0]["Image_ori_array"][0], image) and asks[0]["llm_text_all"] == [res.response]
+    assert res.predictions["IMAGE"] == [f"img:{res.predictions_text['IMAGE'][0]}"] and seen[-1] == res.predictions_text["IMAGE"]
+    got = list(infer.pipelined([msgs, msgs, msgs]))
+    assert [r.response for r in got] == [res.response] * 3 and all(torch.equal(r.text_ids, res.text_ids) for r in got)
