@@ -163,7 +163,7 @@ class UNet3DEngine(UNetEngine):
                 out = h.view(BF, H, W_, C)
                 out._s32 = h32.view(BF, H, W_, C)
                 return out
-            if G and i < 4:      # conv1..3 feed the next GroupNorm of this layer: its statistics come from the conv's epilogue
+            if G and i < 4 and F_ * H * W_ <= 16384:      # conv1..3 feed the next GroupNorm of this layer: its statistics come from the conv
                 h, hp = ops.conv_ex(a.view(B, F_, H * W_, C), w[f"{n}.conv{i}.{ci}.weight"], bias=w[f"{n}.conv{i}.{ci}.bias"], pad=(1, 0),
                                     gn_groups=G)
                 continue
@@ -228,6 +228,12 @@ class UNet3DEngine(UNetEngine):
         return ops.attention(q, kv[..., :C], kv[..., C:], heads).view(y.shape)
 
     # ------------------------------------------------------------------ forward
+    def _og(self, h) -> bool:
+        """ask a resnet's conv2 for the GroupNorm statistics of its output? They feed the temporal conv's first norm, whose image is
+        one SAMPLE (frames x H x W rows): every block of that norm reduces all chunks of its image, which pays only up to ~256 chunks
+        (16 frames of 40 x 72 would be 720: measured slower than the norm's own statistics pass)."""
+        return self.gn_producer and (self.frames * h.shape[1] * h.shape[2]) // 64 <= 256
+
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B2*F, h, w, in_ch] bf16 NHWC -> eps [B2*F, h, w, out_ch] fp32."""
         cfg, w = self.cfg, self.w
@@ -237,7 +243,7 @@ class UNet3DEngine(UNetEngine):
         nb = len(cfg.block_out)
         for i in range(nb):
             for j in range(cfg.layers_per_block):
-                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, out_gn=True)
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, out_gn=self._og(h))
                 h = self._temp_conv(f"down_blocks.{i}.temp_convs.{j}", h)
                 if cfg.down_attn[i]:
                     h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cfg.heads[i], 1)
@@ -247,16 +253,16 @@ class UNet3DEngine(UNetEngine):
                 h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
                                stride=2, pad=1)
                 skips.append(h)
-        h = self._resnet("mid_block.resnets.0", h, out_gn=True)
+        h = self._resnet("mid_block.resnets.0", h, out_gn=self._og(h))
         h = self._temp_conv("mid_block.temp_convs.0", h)
         h = self._transformer("mid_block.attentions.0", h, cfg.heads[-1], 1)
         h = self._temp_transformer("mid_block.temp_attentions.0", h, cfg.heads[-1])
-        h = self._resnet("mid_block.resnets.1", h, out_gn=True)
+        h = self._resnet("mid_block.resnets.1", h, out_gn=self._og(h))
         h = self._temp_conv("mid_block.temp_convs.1", h)
         rheads = list(reversed(cfg.heads))
         for i in range(nb):
             for j in range(cfg.layers_per_block + 1):
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (h, skips.pop()), out_gn=True)
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", (h, skips.pop()), out_gn=self._og(h))
                 h = self._temp_conv(f"up_blocks.{i}.temp_convs.{j}", h)
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], 1)
