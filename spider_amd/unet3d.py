@@ -103,6 +103,13 @@ class UNet3DEngine(UNetEngine):
         # Conv3d (3,1,1) weights [O,I,3,1,1] -> [O,I,3,1]; the base class turns 4-D conv weights into OHWI = [O,3,1,I]
         w = {n: (t[..., 0] if t.ndim == 5 else t) for n, t in weights.items()}
         super().__init__(cfg.as2d(), w, device, dtype=dtype, stream32=stream32)
+        # Producer-side GroupNorm statistics (UNetEngine.gn_producer) are OFF for the video UNet: its large convs run on the 256^2 kernel
+        # (no statistics epilogue -> the fallback pass costs what the norm's own pass costs) and its temporal norms span 16 frames
+        # (720 chunks per image); measured on MI355X 50.4 ms per evaluation with them against 50.2 without. SPIDER_GN_PRODUCER_3D=1 turns
+        # them on (the path stays covered by tests/test_video_engine.py).
+        import os
+        self.gn_producer = self.gn_producer and os.environ.get("SPIDER_GN_PRODUCER_3D", "0") == "1"
+        self.gn_fuse_in = self.gn_fuse_in and self.gn_producer
         is_temporal = lambda l: ".temp_attentions." in l or l.startswith("transformer_in")
         self.cross_layers = [l for l in self.cross_layers if not is_temporal(l)]
         self.frames = 1

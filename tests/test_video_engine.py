@@ -52,10 +52,12 @@ def test_temporal_layers_match_oracle(dev, dtype):
     assert _rel(got, oracle.temp_transformer("transformer_in", x, F_, ocfg.tin_heads)) < bound
 
 
+@pytest.mark.parametrize("producer", [False, True])     # GroupNorm statistics from the producing conv (off by default for the video UNet)
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("frames,hw", [(3, (8, 12)), (4, (10, 6))])
-def test_unet3d_step_matches_oracle(dev, frames, hw, dtype):
+def test_unet3d_step_matches_oracle(dev, frames, hw, dtype, producer):
     ocfg, w, oracle, eng = _mk(dev, dtype=dtype)
+    eng.gn_producer = eng.gn_fuse_in = producer
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 4, frames, *hw, generator=g).bfloat16().float()
     enc = torch.randn(2, 77, ocfg.cross_dim, generator=g).bfloat16().float()
