@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--schedule", default="overlap", choices=["overlap", "serial"],
                    help="text_image: overlap = response k's diffusion decoder on one stream beside response k+1's LLM pass on another "
                         "(one LLM pass + one decoder pass per step either way); serial = one stream")
+    p.add_argument("--pipeline-depth", type=int, default=2, choices=[2, 3],
+                   help="--schedule overlap: requests in flight in SpiderFreeInfer.submit: 2 = [LLM pass of k+1 | decoder pass of k]; "
+                        "3 = [decode loop of k+1 | decoder pass of k, then the prompt pass of k+2] (the prompt pass rides on the decoder stream)")
     p.add_argument("--serial-decoders", action="store_true",
                    help="any2many: one SpiderDecoder.generate call per response (the reference's contract) instead of generate_batch")
     p.add_argument("--throughput-batch", type=int, default=8,
@@ -182,7 +185,8 @@ class Responder:
         thinker = QwenOmniThinker(self.llm) if cfg.mrope_section else _PlainThinker(self.llm)
         self.processor = SyntheticOmniProcessor(cfg.vocab, tags=self.TAGS, prompt_len=a.prompt_len)
         # eos_token_id=[]: random-init weights would emit an EOS id at a random step; every response carries exactly new_tokens tokens
-        self.infer = SpiderFreeInfer(thinker, self.processor, self.decoder_infer, device=dev,
+        depth = getattr(a, "pipeline_depth", 2) if hasattr(thinker, "prefill_begin") else 2
+        self.infer = SpiderFreeInfer(thinker, self.processor, self.decoder_infer, device=dev, depth=depth,
                                      generate_kwargs=dict(max_new_tokens=a.new_tokens, eos_token_id=[], sync_every=a.new_tokens))
         self.infer._streams = _masked_streams(dev)       # tuning aid (SPIDER_BENCH_CUMASK_L / _U); None = the class's own two streams
         g = torch.Generator(device=dev).manual_seed(2047 + rank)  # seed echoes Comic_Generation.py:387
@@ -240,6 +244,8 @@ class Responder:
     def respond_serial(self, batch=None):
         """One request start to finish on one stream (the latency of ONE request; the reference's schedule)."""
         B = batch or self.args.batch
+        while self.infer.flush() is not None:       # requests still in flight under the pipelined schedule: drain them first
+            pass
         self.decoder.stage_events = {}
         out = self.pack(self.infer.predict(inputs=self.request(B)), B)
         self.stage = self.decoder.stage_ms_device()
@@ -253,11 +259,12 @@ class Responder:
         if self.args.schedule == "serial":
             return self.respond_serial(B)
         if self._B != B:                            # another request geometry: drain the pipeline first
-            self.infer.flush()
+            while self.infer.flush() is not None:
+                pass
             self._B = B
         self.decoder.stage_events = {}
         res = self.infer.submit(inputs=self.request(B))
-        while res is None:                          # empty pipeline (first call): prime it; untimed warm-up work
+        while res is None:                          # empty pipeline (first call): prime it (2 or 3 submits); untimed warm-up work
             res = self.infer.submit(inputs=self.request(B))
         self.overlap_ms = self.infer.last_pass_ms or None
         self.stage = self.decoder.stage_ms_device()
@@ -798,6 +805,7 @@ def main():
             print(json.dumps(line), flush=True)
         else:
             roof = measure_roofline(resp, device)
+            sched_depth = resp.infer.depth
             extra = text_image_extras(args, resp, device)
             if not args.no_extras and not args.headline_only and world == 1:
                 del resp
@@ -819,11 +827,16 @@ def main():
                                "product_class": "spider_amd.SpiderFreeInfer",
                                "prompt_sharding": "global list sorted by expected length (dp.order_by_length), then strided over the ranks",
                                "prompts_per_gpu": a.batch, "parallelism": f"dp{world}", "timed_region_includes": extra.pop("_includes"),
-                               "schedule": ("overlap (SpiderFreeInfer.submit): every step = ONE LLM pass + ONE decoder pass; the decoder pass of request k runs on one "
-                                            "HIP stream beside the LLM pass of request k+1 on another (independent consecutive requests), so a step returns "
-                                            "the request submitted one step earlier: the first timed step consumes an LLM pass made during warm-up and the "
-                                            "last one produces an LLM pass nobody reads -- balanced, K LLM passes + K decoder passes in K timed steps; "
-                                            "serial_ms_per_response is the one-stream latency of a single request (SpiderFreeInfer.predict)"
+                               "schedule": ((f"overlap (SpiderFreeInfer.submit, depth {sched_depth}): every step = ONE prompt pass + ONE decode loop + ONE decoder pass of "
+                                             "consecutive independent requests on two HIP streams -- "
+                                             + ("stream L: decode loop of request k+1; stream U: decoder pass of request k, then the prompt pass of request "
+                                                "k+2 into the other KV cache set; a step returns the request submitted two steps earlier"
+                                                if sched_depth == 3 else
+                                                "stream L: LLM pass of request k+1; stream U: decoder pass of request k; a step returns the request "
+                                                "submitted one step earlier")
+                                             + "; the passes the first timed steps consume were made during warm-up and the last steps' passes are read by "
+                                             "nobody: balanced, K of each pass in K timed steps; serial_ms_per_response is the one-stream latency of a "
+                                             "single request (SpiderFreeInfer.predict)")
                                             if a.schedule == "overlap" else "serial (SpiderFreeInfer.predict): the two passes of a request back to back on one stream"),
                                "weights": "random-init of the true shapes"},
                     "roofline": roof, "cpu_baseline": cpu, **extra}

@@ -159,6 +159,13 @@ def finalize_greedy(tokens: torch.Tensor, eos: Optional[List[int]], pad: Optiona
     return tk, n, False
 
 
+class _PrefillHandle:
+    """what LlamaEngine.prefill_begin hands to decode_finish (the locals of `generate` at its half-way point)"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
 class GenerateOutput:
     def __init__(self, sequences, hidden_states=None):
         self.sequences = sequences
@@ -273,8 +280,16 @@ class LlamaEngine:
         c, dv, B, T = self.cfg, self.device, self.max_batch, self.max_len
         self.k_cache = torch.zeros(c.layers, B, c.n_kv, T, c.head_dim, dtype=BF16, device=dv)
         self.v_cache = torch.zeros_like(self.k_cache)
+        # KV cache sets: set 0 is the engine's cache; further sets (allocated on first use) let TWO requests be in flight at once --
+        # the prefill of one on one stream while another decodes on a second stream (SpiderFreeInfer's three-stage pipelining)
+        self._kv_sets = [(self.k_cache, self.v_cache)]
         self.cos_sin = rope_table(c, max(c.max_pos, T)).to(dv)
         self._graphs = {}
+
+    def _kv(self, cache_set: int):
+        while len(self._kv_sets) <= cache_set:
+            self._kv_sets.append((torch.zeros_like(self.k_cache), torch.zeros_like(self.v_cache)))
+        return self._kv_sets[cache_set]
 
     # ------------------------------------------------------------------ embeddings
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
@@ -282,9 +297,10 @@ class LlamaEngine:
 
     # ------------------------------------------------------------------ prefill
     def _prefill(self, h: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, kv_beg: Optional[torch.Tensor],
-                 B: int, S: int, hidden_out: Optional[list], mrope: bool = False):
+                 B: int, S: int, hidden_out: Optional[list], mrope: bool = False, cache_set: int = 0):
         """h [B*S, H] bf16; pos [B*S] (or [3, B*S] with mrope); writes KV slots, returns the final residual stream [B*S, H]."""
         c = self.cfg
+        k_cache, v_cache = self._kv(cache_set)
         sec = c.mrope_section if mrope else None
         if hidden_out is not None:
             hidden_out.append(h.view(B, S, -1).clone())
@@ -292,9 +308,9 @@ class LlamaEngine:
             x = ops.rmsnorm(h, lw["ln1"], c.eps)
             qkv = ops.gemm(x, lw["w_qkv"], bias=lw["b_qkv"])
             q = torch.empty(B, S, c.n_q, c.head_dim, dtype=BF16, device=self.device)
-            ops.rope_kv_append(qkv, pos, slot, self.cos_sin, q, self.k_cache[l], self.v_cache[l], B, S, c.n_q, c.n_kv, c.head_dim,
+            ops.rope_kv_append(qkv, pos, slot, self.cos_sin, q, k_cache[l], v_cache[l], B, S, c.n_q, c.n_kv, c.head_dim,
                                mrope_section=sec)
-            a = ops.attention_cache(q, self.k_cache[l], self.v_cache[l], Lk=S, causal=True, kv_off=0, kv_beg=kv_beg)
+            a = ops.attention_cache(q, k_cache[l], v_cache[l], Lk=S, causal=True, kv_off=0, kv_beg=kv_beg)
             h = ops.gemm(a.view(B * S, -1), lw["w_o"], res=h)
             x = ops.rmsnorm(h, lw["ln2"], c.eps)
             gu = ops.gemm(x, lw["w_gu"])
@@ -307,6 +323,7 @@ class LlamaEngine:
     # ------------------------------------------------------------------ one decode step (graph-capturable)
     def _decode_step(self, st: dict):
         c, B = self.cfg, st["B"]
+        k_cache, v_cache = st["kv"]
         h = ops.embed(self.embed_w, st["cur_ids"]) if st["embeds_in"] is None else st["embeds_in"]
         hs = st.get("hidden_buf")
         if hs is not None:
@@ -321,12 +338,12 @@ class LlamaEngine:
             else:
                 ops.gemv(lw["w_qkv"], ops.rmsnorm(h, lw["ln1"], c.eps, out=st["xn"]), bias=lw["b_qkv"], out=st["qkv"])
             if c.head_dim == 128:   # RoPE + KV append + split-KV attention + combine: one launch
-                ops.attn_decode_fused(st["qkv"], st["pos"], self.cos_sin, self.k_cache[l], self.v_cache[l], st["kv_end"],
+                ops.attn_decode_fused(st["qkv"], st["pos"], self.cos_sin, k_cache[l], v_cache[l], st["kv_end"],
                                       st["kv_beg"], st["attn_cnt"], c.n_q, st["nsplit"], st["attn_ws"], st["attn"])
             else:
-                ops.rope_kv_append(st["qkv"], st["pos"], st["slot"], self.cos_sin, st["q"], self.k_cache[l], self.v_cache[l],
+                ops.rope_kv_append(st["qkv"], st["pos"], st["slot"], self.cos_sin, st["q"], k_cache[l], v_cache[l],
                                    B, 1, c.n_q, c.n_kv, c.head_dim)
-                ops.attn_decode(st["q"], self.k_cache[l], self.v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
+                ops.attn_decode(st["q"], k_cache[l], v_cache[l], st["kv_end"], kv_beg=st["kv_beg"],
                                 nsplit=st["nsplit"], ws=st["attn_ws"], out=st["attn"])
             if fm:
                 h1 = ops.gemv_fm(lw["w_o_fm"], st["attn"], c.hidden, res=h, out=st["h1"])
@@ -352,7 +369,7 @@ class LlamaEngine:
         # advance the device-side cursors and append the token to the on-device history (index math only, one launch)
         ops.decode_advance(st["next_ids"], st["cur_ids"], st["pos"], st["slot"], st["kv_end"], st["hist"], st["n_hist"])
 
-    def _make_state(self, B: int, want_hidden: bool, want_logits: bool) -> dict:
+    def _make_state(self, B: int, want_hidden: bool, want_logits: bool, cache_set: int = 0) -> dict:
         c, dv = self.cfg, self.device
         nq_d = c.n_q * c.head_dim
         # one split-KV block per CU (256): measured on Qwen-7B shapes at T~1.6k: 2.93 / 2.90 / 3.14 ms per token at 32 / 64 / 96 splits
@@ -368,7 +385,7 @@ class LlamaEngine:
                   attn_ws=(torch.empty(B * c.n_q * nsplit * c.head_dim, dtype=torch.float32, device=dv),
                            torch.empty(B * c.n_q * nsplit * 2, dtype=torch.float32, device=dv)),
                   lm_ws=(torch.empty(B * npart, dtype=torch.float32, device=dv), i32(B * npart)),
-                  attn_cnt=i32(B * c.n_kv), embeds_in=None, hist=i32(B, self.max_len), n_hist=i32(B))
+                  attn_cnt=i32(B * c.n_kv), embeds_in=None, hist=i32(B, self.max_len), n_hist=i32(B), kv=self._kv(cache_set))
         if want_hidden:
             st["hidden_buf"] = bf(c.layers + 1, B, c.hidden)
         if want_logits:
@@ -377,14 +394,26 @@ class LlamaEngine:
 
     # ------------------------------------------------------------------ public generate
     @torch.no_grad()
-    def generate(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
-                 attention_mask: Optional[torch.Tensor] = None, max_new_tokens: Optional[int] = None,
-                 stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None, pad_token_id=None,
-                 output_hidden_states: bool = False, return_dict_in_generate: bool = False,
-                 num_beams: int = 1, do_sample: bool = False, use_cache: bool = True, output_attentions: bool = False,
-                 use_graph: bool = True, sync_every: int = 1, return_logits: bool = False,
-                 position_ids: Optional[torch.Tensor] = None, **unused):
-        """Greedy decode. Left-padded batches are described by attention_mask (0 = pad), as
+    def generate(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None, **kw):
+        """Greedy decode = `prefill_begin` + `decode_finish` back to back (arguments: see prefill_begin)."""
+        h = self.prefill_begin(input_ids, inputs_embeds, **kw)
+        return self.decode_finish(h) if isinstance(h, _PrefillHandle) else h
+
+    @torch.no_grad()
+    def prefill_begin(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None,
+                      attention_mask: Optional[torch.Tensor] = None, max_new_tokens: Optional[int] = None,
+                      stopping_criteria: Optional[Sequence[Callable]] = None, eos_token_id=None, pad_token_id=None,
+                      output_hidden_states: bool = False, return_dict_in_generate: bool = False,
+                      num_beams: int = 1, do_sample: bool = False, use_cache: bool = True, output_attentions: bool = False,
+                      use_graph: bool = True, sync_every: int = 1, return_logits: bool = False,
+                      position_ids: Optional[torch.Tensor] = None, cache_set: int = 0, **unused):
+        """First half of `generate`: the prompt pass (KV cache of `cache_set` filled, first token chosen, decode cursors set), all
+        ENQUEUED on the current stream without a host sync; returns a handle for `decode_finish`. Two requests can be in flight on
+        two streams when they use different cache sets (prefill of one beside the decode loop of the other: SpiderFreeInfer's
+        three-stage pipelining); the caller orders `decode_finish(h)` after this call's stream work. More than DECODE_ROWS rows: the
+        whole grouped generate runs here and its result is returned instead of a handle.
+
+        Greedy decode. Left-padded batches are described by attention_mask (0 = pad), as
         prepare_generation_embedding does (spider.py:1658-1661). `sync_every` > 1 checks the stop
         conditions only every N tokens (one device->host copy per check instead of per token).
         position_ids [3, B, S]: multimodal (t, h, w) rotary positions of the prompt (Qwen2.5-Omni thinker with image / audio
@@ -410,7 +439,7 @@ class LlamaEngine:
             return self._generate_grouped(input_ids, inputs_embeds, attention_mask, position_ids, B_all, dict(
                 max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria, eos_token_id=eos_token_id,
                 pad_token_id=pad_token_id, output_hidden_states=output_hidden_states, use_graph=use_graph,
-                sync_every=sync_every, return_logits=return_logits), return_dict_in_generate)
+                sync_every=sync_every, return_logits=return_logits, cache_set=cache_set), return_dict_in_generate)
         if embeds_only:
             h0 = inputs_embeds.to(device=dv, dtype=BF16).contiguous()
             B, S = h0.shape[0], h0.shape[1]
@@ -436,18 +465,20 @@ class LlamaEngine:
             if tuple(position_ids.shape) != (3, B, S):
                 raise ValueError(f"position_ids must be [3, {B}, {S}], got {tuple(position_ids.shape)}")
             pos3 = position_ids.to(device=dv, dtype=torch.int32).contiguous()
-            h = self._prefill(h0.view(B * S, -1), pos3.view(3, -1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0, mrope=True)
+            h = self._prefill(h0.view(B * S, -1), pos3.view(3, -1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0, mrope=True,
+                              cache_set=cache_set)
             # left-padded rows: the pad slots carry a dummy position (get_rope_index writes 1 there) and are masked by kv_beg
             next_pos = torch.where(am.bool()[None], pos3, torch.zeros_like(pos3)).amax(dim=(0, 2)) + 1
         else:
-            h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0)
+            h = self._prefill(h0.view(B * S, -1), pos2d.view(-1), slot2d.view(-1), kv_beg if has_pad else None, B, S, step0,
+                              cache_set=cache_set)
             next_pos = pos2d[:, -1] + 1
 
         # decode state (static buffers + captured hipGraph) is cached per (batch, outputs): repeated generate() calls
         # replay the same graph instead of re-capturing ~200 launches
-        skey = (B, bool(output_hidden_states), bool(return_logits))
+        skey = (B, bool(output_hidden_states), bool(return_logits), int(cache_set))
         if skey not in self._graphs:
-            self._graphs[skey] = [self._make_state(B, output_hidden_states, return_logits), None]
+            self._graphs[skey] = [self._make_state(B, output_hidden_states, return_logits, cache_set), None]
         st = self._graphs[skey][0]
         st["kv_beg"].copy_(kv_beg)
         last = h.view(B, S, -1)[:, -1].contiguous()
@@ -469,6 +500,48 @@ class LlamaEngine:
         tokens[:, 0].copy_(st["next_ids"])
         st["n_hist"].fill_(1)
         logits_steps = [st["logits"].clone()] if return_logits else None
+        return _PrefillHandle(B=B, S=S, st=st, skey=skey, embeds_only=embeds_only, input_ids=input_ids, max_new_tokens=max_new_tokens,
+                              stopping_criteria=stopping_criteria, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                              output_hidden_states=output_hidden_states, return_dict_in_generate=return_dict_in_generate,
+                              use_graph=use_graph, sync_every=sync_every, return_logits=return_logits, hidden_steps=hidden_steps,
+                              logits_steps=logits_steps, tokens=tokens)
+
+    @torch.no_grad()
+    def adopt(self, hd: "_PrefillHandle", cache_set: int = 0) -> "_PrefillHandle":
+        """Move a prefilled request into KV cache set `cache_set` (device copies of the prompt's K / V rows and of the decode cursors,
+        enqueued on the current stream) and return the handle bound to that set. Used by SpiderFreeInfer's three-stage pipelining: the
+        prompt pass of request k+2 fills a STAGING set while request k+1 decodes from set 0; before its own decode loop the request is
+        adopted into set 0, so every decode loop replays the ONE decode graph of set 0 (a second graph executable alive in the
+        process was measured to put the two-stream schedule into a time-slicing regime: every kernel + 10-25 us, step 513 -> 920 ms)."""
+        src = hd.skey[3]
+        if src == cache_set:
+            return hd
+        B, S = hd.B, hd.S
+        skey = hd.skey[:3] + (int(cache_set),)
+        if skey not in self._graphs:
+            self._graphs[skey] = [self._make_state(B, hd.output_hidden_states, hd.return_logits, cache_set), None]
+        dst, st = self._graphs[skey][0], hd.st
+        (ks, vs), (kd, vd) = self._kv(src), self._kv(cache_set)
+        kd[:, :B, :, :S + 1].copy_(ks[:, :B, :, :S + 1])
+        vd[:, :B, :, :S + 1].copy_(vs[:, :B, :, :S + 1])
+        for k in ("cur_ids", "next_ids", "pos", "slot", "kv_end", "kv_beg", "n_hist"):
+            dst[k].copy_(st[k])
+        dst["hist"][:, :1].copy_(st["hist"][:, :1])
+        for k in ("logits", "hidden_buf"):
+            if k in st:
+                dst[k].copy_(st[k])
+        nd = _PrefillHandle(**hd.__dict__)
+        nd.st, nd.skey, nd.tokens = dst, skey, dst["hist"][:, :hd.max_new_tokens]
+        return nd
+
+    @torch.no_grad()
+    def decode_finish(self, hd: "_PrefillHandle"):
+        """Second half of `generate`: the decode loop (one hipGraph replay per token), the stop checks and the HF bookkeeping."""
+        c, dv = self.cfg, self.device
+        B, S, st, skey, embeds_only, input_ids = hd.B, hd.S, hd.st, hd.skey, hd.embeds_only, hd.input_ids
+        max_new_tokens, stopping_criteria, eos_token_id, pad_token_id = hd.max_new_tokens, hd.stopping_criteria, hd.eos_token_id, hd.pad_token_id
+        output_hidden_states, return_dict_in_generate, use_graph = hd.output_hidden_states, hd.return_dict_in_generate, hd.use_graph
+        sync_every, return_logits, hidden_steps, logits_steps, tokens = hd.sync_every, hd.return_logits, hd.hidden_steps, hd.logits_steps, hd.tokens
         eos = _id_list(eos_token_id)
         prompt_cpu = None if embeds_only else input_ids.cpu().long()
         need_check = bool(eos) or bool(stopping_criteria)

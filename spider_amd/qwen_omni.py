@@ -639,7 +639,16 @@ class QwenOmniThinker:
                  **kw):
         """Returns [B, S + new] token ids like GenerationMixin.generate with input_ids. Length and EOS default to the
         checkpoint's generation config as in the reference's bare `model.generate(**inputs, spk=..., use_audio_in_video=True)`
-        (qwen2.5omni_spider_web.py:468): finished rows are pad-filled, the call ends when every row has emitted EOS."""
+        (qwen2.5omni_spider_web.py:468): finished rows are pad-filled, the call ends when every row has emitted EOS.
+        = `prefill_begin` + `decode_finish` back to back."""
+        return self.decode_finish(self.prefill_begin(input_ids, attention_mask, max_new_tokens, thinker_max_new_tokens, **kw))
+
+    @torch.no_grad()
+    def prefill_begin(self, input_ids, attention_mask=None, max_new_tokens: Optional[int] = None,
+                      thinker_max_new_tokens: Optional[int] = None, **kw):
+        """First half of `generate`: towers, embedding splice, rotary positions and the prompt pass of the text decoder, enqueued on
+        the current stream (LlamaEngine.prefill_begin; `cache_set` selects the KV cache the request lives in). -> handle for
+        `decode_finish`."""
         gc = getattr(self.llm, "generation_config", None) or {}
         if max_new_tokens is None:
             max_new_tokens = (thinker_max_new_tokens or gc.get("thinker_max_new_tokens") or gc.get("max_new_tokens")
@@ -653,7 +662,20 @@ class QwenOmniThinker:
                       "feature_attention_mask", "audio_feature_lengths", "use_audio_in_video", "video_second_per_grid")
         emb, pos = self.prepare_inputs(input_ids, attention_mask, **{k: kw.pop(k) for k in tower_keys if k in kw})
         kw.pop("spk", None); kw.pop("return_audio", None)                          # talker options: no speech on this path
-        out = self.llm.generate(inputs_embeds=emb, position_ids=pos, attention_mask=attention_mask, max_new_tokens=max_new_tokens, **kw)
+        h = self.llm.prefill_begin(inputs_embeds=emb, position_ids=pos, attention_mask=attention_mask, max_new_tokens=max_new_tokens, **kw)
+        return (h, input_ids)
+
+    @torch.no_grad()
+    def adopt(self, handle, cache_set: int = 0):
+        """move a prefilled request into KV cache set `cache_set` (LlamaEngine.adopt: device copies on the current stream)"""
+        h, input_ids = handle
+        return (self.llm.adopt(h, cache_set) if hasattr(h, "st") else h, input_ids)
+
+    @torch.no_grad()
+    def decode_finish(self, handle):
+        """Second half of `generate`: the decode loop; prepends the prompt ids like GenerationMixin does."""
+        h, input_ids = handle
+        out = self.llm.decode_finish(h) if hasattr(h, "st") else h          # (> 8 rows: prefill_begin already ran the grouped generate)
         if isinstance(out, torch.Tensor):
             return torch.cat([input_ids.to(out.device).long(), out], 1)
         out.sequences = torch.cat([input_ids.to(out.sequences.device).long(), out.sequences], 1)

@@ -48,12 +48,20 @@ class SpiderFreeResult:
 
 class SpiderFreeInfer:
     def __init__(self, thinker, processor, decoder_infer=None, cfg=None, device="cuda:0", generate_kwargs: Optional[dict] = None,
-                 pipelined: bool = False, process_mm_info=None, streams=None):
+                 pipelined: bool = False, process_mm_info=None, streams=None, depth: int = 2):
         """thinker: QwenOmniThinker (`model` of the reference); processor: the checkpoint's Qwen2_5OmniProcessor or an object with its
         three methods (apply_chat_template / __call__ / batch_decode); decoder_infer: SpiderDecoderInfer (built from `cfg` when
         omitted); generate_kwargs: extra arguments of every `thinker.generate` call (the reference passes spk / use_audio_in_video);
         process_mm_info: the `qwen_omni_utils.process_mm_info` callable (messages, use_audio_in_video) -> (audios, images, videos);
-        text-only messages need none. pipelined: `__call__` returns the PREVIOUS request's result (see `submit`)."""
+        text-only messages need none. pipelined: `__call__` returns an EARLIER request's result (see `submit`). depth: requests in
+        flight under `submit` -- 2 (default): [LLM pass of k+1 | decoder pass of k]; 3: [decode loop of k+1 | decoder pass of k, then the
+        prompt pass of k+2 into a staging KV cache set] (the thinker must offer prefill_begin / adopt / decode_finish). Measured on
+        MI355X: depth 3 moves the prompt pass off the LLM stream (LLM pass 510 -> 461 ms) but the step stays at ~514 ms."""
+        if depth not in (2, 3):
+            raise ValueError("depth must be 2 or 3")
+        if depth == 3 and not (hasattr(thinker, "prefill_begin") and hasattr(thinker, "decode_finish")):
+            raise ValueError("depth=3 needs a thinker with prefill_begin / decode_finish (QwenOmniThinker)")
+        self.depth = depth
         if decoder_infer is None:
             if cfg is None:
                 raise ValueError("SpiderFreeInfer needs a SpiderDecoderInfer or the config to build one from")
@@ -66,6 +74,7 @@ class SpiderFreeInfer:
         self.is_pipelined = bool(pipelined)
         self._streams = streams          # optional (LLM stream, decoder stream) of the pipelined schedule, e.g. CU-masked ones (tuning aid)
         self._pending = None             # (text_ids on host, responses, images) of the request whose decoder pass comes next
+        self._prefilled = None           # depth 3: (handle, images, llm key, cache set) of the request whose decode loop comes next
         self._warm = set()               # LLM-pass geometries that have run (and captured their hipGraphs) on one thread already
         self._last_dec = None            # geometry of the most recent decoder pass (the one the decoders' graphs are captured for)
         self.last_pass_ms: Dict[str, float] = {}
@@ -89,6 +98,30 @@ class SpiderFreeInfer:
         images = inputs.pop("_images", None)
         with ops.workspace_scope("llm"):
             text_ids = self.model.generate(**inputs, **self.generate_kwargs)
+        text_ids = text_ids.cpu()
+        resp = self.processor.batch_decode(text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        return text_ids, [r.split("\n")[-1] for r in resp], images
+
+    def prefill_pass(self, inputs: dict, cache_set: int):
+        """depth 3, first half of the LLM pass: towers + prompt pass into KV cache set `cache_set`, enqueued on the current stream."""
+        inputs = dict(inputs)
+        images = inputs.pop("_images", None)
+        with ops.workspace_scope("llm_prefill"):
+            handle = self.model.prefill_begin(**inputs, **self.generate_kwargs, cache_set=cache_set)
+        return handle, images
+
+    def _adopt(self, pre):
+        """Every decode loop runs from KV cache set 0 (ONE decode graph in the process): a request whose prompt pass filled the staging
+        set is moved there first -- device copies of its prompt K / V rows and cursors (~0.1 ms) on the CURRENT stream, i.e. ordered
+        before everything this step enqueues on either stream (the new prompt pass overwrites the staging set later in the step)."""
+        if pre is None or not hasattr(self.model, "adopt"):
+            return pre
+        return (self.model.adopt(pre[0], 0),) + tuple(pre[1:])
+
+    def decode_pass(self, handle, images):
+        """depth 3, second half of the LLM pass: decode loop + `batch_decode` + the last-line rule (ends with the device->host copy)."""
+        with ops.workspace_scope("llm"):
+            text_ids = self.model.decode_finish(handle)
         text_ids = text_ids.cpu()
         resp = self.processor.batch_decode(text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
         return text_ids, [r.split("\n")[-1] for r in resp], images
@@ -137,6 +170,8 @@ class SpiderFreeInfer:
     # ------------------------------------------------------------------ one request start to finish (the reference's schedule)
     @torch.no_grad()
     def predict(self, messages=None, inputs: Optional[dict] = None):
+        if self._prefilled is not None:
+            raise RuntimeError("a prefilled request is in flight (depth-3 pipelining): flush() before calling predict()")
         inputs = self._inputs_of(messages, inputs)
         pending = self.llm_pass(inputs)
         out = self.decoder_pass(*pending)
@@ -164,6 +199,8 @@ class SpiderFreeInfer:
         `flush()` returns the last request's result. Passes of a geometry that has not run before are executed one after the other on
         the calling thread (see above), so the pipeline is full from the third request of a kind on."""
         inputs = self._inputs_of(messages, inputs)
+        if self.depth == 3:
+            return self._submit3(inputs)
         dev = self.device
         lkey = ("llm", self._llm_key(inputs))
         if self._pending is None:                   # pipeline empty: nothing to overlap with
@@ -222,9 +259,110 @@ class SpiderFreeInfer:
             self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
         return self._unbatch(box["out"])
 
+    # ------------------------------------------------------------------ depth 3: the prompt pass rides on the decoder stream
+    def _overlap(self, on_u, on_l):
+        """run on_u() on the decoder stream from a helper host thread and on_l() on the LLM stream from this thread; both finished
+        (device included) on return. -> (result of on_u, result of on_l)"""
+        dev = self.device
+        gpu = dev.type == "cuda"
+        import contextlib
+        sL = sU = None
+        if gpu:
+            sL, sU = self._two_streams()
+            cur = torch.cuda.current_stream(dev)
+            sU.wait_stream(cur)
+            sL.wait_stream(cur)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        on = (lambda st: torch.cuda.stream(st)) if gpu else (lambda st: contextlib.nullcontext())
+        mark = (lambda i, st: ev[i].record(st)) if gpu else (lambda i, st: None)
+        box = {}
+
+        def _u():
+            try:
+                if gpu:
+                    torch.cuda.set_device(dev)
+                with on(sU):
+                    mark(0, sU)
+                    box["u"] = on_u()
+                    mark(1, sU)
+            except BaseException as e:              # surfaced on the calling thread below
+                box["err"] = e
+
+        th = threading.Thread(target=_u, name="spider-decoder-enqueue")
+        th.start()
+        try:
+            with on(sL):
+                mark(2, sL)
+                box["l"] = on_l()
+                mark(3, sL)
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        self.last_pass_ms = {"overlapped": True}
+        if gpu:
+            sU.synchronize()
+            sL.synchronize()
+            self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
+        return box["u"], box["l"]
+
+    def _submit3(self, inputs: dict):
+        """depth 3. Step k runs, concurrently: stream L / this thread: the decode loop of request k+1 (prefilled one step ago);
+        stream U / helper thread: the decoder pass of request k, THEN the prompt pass of the new request k+2 into the STAGING KV cache
+        set (request k+1 was moved from there into set 0 at the top of the step: `_adopt`) -- the decoder stream has slack (the decode
+        loop is the longer half), so the prompt pass leaves the critical stream. A request's result comes back two submits after it was
+        handed in; passes whose hipGraphs do not exist yet run alone (as in depth 2)."""
+        lkey = ("llm", self._llm_key(inputs))
+        cset = 1        # the prompt pass always fills the STAGING set; decode loops run from set 0 (decode_pass adopts the request)
+        pre, pend = self._adopt(self._prefilled), self._pending
+        B_new = int(inputs["input_ids"].shape[0])
+        if pre is None and pend is None:            # empty pipeline: the new request's prompt pass only
+            self._prefilled = (*self.prefill_pass(inputs, cset), lkey, cset, B_new)
+            self._warm.add(lkey)
+            return None
+        dgk = ("dg", pre[4], 0) if pre is not None else None           # decode graph of (rows, cache set 0)
+        dkey = self._dec_key(pend) if pend is not None else None
+        warm = (pre is not None and pend is not None and lkey in self._warm and dgk in self._warm and dkey == self._last_dec)
+        if not warm:                                 # some graph of this step does not exist yet: one pass after the other, one thread
+            out = None
+            if pend is not None:
+                out = self.decoder_pass(*pend)
+                self._last_dec = dkey
+            self._pending = self.decode_pass(pre[0], pre[1]) if pre is not None else None
+            if dgk is not None:
+                self._warm.add(dgk)
+            self._prefilled = (*self.prefill_pass(inputs, cset), lkey, cset, B_new)
+            self._warm.add(lkey)
+            self.last_pass_ms = {}
+            return None if out is None else self._unbatch(out)
+
+        def on_u():
+            res = self.decoder_pass(*pend)
+            return res, self.prefill_pass(inputs, cset)
+
+        (out, newpre), newpend = self._overlap(on_u, lambda: self.decode_pass(pre[0], pre[1]))
+        self._pending, self._prefilled = newpend, (*newpre, lkey, cset, B_new)
+        return self._unbatch(out)
+
     @torch.no_grad()
     def flush(self):
-        """Decoder pass of the last submitted request (nothing left to overlap it with)."""
+        """Drain one request: the decoder pass of the oldest request in flight (nothing left to overlap it with); with depth 3 a
+        prefilled request advances to its decode loop. Call until it returns None."""
+        if self.depth == 3:
+            if self._pending is None and self._prefilled is not None:
+                pre, self._prefilled = self._adopt(self._prefilled), None
+                self._pending = self.decode_pass(pre[0], pre[1])
+                self._warm.add(("dg", pre[4], 0))
+            if self._pending is None:
+                return None
+            pend, self._pending = self._pending, None
+            out = self.decoder_pass(*pend)
+            self._last_dec = self._dec_key(pend)
+            if self._prefilled is not None:
+                pre, self._prefilled = self._adopt(self._prefilled), None
+                self._pending = self.decode_pass(pre[0], pre[1])
+                self._warm.add(("dg", pre[4], 0))
+            return self._unbatch(out)
         if self._pending is None:
             return None
         pending, self._pending = self._pending, None
@@ -238,6 +376,8 @@ class SpiderFreeInfer:
             r = self.submit(inputs=rq) if isinstance(rq, dict) else self.submit(messages=rq)
             if r is not None:
                 yield r
-        r = self.flush()
-        if r is not None:
+        while True:
+            r = self.flush()
+            if r is None:
+                break
             yield r

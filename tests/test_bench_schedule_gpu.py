@@ -24,20 +24,24 @@ def _bench():
 
 def _args(**kw):
     base = dict(llm="qwen25_7b", batch=1, throughput_batch=0, prompt_len=192, new_tokens=12, denoise_steps=5, schedule="overlap",
-                workload="text_image", no_stream32=False, serial_decoders=False)
+                workload="text_image", no_stream32=False, serial_decoders=False, pipeline_depth=2)
     base.update(kw)
     return argparse.Namespace(**base)
 
 
-def test_overlapped_schedule_equals_serial(dev):
+@pytest.mark.parametrize("depth", [2, 3])
+def test_overlapped_schedule_equals_serial(dev, depth):
+    """depth 3: the prompt pass of request k+2 rides on the decoder stream behind the decoder pass of request k while request k+1
+    decodes from the other KV cache set"""
     bench = _bench()
-    resp = bench.Responder(_args(), dev)
+    resp = bench.Responder(_args(pipeline_depth=depth), dev)
+    assert resp.infer.depth == depth
     from spider_amd import SpiderFreeInfer
     assert isinstance(resp.infer, SpiderFreeInfer)
     torch.cuda.manual_seed(1234)                       # the pipeline draws its latents from the device's default generator
-    ref = [{k: v.clone() for k, v in resp.respond_serial().items()} for _ in range(3)]
+    ref = [{k: v.clone() for k, v in resp.respond_serial().items()} for _ in range(4)]
     torch.cuda.manual_seed(1234)
-    outs = [resp.respond() for _ in range(3)]          # call 1 primes the pipeline (passes run alone), calls 2-3 overlap the two passes
+    outs = [resp.respond() for _ in range(4)]          # call 1 primes the pipeline (passes run alone), the later calls overlap the passes
     last = resp.infer.flush()
     torch.cuda.synchronize()
     assert resp.overlap_ms and resp.overlap_ms["decoder_pass_ms"] > 0 and resp.overlap_ms["llm_pass_ms"] > 0

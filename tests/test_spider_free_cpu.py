@@ -20,6 +20,27 @@ class FakeThinker:
         return torch.cat([input_ids, new], 1)
 
 
+class FakeThinker3(FakeThinker):
+    """with the split API of QwenOmniThinker: prefill_begin / decode_finish (and the KV cache set each request lives in)"""
+
+    def __init__(self):
+        super().__init__()
+        self.pre, self.dec = [], []
+
+    def prefill_begin(self, input_ids, attention_mask=None, cache_set=0, **kw):
+        self.pre.append((threading.current_thread().name, cache_set, int(input_ids[0, 0])))
+        return ("handle", input_ids, cache_set)
+
+    def adopt(self, handle, cache_set=0):
+        self.adopted = getattr(self, "adopted", 0) + 1
+        return (handle[0], handle[1], cache_set)
+
+    def decode_finish(self, handle):
+        _, input_ids, cache_set = handle
+        self.dec.append((threading.current_thread().name, cache_set, int(input_ids[0, 0])))
+        return FakeThinker.generate(self, input_ids)
+
+
 class FakePipe:
     """StableDiffusionPipeline surface as SpiderDecoder uses it: pipe(prompt=[...], **kwargs).images"""
     def __init__(self):
@@ -130,3 +151,39 @@ def test_errors():
     infer.submit(inputs={"input_ids": torch.ones(1, 4, dtype=torch.long)}) if False else None
     with pytest.raises(RuntimeError, match="decoder failed"):
         infer.flush()
+
+
+def test_depth3_pipelining_state_machine():
+    """depth 3: [decode loop of k+1 | decoder pass of k, then the prompt pass of k+2]; results in request order, two submits late;
+    every request exactly one prompt pass, one decode loop, one decoder pass; KV cache sets alternate; cold steps on one thread."""
+    pipe, thinker = FakePipe(), FakeThinker3()
+    dinf = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": pipe}, device="cpu")})
+    proc = SyntheticOmniProcessor(vocab=500, head=3, prompt_len=4)
+    infer = SpiderFreeInfer(thinker, proc, dinf, device="cpu", depth=3)
+    ref, pipe_r, _ = make()
+    ref.processor.prompt_len = 4
+    reqs = [{"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)} for i in range(7)]
+    serial = [ref.predict(inputs=r).response for r in reqs]
+    outs = [infer.submit(inputs=r) for r in reqs]
+    assert outs[0] is None and outs[1] is None and [o.response for o in outs[2:]] == serial[:5]
+    with pytest.raises(RuntimeError, match="flush"):
+        infer.predict(inputs=reqs[0])
+    tail = []
+    while True:
+        r = infer.flush()
+        if r is None:
+            break
+        tail.append(r.response)
+    assert tail == serial[5:]
+    main, helper = threading.current_thread().name, "spider-decoder-enqueue"
+    assert [p[2] for p in thinker.pre] == [10 + i for i in range(7)] and [d[2] for d in thinker.dec] == [10 + i for i in range(7)]
+    assert [p[1] for p in thinker.pre] == [1] * 7         # every prompt pass fills the staging KV cache set ...
+    assert [d[1] for d in thinker.dec] == [0] * 7 and thinker.adopted >= 7      # ... and every decode loop runs from set 0 after an adopt
+    # submits 1-3 are cold (prompt pass / + first decode graph of set 0 / + decoder graphs and decode graph of set 1): calling thread;
+    # from the 4th on the decoder pass and the NEW request's prompt pass run on the helper thread, the decode loop on the calling one
+    assert [p[0] for p in thinker.pre] == [main, main, main, helper, helper, helper, helper]
+    assert [d[0] for d in thinker.dec] == [main] * 7
+    assert [c[0] for c in pipe.calls] == [main, helper, helper, helper, helper, main, main]
+    assert list(r.response for r in infer.pipelined(reqs[:4])) == serial[:4]
+    with pytest.raises(ValueError):
+        SpiderFreeInfer(FakeThinker(), proc, dinf, device="cpu", depth=3)
