@@ -8,7 +8,11 @@ shapes:
                    -> signal-tag routing of a text carrying exactly one <IMAGE>caption</IMAGE>
                    -> CLIP-L/14 text encoder (cond + uncond) -> SD-v1.5 UNet, 64x64 latent (512^2 image),
                       PNDM 40 steps = 41 UNet calls at CFG batch 2, guidance 7.5 -> VAE decode to 512x512x3
-A "step" is one such response per GPU (`--batch` prompts per GPU, default 1 = the reference's batch).
+The chain runs through the product class `spider_amd.SpiderFreeInfer` (the `predict` flow of qwen2.5omni_spider_web.py:458-521):
+QwenOmniThinker.generate -> batch_decode -> extract_answer -> SpiderDecoderInfer -> SpiderDecoder.generate -> StableDiffusionPipeline;
+bench.py builds random-init engines of the true shapes and a synthetic processor, hands requests to the class and packs the results.
+A "step" is one such response per GPU (`--batch` prompts per GPU, default 1 = the reference's batch); `--schedule overlap` (default) is
+the class's own pipelining of consecutive requests on two HIP streams (`SpiderFreeInfer.submit`).
 N > 1: one process per GPU (torch.distributed / RCCL), prompts sharded with no data-path collective and ONE gather
 of the padded outputs to rank 0 per step; weak scaling.
 
@@ -18,8 +22,10 @@ any GPU call); under `python -m torch.distributed.run` it reads RANK / LOCAL_RAN
 512^2 image (SD-v1.5) + 5 s of audio (AudioLDM-L) + a 16-frame 320x576 video (zeroscope) through SpiderDecoder.generate,
 then the ONE gather of the padded outputs.
 
-One JSON line on rank 0, with `roofline` (dominant kernel = the decode weight-streaming GEMV, HBM-bound, timed live
-with HIP events) and `cpu_baseline` (the fp32 CPU oracle timed on this box's host cores on a bounded sample).
+One JSON line on rank 0, with `roofline` (dominant kernel = the decode weight-streaming GEMV, HBM-bound, timed live with HIP events IN
+THE CONDITION OF THE TIMED REGION -- beside the replaying decoder stream under `--schedule overlap` -- with the stand-alone figure next
+to it) and `cpu_baseline` (the fp32 CPU oracle timed on this box's host cores on a bounded sample); at N = 1 also one timed step of the
+any-to-many workload (`any2many`: configs[3]/[4], 8 prompts).
 """
 import argparse
 import json
