@@ -59,8 +59,8 @@ class SpiderFreeInfer:
         MI355X: depth 3 moves the prompt pass off the LLM stream (LLM pass 510 -> 461 ms) but the step stays at ~514 ms."""
         if depth not in (2, 3):
             raise ValueError("depth must be 2 or 3")
-        if depth == 3 and not (hasattr(thinker, "prefill_begin") and hasattr(thinker, "decode_finish")):
-            raise ValueError("depth=3 needs a thinker with prefill_begin / decode_finish (QwenOmniThinker)")
+        if depth == 3 and not all(hasattr(thinker, m) for m in ("prefill_begin", "adopt", "decode_finish")):
+            raise ValueError("depth=3 needs a thinker with prefill_begin / adopt / decode_finish (QwenOmniThinker)")
         self.depth = depth
         if decoder_infer is None:
             if cfg is None:
@@ -114,7 +114,7 @@ class SpiderFreeInfer:
         """Every decode loop runs from KV cache set 0 (ONE decode graph in the process): a request whose prompt pass filled the staging
         set is moved there first -- device copies of its prompt K / V rows and cursors (~0.1 ms) on the CURRENT stream, i.e. ordered
         before everything this step enqueues on either stream (the new prompt pass overwrites the staging set later in the step)."""
-        if pre is None or not hasattr(self.model, "adopt"):
+        if pre is None:
             return pre
         return (self.model.adopt(pre[0], 0),) + tuple(pre[1:])
 
@@ -201,7 +201,6 @@ class SpiderFreeInfer:
         inputs = self._inputs_of(messages, inputs)
         if self.depth == 3:
             return self._submit3(inputs)
-        dev = self.device
         lkey = ("llm", self._llm_key(inputs))
         if self._pending is None:                   # pipeline empty: nothing to overlap with
             self._pending = self.llm_pass(inputs)
@@ -216,53 +215,14 @@ class SpiderFreeInfer:
             self._warm.add(lkey)
             self.last_pass_ms = {}
             return self._unbatch(out)
-        gpu = dev.type == "cuda"                    # (on a CPU device the two passes are simply two host threads: host-logic tests)
-        import contextlib
-        if gpu:
-            sL, sU = self._two_streams()
-            cur = torch.cuda.current_stream(dev)
-            sU.wait_stream(cur)
-            sL.wait_stream(cur)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        on = (lambda st: torch.cuda.stream(st)) if gpu else (lambda st: contextlib.nullcontext())
-        mark = (lambda i, st: ev[i].record(st)) if gpu else (lambda i, st: None)
-        if not gpu:
-            sL = sU = None
-        box = {}
+        out, self._pending = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
+        return self._unbatch(out)
 
-        def _dec():
-            try:
-                if gpu:
-                    torch.cuda.set_device(dev)
-                with on(sU):
-                    mark(0, sU)
-                    box["out"] = self.decoder_pass(*pending)
-                    mark(1, sU)
-            except BaseException as e:              # surfaced on the calling thread below
-                box["err"] = e
-
-        th = threading.Thread(target=_dec, name="spider-decoder-enqueue")
-        th.start()
-        try:
-            with on(sL):                            # the LLM pass's ~22 k launches fill its hardware queue: its enqueue blocks this
-                mark(2, sL)                         # thread for most of the pass, which is why the decoder has a thread of its own
-                self._pending = self.llm_pass(inputs)
-                mark(3, sL)
-        finally:
-            th.join()
-        if "err" in box:
-            raise box["err"]
-        self.last_pass_ms = {"overlapped": True}
-        if gpu:
-            sU.synchronize()
-            sL.synchronize()
-            self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
-        return self._unbatch(box["out"])
-
-    # ------------------------------------------------------------------ depth 3: the prompt pass rides on the decoder stream
     def _overlap(self, on_u, on_l):
         """run on_u() on the decoder stream from a helper host thread and on_l() on the LLM stream from this thread; both finished
-        (device included) on return. -> (result of on_u, result of on_l)"""
+        (device included) on return. -> (result of on_u, result of on_l). The LLM pass's ~22 k launches fill its hardware queue, so its
+        enqueue blocks the enqueueing thread for most of the pass: that is why the decoder pass has a thread of its own. (On a CPU
+        device the two passes are simply two host threads: host-logic tests.)"""
         dev = self.device
         gpu = dev.type == "cuda"
         import contextlib
@@ -306,6 +266,7 @@ class SpiderFreeInfer:
             self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
         return box["u"], box["l"]
 
+    # ------------------------------------------------------------------ depth 3: the prompt pass rides on the decoder stream
     def _submit3(self, inputs: dict):
         """depth 3. Step k runs, concurrently: stream L / this thread: the decode loop of request k+1 (prefilled one step ago);
         stream U / helper thread: the decoder pass of request k, THEN the prompt pass of the new request k+2 into the STAGING KV cache
