@@ -49,6 +49,7 @@ struct GemmArgs {
     int act;                // 0 none, 1 silu, 2 gelu(erf), 3 quick-gelu, 5 leaky-relu(act_param), 6 relu, 7 tanh
     float act_param;
     int geglu;              // 1: W = [value rows (N) | gate rows (N)], out[m,n] = bf16(v) * bf16(gelu(bf16(g)))  (diffusers GEGLU)
+                            // 2: W = [gate rows (N) | up rows (N)],    out[m,n] = bf16(silu(bf16(g))) * bf16(u)  (LlamaMLP's SwiGLU, prefill)
     float out_scale;        // multiplies the final value (1/rescale_output_factor)
     int splits, kt_per_split;
     // implicit-GEMM conv (NHWC): A is the image [B, Hin, Win, Cin]; K = kh*kw*Cin (tap-major, channel-minor).
@@ -362,8 +363,13 @@ __device__ __forceinline__ void geglu_out(const GemmArgs& p, f32x4 (&acc)[MT][2 
                     v = ms.y * (v - ms.x * cv[j][e]) + bv[j][e];
                     gt = ms.y * (gt - ms.x * cg[j][e]) + bg[j][e];
                 } else if (p.bias) { v += bv[j][e]; gt += bg[j][e]; }
-                v = h16_to_f32(f32_to_h16(v));
-                gt = h16_to_f32(f32_to_h16(gelu_erf_f(h16_to_f32(f32_to_h16(gt)))));
+                if (p.geglu == 2) {      // SwiGLU (LlamaMLP, modeling_llama3.py:197-199): first half = gate rows, second = up rows
+                    v = h16_to_f32(f32_to_h16(silu_f(h16_to_f32(f32_to_h16(v)))));
+                    gt = h16_to_f32(f32_to_h16(gt));
+                } else {
+                    v = h16_to_f32(f32_to_h16(v));
+                    gt = h16_to_f32(f32_to_h16(gelu_erf_f(h16_to_f32(f32_to_h16(gt)))));
+                }
                 r[j][e] = v * gt;
             }
         }
@@ -2102,20 +2108,21 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
                      float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
-    SPIDER_CHECK(ldc % 4 == 0 && ldc >= (act == 4 ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
+    const bool glu = act == 4 || act == 8;      // 4: GEGLU, 8: SwiGLU (fused gated-linear-unit epilogues: the output has N / 2 columns)
+    SPIDER_CHECK(ldc % 4 == 0 && ldc >= (glu ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
     SPIDER_CHECK((C != nullptr) != (C32 != nullptr), "gemm: exactly one of C (bf16) / C32 (fp32) must be given");
     SPIDER_CHECK(!rowbias || rows_per_group > 0, "gemm: rowbias needs rows_per_group > 0");
-    SPIDER_CHECK(act >= 0 && act <= 7, "gemm: unknown activation");
-    SPIDER_CHECK(act != 4 || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU epilogue needs bf16 output, even N, no res/rowbias");
-    SPIDER_CHECK((!res32 && !c32d) || (C && act != 4 && !(res && res32) && (size_t)M * ldc * 4 < ((size_t)1 << 31)),
+    SPIDER_CHECK(act >= 0 && act <= 8, "gemm: unknown activation");
+    SPIDER_CHECK(!glu || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU / SwiGLU epilogue needs bf16 output, even N, no res/rowbias");
+    SPIDER_CHECK((!res32 && !c32d) || (C && !glu && !(res && res32) && (size_t)M * ldc * 4 < ((size_t)1 << 31)),
                  "gemm: the fp32 residual stream needs the 16-bit output, no GEGLU, at most one residual, and < 2 GiB of fp32 rows");
     GemmArgs a{};
     a.res32 = res32; a.c32d = c32d;
     a.A = (const h16_t*)A; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.C32 = (float*)C32;
     a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = rows_per_group; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc;
-    a.geglu = act == 4;
-    a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU output has N/2 columns
+    a.geglu = act == 4 ? 1 : (act == 8 ? 2 : 0);
+    a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU / SwiGLU output has N/2 columns
     a.act = a.geglu ? 0 : act;
     a.act_param = 0.1f;             // leaky-relu slope of the GEMM form (HiFi-GAN); the conv form takes it as an argument
     a.out_scale = out_scale; a.conv = 0; a.ws = (float*)ws;

@@ -159,6 +159,9 @@ def finalize_greedy(tokens: torch.Tensor, eos: Optional[List[int]], pad: Optiona
     return tk, n, False
 
 
+_FUSE_SWIGLU = os.environ.get("SPIDER_PREFILL_SWIGLU_FUSE", "1") != "0"     # tuning aid: 0 = separate SwiGLU launch after the gate/up GEMM
+
+
 class _PrefillHandle:
     """what LlamaEngine.prefill_begin hands to decode_finish (the locals of `generate` at its half-way point)"""
 
@@ -313,8 +316,10 @@ class LlamaEngine:
             a = ops.attention_cache(q, k_cache[l], v_cache[l], Lk=S, causal=True, kv_off=0, kv_beg=kv_beg)
             h = ops.gemm(a.view(B * S, -1), lw["w_o"], res=h)
             x = ops.rmsnorm(h, lw["ln2"], c.eps)
-            gu = ops.gemm(x, lw["w_gu"])
-            act = ops.swiglu(gu)
+            if _FUSE_SWIGLU:
+                act = ops.gemm(x, lw["w_gu"], act="swiglu")  # gate / up projection with SwiGLU in the epilogue (no [S, 2I] round trip)
+            else:
+                act = ops.swiglu(ops.gemm(x, lw["w_gu"]))
             h = ops.gemm(act, lw["w_down"], res=h)
             if hidden_out is not None:
                 hidden_out.append(h.view(B, S, -1).clone())

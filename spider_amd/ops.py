@@ -15,7 +15,7 @@ import torch
 from . import lib as _lib
 
 BF16 = torch.bfloat16
-ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "leaky_relu": 5, "relu": 6, "tanh": 7}
+ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "leaky_relu": 5, "relu": 6, "tanh": 7, "swiglu": 8}
 
 
 def _stream() -> int:
@@ -351,7 +351,8 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     N, K = W.shape
     assert A.shape[-1] == K, f"gemm: A[..., {A.shape[-1]}] vs W[{N},{K}]"
     M = A.numel() // K
-    n_out = N // 2 if act == "geglu" else N    # GEGLU epilogue: W = [value rows | gate rows], output has N/2 columns
+    # GEGLU epilogue: W = [value rows | gate rows]; SwiGLU epilogue (LlamaMLP): W = [gate rows | up rows]; the output has N/2 columns
+    n_out = N // 2 if act in ("geglu", "swiglu") else N
     if out is None:
         out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else dt, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
