@@ -101,15 +101,9 @@ class ClapTextEngine:
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
-        import glob, json, os
-        from safetensors import safe_open
-        cfg = ClapTextConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype)
+        from .checkpoint import load_state_dict, read_config
+        cfg = ClapTextConfig.from_hf_dict(read_config(path))
+        return cls(cfg, load_state_dict(path), device, dtype=dtype)
 
     def _encode_one(self, ids: torch.Tensor) -> torch.Tensor:
         """ids [n] int32 (no padding) -> pooled+projected embedding [1, proj_dim] bf16."""

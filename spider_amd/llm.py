@@ -262,20 +262,15 @@ class LlamaEngine:
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", max_batch=1, max_len=4096):
-        """Load an HF safetensors checkpoint directory (config.json + *.safetensors)."""
-        import glob
-        import json
-        import os
-        from safetensors import safe_open
-        cfg = LLMConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    kk = k.replace("thinker.model.", "model.").replace("thinker.lm_head.", "lm_head.")
-                    if kk.startswith("model.") or kk.startswith("lm_head."):
-                        w[kk] = sf.get_tensor(k)
-        eng = cls(cfg, w, device, max_batch, max_len)
+        """Load an HF checkpoint directory: config.json + model.safetensors(.index.json + shards) or pytorch_model.bin
+        (spider_amd/checkpoint.py). From a Qwen2.5-Omni directory only `thinker.model.*` / `thinker.lm_head.*` are read."""
+        from .checkpoint import load_state_dict, read_config
+
+        def keep(k: str):
+            kk = k.replace("thinker.model.", "model.").replace("thinker.lm_head.", "lm_head.")
+            return kk if kk.startswith(("model.", "lm_head.")) else None
+        cfg = LLMConfig.from_hf_dict(read_config(path))
+        eng = cls(cfg, load_state_dict(path, keep=keep), device, max_batch, max_len)
         eng.generation_config = read_generation_config(path)
         return eng
 

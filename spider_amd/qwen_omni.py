@@ -112,16 +112,14 @@ class OmniTokenIds:
 
 
 def _load_safetensors(path: str, prefixes: Sequence[str]) -> Dict[str, torch.Tensor]:
-    import glob, os
-    from safetensors import safe_open
-    w = {}
-    for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-        with safe_open(f, framework="pt", device="cpu") as sf:
-            for k in sf.keys():
-                for p in prefixes:
-                    if k.startswith(p):
-                        w[k[len(p):]] = sf.get_tensor(k)
-    return w
+    from .checkpoint import load_state_dict
+
+    def keep(k: str):
+        for p in prefixes:
+            if k.startswith(p):
+                return k[len(p):]
+        return None
+    return load_state_dict(path, keep=keep)
 
 
 def _cache_get(cache: dict, key, make, limit: int = 8):

@@ -74,7 +74,8 @@ class SpiderDecoder:
         cls = registry.get_model_class(self.diffusion_types.get(modality) or {"IMAGE": "sd", "VIDEO": "vd", "AUDIO": "ad"}[modality])
         if cls is None:
             return None
-        pipe = cls.from_pretrained(ckpt, torch_dtype=self.diffusion_dtype).to(self.device)   # base_model.py:207-219 (torch.float16)
+        # base_model.py:207-219 (torch.float16); the engines are built ON this rank's device (one process per GPU), not moved to it
+        pipe = cls.from_pretrained(ckpt, torch_dtype=self.diffusion_dtype, device=self.device).to(self.device)
         self._pipes[modality] = pipe
         return pipe
 

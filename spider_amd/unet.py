@@ -246,16 +246,10 @@ class UNetEngine:
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
-        """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors."""
-        import glob, json, os
-        from safetensors import safe_open
-        cfg = UNetConfig.from_diffusers_dict(json.load(open(os.path.join(path, "config.json"))))
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
+        """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors / .bin (spider_amd/checkpoint.py)."""
+        from .checkpoint import load_state_dict, read_config
+        cfg = UNetConfig.from_diffusers_dict(read_config(path))
+        return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32)
 
     # ------------------------------------------------------------------ per-call preparation
     def prepare(self, timesteps: torch.Tensor, enc: Optional[torch.Tensor], added: Optional[dict] = None,

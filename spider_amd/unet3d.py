@@ -130,15 +130,10 @@ class UNet3DEngine(UNetEngine):
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
-        import glob, json, os
-        from safetensors import safe_open
-        cfg = UNet3DConfig.from_diffusers_dict(json.load(open(os.path.join(path, "config.json"))))
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
+        """diffusers layout; cerspense/zeroscope_v2_576w publishes diffusion_pytorch_model.bin only (spider_amd/checkpoint.py)."""
+        from .checkpoint import load_state_dict, read_config
+        cfg = UNet3DConfig.from_diffusers_dict(read_config(path))
+        return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32)
 
     def prepare(self, timesteps, enc, added=None, class_labels=None, frames: int = 1):
         """enc [B2, 77, cross]; the UNet input of step() is [B2*frames, h, w, C] (sample-major, frame-minor)."""

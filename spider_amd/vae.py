@@ -104,8 +104,8 @@ class VAEDecoderEngine:
         """diffusers layout: <path>/config.json + *.safetensors. `scaling` overrides the checkpoint's scaling_factor (the
         reference's SD pipeline hard-codes 0.18215, custom_sd.py:388; its AudioLDM pipeline reads the config,
         custom_ad.py:289)."""
-        import glob, json, os
-        from safetensors import safe_open
+        import json, os
+        from .checkpoint import load_state_dict
         cj = os.path.join(path, "config.json")
         cj_d = json.load(open(cj)) if os.path.exists(cj) else {}
         cfg = VAEConfig.from_diffusers_dict(cj_d) if cj_d else VAEConfig.sd15()
@@ -113,11 +113,8 @@ class VAEDecoderEngine:
             dtype = torch.bfloat16      # diffusers runs such a VAE in fp32 (it overflows IEEE half): take the wide-range 16-bit format
         if scaling is not None:
             cfg.scaling = scaling
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    w[k] = sf.get_tensor(k)
+        # the decoder half only: the encoder's tensors are never read
+        w = load_state_dict(path, keep=lambda k: k if k.startswith(("decoder.", "post_quant_conv.")) else None)
         return cls(cfg, w, device, dtype=dtype)
 
     def _gn(self, n, x, silu):

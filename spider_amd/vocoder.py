@@ -97,15 +97,9 @@ class HifiGanEngine:
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16):
-        import glob, json, os
-        from safetensors import safe_open
-        cfg = HifiGanConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
-        w = {}
-        for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    w[k] = sf.get_tensor(k)
-        return cls(cfg, w, device, dtype=dtype)
+        from .checkpoint import load_state_dict, read_config
+        cfg = HifiGanConfig.from_hf_dict(read_config(path))
+        return cls(cfg, load_state_dict(path), device, dtype=dtype)
 
     @property
     def config(self):   # the pipeline reads vocoder.config.{upsample_rates, sampling_rate, model_in_dim} (custom_ad.py:490-500)

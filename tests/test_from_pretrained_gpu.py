@@ -1,0 +1,117 @@
+"""GPU: a checkpoint DIRECTORY through the loaders the reference calls -- `cls.from_pretrained(ckpt, torch_dtype=torch.float16)`
+(base_model.py:207-219, spider_decoder.py:109) -- on a tiny synthetic Stable-Diffusion directory written in the published diffusers
+layout: unet/ as a torch pickle (.bin) next to an fp16 variant that must not be read, vae/ with encoder tensors beside the decoder's,
+text_encoder/ as an indexed two-shard safetensors set, tokenizer/ as CLIP BPE files, scheduler/scheduler_config.json. The loaded
+pipeline must equal, bit for bit, one assembled directly from the same tensors; SpiderDecoder must reach it from its config dict."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import save_file
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip_bpe_files(d):
+    """A CLIP tokenizer with an empty merge table: byte alphabet, the same with the end-of-word mark, the two specials."""
+    from tokenizers.pre_tokenizers import ByteLevel
+    os.makedirs(d, exist_ok=True)
+    chars = sorted(ByteLevel.alphabet())
+    vocab = chars + [c + "</w>" for c in chars] + ["<|startoftext|>", "<|endoftext|>"]
+    json.dump({t: i for i, t in enumerate(vocab)}, open(os.path.join(d, "vocab.json"), "w"))
+    open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"model_max_length": 77, "bos_token": "<|startoftext|>", "eos_token": "<|endoftext|>", "unk_token": "<|endoftext|>",
+               "pad_token": "<|endoftext|>", "tokenizer_class": "CLIPTokenizer"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    return len(vocab)
+
+
+def _write_sd_directory(root):
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from oracle.unet import UNetCfg, random_unet_weights
+    n_vocab = _clip_bpe_files(os.path.join(root, "tokenizer"))
+    uc, vc = UNetCfg.tiny(), VAECfg.tiny()
+    cc = CLIPCfg(n_vocab, 64, 2, 2, 128, 77)
+    wu, wv, wc = random_unet_weights(uc, seed=1), random_weights(vae_param_shapes(vc), seed=2), random_weights(clip_param_shapes(cc), seed=3)
+    half = lambda w: {k: v.to(torch.float16).contiguous() for k, v in w.items()}
+    # unet/: pickle + a misleading fp16 variant (zeros) that a glob over *.safetensors would pick up
+    os.makedirs(os.path.join(root, "unet"))
+    json.dump({"_class_name": "UNet2DConditionModel", "in_channels": 4, "out_channels": 4, "block_out_channels": [64, 128, 128],
+               "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+               "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"], "attention_head_dim": 2,
+               "layers_per_block": 2, "cross_attention_dim": 64, "norm_num_groups": 32, "sample_size": 16,
+               "use_linear_projection": False}, open(os.path.join(root, "unet", "config.json"), "w"))
+    torch.save(half(wu), os.path.join(root, "unet", "diffusion_pytorch_model.bin"))
+    save_file({k: torch.zeros_like(v) for k, v in half(wu).items()}, os.path.join(root, "unet", "diffusion_pytorch_model.fp16.safetensors"))
+    # vae/: the published file holds encoder + quant_conv tensors too
+    os.makedirs(os.path.join(root, "vae"))
+    json.dump({"_class_name": "AutoencoderKL", "latent_channels": vc.latent, "out_channels": vc.out_ch, "block_out_channels": list(vc.block_out),
+               "layers_per_block": vc.layers_per_block, "norm_num_groups": vc.groups, "scaling_factor": 0.18215},
+              open(os.path.join(root, "vae", "config.json"), "w"))
+    extra = {"encoder.conv_in.weight": torch.randn(8, 3, 3, 3).half(), "quant_conv.weight": torch.randn(8, 8, 1, 1).half()}
+    save_file({**half(wv), **extra}, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    # text_encoder/: two shards behind an index, plus the position_ids buffer old exports carry
+    os.makedirs(os.path.join(root, "text_encoder"))
+    json.dump({"architectures": ["CLIPTextModel"], "vocab_size": cc.vocab, "hidden_size": cc.hidden, "num_hidden_layers": cc.layers,
+               "num_attention_heads": cc.heads, "intermediate_size": cc.inter, "max_position_embeddings": cc.max_pos,
+               "layer_norm_eps": 1e-5, "hidden_act": "quick_gelu"}, open(os.path.join(root, "text_encoder", "config.json"), "w"))
+    hc = half(wc)
+    names = sorted(hc)
+    shard = {n: ("model-00001-of-00002.safetensors" if i % 2 == 0 else "model-00002-of-00002.safetensors") for i, n in enumerate(names)}
+    for f in set(shard.values()):
+        t = {n: hc[n] for n in names if shard[n] == f}
+        if f.startswith("model-00001"):
+            t["text_model.embeddings.position_ids"] = torch.arange(77)[None]
+        save_file(t, os.path.join(root, "text_encoder", f))
+    json.dump({"metadata": {}, "weight_map": shard}, open(os.path.join(root, "text_encoder", "model.safetensors.index.json"), "w"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump({"_class_name": "PNDMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "skip_prk_steps": True, "steps_offset": 1, "set_alpha_to_one": False},
+              open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    json.dump({"_class_name": "StableDiffusionPipeline"}, open(os.path.join(root, "model_index.json"), "w"))
+    return (uc, vc, cc), (half(wu), half(wv), hc)
+
+
+def test_sd_directory_loads_and_equals_direct_assembly(dev, tmp_path):
+    from transformers import CLIPTokenizer
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.pipelines import StableDiffusionPipeline
+    from spider_amd.schedulers import PNDMScheduler
+    from spider_amd.unet import UNetConfig, UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    root = str(tmp_path / "sd")
+    (uc, vc, cc), (wu, wv, wc) = _write_sd_directory(root)
+    pipe = StableDiffusionPipeline.from_pretrained(root, torch_dtype=torch.float16, device=dev)
+    assert pipe.unet.dtype == torch.float16 and pipe.unet.stream32
+    assert isinstance(pipe.scheduler, PNDMScheduler) and pipe.sample_size == 16
+    assert not any(k.startswith(("encoder.", "quant_conv.")) for k in pipe.vae.w)        # the decoder half only
+    vcfg = VAEConfig(**vc.__dict__)
+    vcfg.scaling = 0.18215
+    ref = StableDiffusionPipeline(UNetEngine(UNetConfig(**uc.__dict__), wu, dev, dtype=torch.float16, stream32=True),
+                                  VAEDecoderEngine(vcfg, wv, dev, dtype=torch.float16),
+                                  CLIPTextEngine(CLIPTextConfig(cc.vocab, cc.hidden, cc.layers, cc.heads, cc.inter, cc.max_pos), wc, dev,
+                                                 dtype=torch.float16),
+                                  CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer")), sample_size=16)
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    a = pipe(prompt=["a red door"], num_inference_steps=6, latents=lat, output_type="np").images
+    b = ref(prompt=["a red door"], num_inference_steps=6, latents=lat, output_type="np").images
+    assert np.isfinite(a).all() and a.std() > 1e-3          # the zero-filled fp16 variant was not what got loaded
+    assert np.array_equal(a, b)
+
+
+def test_spider_decoder_reaches_the_directory_from_its_config(dev, tmp_path):
+    """Decoders-Controller config -> pipeline class by registry name -> from_pretrained(ckpt) on THIS rank's device
+    (spider_decoder.py:104-119)."""
+    from spider_amd.spider_decoder import SpiderDecoder
+    root = str(tmp_path / "sd")
+    _write_sd_directory(root)
+    dec = SpiderDecoder(diffusion_modules={"IMAGE": {"type": "sd", "ckpt": root}}, device=dev,
+                        decode_kwargs={"IMAGE": {"num_inference_steps": 4}})
+    out = dec.decode_image({"llm_text_res": ["a red door"]}, num_inference_steps=4)
+    assert len(out) == 1 and out[0].size == (64, 64)
+    assert str(dec._pipes["IMAGE"].unet.device) == str(dev)
+    # a directory that is not a checkpoint fails with the path in the message, not with a KeyError deep in an engine
+    bad = SpiderDecoder(diffusion_modules={"IMAGE": {"type": "sd", "ckpt": str(tmp_path / "nothing")}}, device=dev)
+    with pytest.raises(FileNotFoundError, match="nothing"):
+        bad.decode_image({"llm_text_res": ["x"]})
