@@ -284,12 +284,6 @@ int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, floa
  * the random per-key keep decision): bit j % 64 of word j / 64 = (u[j] < thr) for j < n_valid, 0 beyond. u [n] fp32 on the device. */
 int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, float thr, void* stream);
 
-/* Weight prefetch into the 256 MB Infinity Cache: `blocks` workgroups read `bytes` at p (16-byte aligned) and drop them, so that the
- * kernel which streams these weights shortly afterwards -- on any XCD -- finds them on die (the reference has no counterpart: torch
- * streams the UNet's 1.7 GB of weights cold from HBM every step, custom_sd.py:634-639). nt != 0: streaming-hint loads. sink: one
- * device word, never written in practice (keeps the loads alive); may be null. Host-side scheduling: spider_amd/prefetch.py. */
-int spider_prefetch_weights(const void* p, long bytes, int blocks, int nt, void* sink, void* stream);
-
 /* ======================= IEEE-half (f16) instantiations of the diffusion-side operators =======================
  * The reference runs its diffusion decoders in torch.float16 (spider_decoder.py:109,114,130,136,153,159; base_model.py:211;
  * StoryDiffusion/Comic_Generation.py:313). Every operator above that the UNet / VAE / text-encoder engines use also exists with

@@ -772,32 +772,6 @@ __global__ __launch_bounds__(256) void pack_keep_kernel(const float* __restrict_
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && idx < ((n + 63) / 64) * 64) words[idx >> 6] = m;
 }
-
-// Weight prefetch into the Infinity Cache (spider_prefetch_weights): a few blocks read `bytes` at p and drop them. The 256 MB
-// memory-side cache keeps what passes through it, so a consumer that runs shortly afterwards on ANY XCD finds the lines there:
-// measured (scripts/exp/small_gemm_floor.py) a weight-streaming 64^2-tile linear costs 0.38 us per K tile on HBM-cold weights,
-// 0.26 on weights resident in the Infinity Cache, 0.25 on weights in its own L2. nt != 0 reads with the streaming hint (less
-// pollution of the reading XCD's L2). `sink` is never written (the sum of finite loads is not the magic pattern in practice; it
-// only keeps the loads alive).
-typedef uint32_t pf_u32x4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__global__ __launch_bounds__(256) void prefetch_kernel(const pf_u32x4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned acc = 0;
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-        pf_u32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-    }
-    for (; i < n16; i += stride) {
-        const pf_u32x4 v = NT ? __builtin_nontemporal_load(p + i) : p[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    }
-    if (acc == 0x9E3779B9u && sink) atomicOr(sink, 1u);
-}
 #endif
 
 static int gn_nchunk(int HW) {
@@ -1100,18 +1074,6 @@ int SPIDER_FN(spider_softmax_rows_f32)(const float* x, void* y, int rows, int n,
 int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, float mul, float add, int clamp01, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: bad shape");
     nhwc_to_nchw_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(x, y, B, C, HW, mul, add, clamp01);
-    SPIDER_LAUNCH_OK();
-    return 0;
-}
-
-// Read `bytes` at p (16-byte aligned) with `blocks` workgroups and drop them: brings a weight into the Infinity Cache ahead of the
-// kernel that streams it (host side: spider_amd/prefetch.py). sink: one device word that is never written in practice (may be null).
-int spider_prefetch_weights(const void* p, long bytes, int blocks, int nt, void* sink, void* stream) {
-    SPIDER_CHECK(p != nullptr && bytes > 0 && blocks > 0 && blocks <= 1024 && ((uintptr_t)p & 15) == 0, "prefetch_weights: bad arguments");
-    const size_t n16 = (size_t)bytes / 16;
-    if (n16 == 0) return 0;
-    if (nt) prefetch_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>((const pf_u32x4*)p, n16, (unsigned*)sink);
-    else prefetch_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>((const pf_u32x4*)p, n16, (unsigned*)sink);
     SPIDER_LAUNCH_OK();
     return 0;
 }

@@ -80,7 +80,6 @@ SIGNATURES = {
     "spider_lincomb_f32": (_i, [_vp, _vp, _i, _vp, _l, _vp]),
     "spider_softmax_rows_f32_bf16": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "spider_pack_keep_bits_f32": (_i, [_vp, _vp, _i, _i, _f, _vp]),
-    "spider_prefetch_weights": (_i, [_vp, _l, _i, _i, _vp, _vp]),
     "spider_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
 }
 

@@ -134,18 +134,6 @@ def prebuild_tiled(weights, max_rows: int = 64 << 20) -> int:
     return n
 
 
-# Weight hook (spider_amd/prefetch.py): when set, every weight-streaming operator below reports the tensor its kernel is about to
-# read -- the tile-major copy where that is what the kernel gets -- BEFORE it enqueues the kernel. One hook per process (the UNet
-# engines trace / capture one forward at a time); None costs one global read per call.
-_WEIGHT_HOOK = None
-
-
-def set_weight_hook(fn):
-    global _WEIGHT_HOOK
-    prev, _WEIGHT_HOOK = _WEIGHT_HOOK, fn
-    return prev
-
-
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -372,8 +360,6 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     o32 = torch.empty(out.shape, dtype=torch.float32, device=A.device) if want32 else None
     if res32 is not None:
         _chk(res32, torch.float32, "res32")
-    if _WEIGHT_HOOK is not None:
-        _WEIGHT_HOOK(W if wt is None else wt)
     _lib.call(f"spider_gemm_{sfx}", _p(A), _p(W if wt is None else wt), _p(c16), _p(c32), _p(bias), _p(res), _p(rowbias), rows_per_group,
               M, N, K, K, n_out, ACT[act], float(out_scale), int(wt is not None), _p(res32), _p(o32), _p(_workspace(A.device)), WS_BYTES,
               _stream())
@@ -409,8 +395,6 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
     if res is not None:
         _chk(res, dt, "res")
     wt = _tiled(Wf, M)
-    if _WEIGHT_HOOK is not None:
-        _WEIGHT_HOOK(Wf if wt is None else wt)
     _lib.call(f"spider_gemm_ln_{sfx}", _p(A), _p(Wf if wt is None else wt), _p(out), _p(colsum), _p(colbias), _p(res), M, N, K, n_out,
               ACT[act], float(eps), int(wt is not None), _p(_workspace(A.device)), WS_BYTES, _stream())
     return out
@@ -432,8 +416,6 @@ def xattn_fused(x, mq_fm, mo_fm, colsum, colbias, bias_o, B2, heads, n_keys, eps
     o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
     if x32 is not None:
         _chk(x32, torch.float32, "x32")
-    if _WEIGHT_HOOK is not None:
-        _WEIGHT_HOOK(mq_fm); _WEIGHT_HOOK(mo_fm)
     _lib.call(f"spider_xattn_fused_{sfx}", _p(x), _p(mq_fm), _p(mo_fm), _p(colsum), _p(colbias), _p(bias_o), _p(out), B2, n_tok, C,
               heads, n_keys, float(eps), _p(x32), _p(o32), _stream())
     return (out, o32) if want32 else out
@@ -514,8 +496,6 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     args = (_p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
             Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
             _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES, _stream())
-    if _WEIGHT_HOOK is not None:
-        _WEIGHT_HOOK(w if wt is None else wt)
     part = None
     HWo = Ho * Wo
     # (every block of the consuming GroupNorm reduces the partials of its image: beyond ~256 chunks -- the UNet3D's temporal norms
@@ -550,8 +530,6 @@ def gemm_gn_in(A, W, part: GnPartial, gamma, beta, HW: int, eps: float, bias=Non
     out = torch.empty(*A.shape[:-1], N, dtype=dt, device=A.device)
     o32 = torch.empty(out.shape, dtype=torch.float32, device=A.device) if want32 else None
     wt = _tiled(W, M)
-    if _WEIGHT_HOOK is not None:
-        _WEIGHT_HOOK(W if wt is None else wt)
     _lib.call(f"spider_gemm_gn_in_{sfx}", _p(A), _p(W if wt is None else wt), _p(out), _p(bias), M, N, K, N, int(wt is not None),
               _p(part.t), part.nchunk, _p(gamma), _p(beta), part.groups, float(eps), HW, _p(o32), _stream())
     return (out, o32) if want32 else out

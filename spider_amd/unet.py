@@ -162,9 +162,6 @@ class UNetEngine:
         # A operand (round 4; tuning aids: SPIDER_GN_PRODUCER=0 / SPIDER_GN_FUSE_IN=0 restore the stand-alone GroupNorm passes)
         self.gn_producer = ops.GN_PRODUCER
         self.gn_fuse_in = os.environ.get("SPIDER_GN_FUSE_IN", "1") != "0"
-        # weights prefetched into the Infinity Cache a bounded window ahead of the captured step (spider_amd/prefetch.py)
-        self.weight_prefetch = os.environ.get("SPIDER_WEIGHT_PREFETCH", "0") != "0"
-        self._prefetcher = None
         self.xattn_min_rows = int(os.environ.get("SPIDER_XATTN_MIN_ROWS", "1024"))
         self.xw: Dict[str, dict] = {}
         for b in list(self.ln):
@@ -552,20 +549,12 @@ class UNetEngine:
             self._x_static.copy_(x)
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
-            pf = None
             with torch.cuda.stream(s):
-                if self.weight_prefetch:
-                    # warm-up outside capture, traced: the weights this geometry's kernels read, in launch order (prefetch.py)
-                    from .prefetch import WeightPrefetcher
-                    pf = WeightPrefetcher(self.device)
-                    pf.record(lambda: self._forward(self._x_static))
-                else:
-                    self._forward(self._x_static)       # warm-up outside capture
+                self._forward(self._x_static)       # warm-up outside capture
             torch.cuda.current_stream(self.device).wait_stream(s)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._out_static = self._forward(self._x_static) if pf is None else pf.run(lambda: self._forward(self._x_static))
-            self._prefetcher = pf
+                self._out_static = self._forward(self._x_static)
             self._graph_key = key
         self._x_static.copy_(x)
         self._graph.replay()
