@@ -293,6 +293,57 @@ class LlamaEngine:
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
         return ops.embed(self.embed_w, ids.to(device=self.device, dtype=torch.int32).contiguous())
 
+    def resize_token_embeddings(self, new_num_tokens: Optional[int] = None, std: float = 0.02, seed: Optional[int] = None):
+        """`PreTrainedModel.resize_token_embeddings` as the reference calls it after adding its signal tokens to the tokenizer
+        (spider.py:177: `self.llama_model.resize_token_embeddings(len(self.llama_tokenizer))`): the input embedding and -- unless
+        tied -- the lm_head grow (or shrink) to `new_num_tokens` rows. Old rows keep their values; new rows are N(0, std^2), the
+        `_init_weights` rule of the pinned transformers 4.43 (modeling_llama3.py:405-414) -- a trained Spider checkpoint then
+        overwrites them (`load_token_rows`). Captured decode graphs and the vocabulary-sized buffers are rebuilt on the next call.
+        Returns the embedding matrix, like the HF method returns the embedding module."""
+        c = self.cfg
+        old = self.embed_w.shape[0]
+        if new_num_tokens is None or new_num_tokens == old:
+            return self.embed_w
+        if new_num_tokens <= 0:
+            raise ValueError(f"resize_token_embeddings: new_num_tokens={new_num_tokens}")
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=self.device).manual_seed(seed)
+
+        def grow(w):
+            out = torch.empty(new_num_tokens, w.shape[1], dtype=w.dtype, device=w.device)
+            n = min(old, new_num_tokens)
+            out[:n] = w[:n]
+            if new_num_tokens > old:
+                out[old:] = (torch.randn(new_num_tokens - old, w.shape[1], generator=gen, device=w.device, dtype=torch.float32) * std).to(w.dtype)
+            return out.contiguous()
+        tied = self.lm_head is self.embed_w
+        self.embed_w = grow(self.embed_w)
+        self.lm_head = self.embed_w if tied else grow(self.lm_head)
+        import dataclasses
+        self.cfg = dataclasses.replace(c, vocab=new_num_tokens)     # (the config object may be shared with other engines)
+        self._vocab_changed()
+        return self.embed_w
+
+    def load_token_rows(self, first_row: int, embed_rows: Optional[torch.Tensor] = None, lm_head_rows: Optional[torch.Tensor] = None):
+        """Overwrite rows [first_row, first_row + n) of the input embedding and / or the lm_head: the trained rows a Spider
+        checkpoint stores for its signal tokens (the reference keeps `old_embed_tokens` / `old_lm_head` copies for exactly
+        this split, spider.py:165-173)."""
+        for w, rows, name in ((self.embed_w, embed_rows, "embed_rows"), (self.lm_head, lm_head_rows, "lm_head_rows")):
+            if rows is None:
+                continue
+            if rows.ndim != 2 or rows.shape[1] != w.shape[1] or first_row < 0 or first_row + rows.shape[0] > w.shape[0]:
+                raise ValueError(f"load_token_rows: {name} {tuple(rows.shape)} does not fit rows [{first_row}, ...) of {tuple(w.shape)}")
+            w[first_row:first_row + rows.shape[0]] = rows.to(device=w.device, dtype=w.dtype)
+        self._vocab_changed()
+
+    def _vocab_changed(self):
+        """the lm_head moved or changed: drop what was derived from it (fragment-major copy, captured decode graphs, lm_head
+        workspaces and logits buffers, all keyed in self._graphs)"""
+        if self.fm_batch:
+            self.lm_head_fm = ops.repack_fm16(self.lm_head, self.norm)
+        self._graphs = {}
+
     # ------------------------------------------------------------------ prefill
     def _prefill(self, h: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, kv_beg: Optional[torch.Tensor],
                  B: int, S: int, hidden_out: Optional[list], mrope: bool = False, cache_set: int = 0):

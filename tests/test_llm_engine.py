@@ -270,3 +270,48 @@ def test_batched_fold_path_tokens_match_single_row_path(dev, golden_dir):
             assert float((lb - ls).norm() / ls.norm()) < 2.5e-2, (b, t)
     # the two reference-generated rows: all tokens equal on the batched path too
     assert torch.equal(batched.sequences[:2, S:S + T].cpu(), torch.from_numpy(z["tokens"])[:, :T])
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_resize_token_embeddings_equals_an_engine_built_on_the_grown_tables(dev, tied):
+    """spider.py:177: the tokenizer gains signal tokens, `resize_token_embeddings(len(tokenizer))` grows embedding + lm_head, the
+    checkpoint's trained rows are loaded; prompts may then contain the new ids and the model may emit them. The resized engine
+    must generate exactly what an engine constructed from the grown tables generates (also after a graph was captured at the
+    old size), and the fp32 oracle on the grown tables must agree."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    V0, V1 = 300, 311
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, V0, 10000.0, None, 1e-6, False, 256, tied)
+    w = LlamaOracle.random_weights(ocfg, seed=5, std=0.08)
+    eng = LlamaEngine(LLMConfig(**ocfg.__dict__), w, dev, max_batch=2, max_len=64)
+    ids0 = torch.randint(3, V0, (2, 7), generator=torch.Generator().manual_seed(1))
+    before = eng.generate(input_ids=ids0, max_new_tokens=6)            # captures a decode graph at the old vocabulary
+    g = torch.Generator().manual_seed(9)
+    new_embed = (torch.randn(V1 - V0, 256, generator=g) * 0.3).bfloat16()
+    new_head = (torch.randn(V1 - V0, 256, generator=g) * 0.3).bfloat16()
+    ret = eng.resize_token_embeddings(V1, seed=3)
+    assert ret.shape == (V1, 256) and eng.cfg.vocab == V1 and eng.embed_w.shape[0] == V1 and eng.lm_head.shape[0] == V1
+    assert (eng.lm_head is eng.embed_w) == tied
+    assert torch.equal(eng.embed_w[:V0].cpu(), w["model.embed_tokens.weight"].bfloat16())        # old rows untouched
+    assert float(eng.embed_w[V0:].float().std()) > 0                                             # new rows initialised, not zeros
+    assert eng.resize_token_embeddings(V1) is eng.embed_w                                        # same size: no-op
+    eng.load_token_rows(V0, embed_rows=new_embed, lm_head_rows=None if tied else new_head)
+    w2 = dict(w)
+    w2["model.embed_tokens.weight"] = torch.cat([w["model.embed_tokens.weight"].bfloat16(), new_embed]).float()
+    w2["lm_head.weight"] = w2["model.embed_tokens.weight"] if tied else torch.cat([w["lm_head.weight"].bfloat16(), new_head]).float()
+    cfg2 = LLMConfig(**{**ocfg.__dict__, "vocab": V1})
+    ref_eng = LlamaEngine(cfg2, w2, dev, max_batch=2, max_len=64)
+    ids = ids0.clone()
+    ids[0, 3], ids[1, 5] = V0 + 2, V1 - 1                               # signal-token ids inside the prompts
+    a = eng.generate(input_ids=ids, max_new_tokens=8, return_dict_in_generate=True, return_logits=True)
+    b = ref_eng.generate(input_ids=ids, max_new_tokens=8, return_dict_in_generate=True, return_logits=True)
+    assert torch.equal(a.sequences, b.sequences) and torch.equal(a.logits, b.logits)
+    assert a.logits.shape[-1] == V1
+    oracle = LlamaOracle(LlamaCfg(**{**ocfg.__dict__, "vocab": V1}), w2)
+    ref_tok, ref_logits = oracle.greedy(ids, 8, return_logits=True)
+    _check_tokens(a.sequences[:, 7:].cpu(), ref_tok, ref_logits.numpy(), margin_tol=0.08)
+    # shrinking back restores the old behaviour exactly
+    eng.resize_token_embeddings(V0)
+    assert torch.equal(eng.generate(input_ids=ids0, max_new_tokens=6), before)
+    with pytest.raises(ValueError):
+        eng.load_token_rows(V0 - 1, embed_rows=new_embed)
