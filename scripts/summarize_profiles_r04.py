@@ -45,13 +45,15 @@ unet = {}
 if ku:
     rows = list(csv.DictReader(open(ku)))
     ours = [r for r in rows if "at::native" not in r["Name"] and "rocclr" not in r["Name"]]
-    evals = 22.0
+    # evaluations in the trace = calls of conv_in's kernel (exactly one per UNet evaluation): warm-up + capture warm-up + 20 replays
+    # + the checksum step of scripts/prof_unet.py
+    evals = float(next((r["Calls"] for r in ours if "conv_small_cin_kernel" in r["Name"]), 22))
     n_launch = sum(float(r["Calls"]) for r in ours) / evals
     t_ms = sum(float(r["TotalDurationNs"]) for r in ours) / 1e6 / evals
     log = open(f"{G}/{tag}_prof_unet.log").read() if os.path.exists(f"{G}/{tag}_prof_unet.log") else ""
     step = [l for l in log.splitlines() if l.startswith("unet step ms")]
     with open(f"{P}/{tag}_unet_step_stats.txt", "w") as f:
-        f.write("UNET_DTYPE=f16 UNET_STREAM32=1 rocprofv3 --kernel-trace --stats -- python scripts/prof_unet.py 20   (SD-v1.5 UNet, f16 + fp32 residual stream, CFG batch 2, 64x64 latent; 22 evaluations)\n")
+        f.write(f"UNET_DTYPE=f16 UNET_STREAM32=1 rocprofv3 --kernel-trace --stats -- python scripts/prof_unet.py 20   (SD-v1.5 UNet, f16 + fp32 residual stream, CFG batch 2, 64x64 latent; {evals:.0f} evaluations)\n")
         f.write(f"launches per UNet step: {n_launch:.0f}   kernel time per step: {t_ms:.3f} ms   wall (under the profiler): {step[-1] if step else 'n/a'}\n")
         for r in ours[:30]:
             f.write(f"{short(r['Name']):80s} n/step {float(r['Calls']) / evals:6.1f} avg_us {float(r['AverageNs']) / 1e3:8.1f} "

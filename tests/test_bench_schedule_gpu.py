@@ -73,3 +73,41 @@ def test_spider_free_infer_contract(dev):
     assert len(got) == 4 and all(r.response == got[0].response for r in got)
     with pytest.raises(ValueError):
         infer()
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_soak_changing_geometry(dev, depth):
+    """28 chat requests whose prompt lengths change in runs (every change is a new LLM geometry: its first pass must NOT be
+    overlapped -- it captures graphs), some answered twice in a row: the pipelined results equal `predict` of the same requests
+    bit for bit (response text, token ids, image bytes), arrive in request order, and the device memory in use stops growing once
+    every geometry has been seen."""
+    bench = _bench()
+    resp = bench.Responder(_args(prompt_len=96, new_tokens=8, denoise_steps=3, pipeline_depth=depth), dev)
+    infer = resp.infer
+    words = [12, 12, 12, 30, 30, 12, 12, 50, 50, 50, 12, 30, 30, 30, 50, 12, 12, 12, 12, 30, 50, 50, 12, 12, 30, 30, 12, 12]
+    reqs = [[{"role": "user", "content": " ".join(f"w{(7 * i + j) % 91}" for j in range(n))}] for i, n in enumerate(words)]
+    import numpy as np
+
+    def key(r):
+        return r.response, r.text_ids.cpu(), np.asarray(r.predictions["IMAGE"][0]).copy()
+
+    torch.cuda.manual_seed(77)
+    ref = [key(infer(m)) for m in reqs]
+    torch.cuda.synchronize()
+    torch.cuda.manual_seed(77)
+    got, mem = [], []
+    for r in infer.pipelined(reqs):
+        got.append(key(r))
+        mem.append(torch.cuda.memory_allocated(dev))
+    assert len(got) == len(reqs)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g[0] == r[0], f"request {i}: response text differs"
+        assert torch.equal(g[1], r[1]), f"request {i}: token ids differ"
+        assert np.array_equal(g[2], r[2]), f"request {i}: image differs"
+    assert len({g[0] for g in got}) > 3, "the requests are different requests"
+    # all three geometries were seen by request 10; allow the allocator one block of slack afterwards
+    assert max(mem[12:]) - min(mem[12:]) <= 64 << 20, [m >> 20 for m in mem]
+    # and a second sweep over the same requests (everything warm: every pass overlapped) is still identical
+    torch.cuda.manual_seed(77)
+    again = [key(r) for r in infer.pipelined(reqs)]
+    assert all(a[0] == r[0] and torch.equal(a[1], r[1]) and np.array_equal(a[2], r[2]) for a, r in zip(again, ref))
