@@ -56,7 +56,12 @@ class SyntheticOmniProcessor:
     """Stand-in for the checkpoint's Qwen2_5OmniProcessor (qwen2.5omni_spider_web.py:461-471) where no vocabulary files exist
     (bench.py, tests): same three methods `SpiderFreeInfer` calls. Random-init weights emit no signal tags, so `batch_decode` renders a
     row as one response line that carries exactly one caption per modality in `tags`, the caption built from the row's first
-    GENERATED ids (the prompt length is remembered from the last `__call__`, or given as `prompt_len`)."""
+    GENERATED ids. Where the generated part starts is read from the row itself, like a chat template's assistant marker: `__call__`
+    ends every prompt with the id ASSISTANT (1, which the word hash never produces) and `batch_decode` takes what follows its last
+    occurrence -- no state carried from one request to the next, so requests may be decoded in another order than they were
+    tokenised (SpiderFreeInfer depth 3 tokenises request k+2 before it decodes request k+1). Rows without the marker (prompts handed
+    over as ready-made `input_ids`, bench.py) start at the fixed `prompt_len`."""
+    ASSISTANT = 1
 
     def __init__(self, vocab=152064, tags=("IMAGE",), prompt_len=None, head=8):
         self.vocab, self.tags, self.prompt_len, self.head = vocab, tuple(tags), prompt_len, head
@@ -72,14 +77,16 @@ class SyntheticOmniProcessor:
 
     def __call__(self, text=None, audios=None, images=None, videos=None, return_tensors="pt", padding=True):
         ids = self._tok([text] if isinstance(text, str) else list(text), padding="longest").input_ids
+        ids = torch.cat([ids, torch.full((ids.shape[0], 1), self.ASSISTANT, dtype=ids.dtype)], 1)
         self.prompt_len = ids.shape[1]
         return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
 
     def batch_decode(self, text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
-        S = self.prompt_len or 0
         names = {"IMAGE": "scene", "AUDIO": "sound", "VIDEO": "clip"}
         out = []
         for row in text_ids:
+            marks = (torch.as_tensor(row) == self.ASSISTANT).nonzero()
+            S = int(marks[-1]) + 1 if marks.numel() else (self.prompt_len or 0)
             head = " ".join(str(int(t)) for t in row[S:S + self.head])
             out.append("system\nuser\nassistant\nSure. " + " ".join(f"<{m}>{names.get(m, 'item')} {head}</{m}>" for m in self.tags))
         return out

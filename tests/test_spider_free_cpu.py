@@ -16,7 +16,7 @@ class FakeThinker:
 
     def generate(self, input_ids, attention_mask=None, **kw):
         self.calls.append((threading.current_thread().name, tuple(input_ids.shape), dict(kw)))
-        new = (input_ids[:, :1] + torch.arange(1, 5)[None]) % 97
+        new = (input_ids[:, :1] + torch.arange(11, 15)[None]) % 97      # (never 1: the synthetic processor's assistant marker)
         return torch.cat([input_ids, new], 1)
 
 
