@@ -1,13 +1,17 @@
 """Long fp32 ORACLE loops, run once in the build container, so that the GPU suite can compare full denoising loops without spending
 its time budget on CPU work:
 
-    python tests/golden/make_oracle_loops.py            # ~1 h on 8 cores
+    python tests/golden/make_oracle_loops.py [sdxl] [zeroscope]      # sdxl: ~5 min, zeroscope: ~1.5 h on 8 cores
 
   oracle_loop_sdxl50.npz   SDXL UNet (oracle.unet.UNetCfg.sdxl(), weights random_unet_weights(seed=4)), CFG batch 2 on a
                            [1, 4, 64, 64] latent (512^2), 50 DDIM steps, guidance 5.0 -- the scheduler / step count / guidance
                            of the story decoder (Comic_Generation.py:316-317, 440) without the
                            consistent-self-attention coins: inputs (latent, prompt states, pooled states, time ids) and the
                            fp32 latents after the loop, plus the latents after steps 1, 10 and 25.
+
+  oracle_loop_zeroscope40_f16.npz  zeroscope UNet3D (oracle.unet3d.UNet3DCfg.zeroscope(), weights random_unet3d_weights(seed=6)),
+                           CFG batch 2 on the [1, 4, 16, 40, 72] latent of configs[3] / [4], 40 DDIM steps, guidance 9.0
+                           (spider_decoder.py:122-143, custom_vd.py:664-697): checksums of the seeded inputs and the fp32 latents after 1, 20, 40 steps.
 
 These vectors are produced by the CPU RESTATEMENT (oracle/unet.py), not by the reference: diffusers is absent from the image
 (SURVEY.md section 8c), so they pin the HIP engine to the oracle over a whole loop -- the quantity north_star names -- and leave the
@@ -58,6 +62,45 @@ def sdxl_loop(steps=50, guidance=5.0, keep=(1, 10, 25)):
                         latents_out=x.numpy(), steps=steps, guidance=guidance, weights_seed=4, **kept)
 
 
+def zeroscope_inputs(frames=16):
+    g = torch.Generator().manual_seed(23)
+    lat = torch.randn(1, 4, frames, 40, 72, generator=g)
+    enc = torch.randn(2, 77, 1024, generator=g).bfloat16().float()
+    return lat, enc
+
+
+@torch.no_grad()
+def zeroscope_loop(frames=16, steps=40, guidance=9.0, keep=(1, 20)):
+    """configs[3] / [4]'s video decoder: zeroscope UNet3D, [1, 4, 16, 40, 72] latents, 40 DDIM steps, guidance 9.0
+    (spider_decoder.py:122-143 -> custom_vd.py:664-697; the scheduler sees the frames as batch, :684-692)."""
+    from oracle.unet3d import UNet3DCfg, UNet3DOracle, random_unet3d_weights
+    ocfg = UNet3DCfg.zeroscope()
+    unet, sched = UNet3DOracle(ocfg, random_unet3d_weights(ocfg, seed=6)), DDIMOracle()
+    lat, enc = zeroscope_inputs(frames)
+    ts = sched.set_timesteps(steps)
+    x = lat * sched.init_noise_sigma
+    kept = {}
+    t0 = time.time()
+    for i, t in enumerate(ts):
+        e = unet.forward(torch.cat([x] * 2), t, enc)
+        eu, ec = e.chunk(2)
+        eps = eu + guidance * (ec - eu)
+        B, C, Fr, H, W = x.shape
+        flat = lambda v: v.permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, W)
+        x = sched.step(flat(eps), t, flat(x))[None, :].reshape(B, Fr, C, H, W).permute(0, 2, 1, 3, 4)
+        if i + 1 in keep:
+            kept[f"after_{i + 1}"] = x.numpy().copy()
+        print(f"step {i + 1}/{steps} t={int(t)} |x|={float(x.norm()):.4f} ({time.time() - t0:.0f} s)", flush=True)
+    # (0.7 MB per latent tensor: the seeded inputs are not stored, only their checksums -- the test regenerates them)
+    np.savez_compressed(os.path.join(OUT, f"oracle_loop_zeroscope{steps}_f{frames}.npz"), latents_in_sum=float(lat.double().sum()),
+                        enc_sum=float(enc.double().sum()), latents_out=x.contiguous().numpy(), steps=steps, guidance=guidance,
+                        frames=frames, weights_seed=6, **kept)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 8)))
-    sdxl_loop()
+    which = sys.argv[1:] or ["sdxl", "zeroscope"]
+    if "sdxl" in which:
+        sdxl_loop()
+    if "zeroscope" in which:
+        zeroscope_loop()

@@ -115,3 +115,130 @@ def test_spider_decoder_reaches_the_directory_from_its_config(dev, tmp_path):
     bad = SpiderDecoder(diffusion_modules={"IMAGE": {"type": "sd", "ckpt": str(tmp_path / "nothing")}}, device=dev)
     with pytest.raises(FileNotFoundError, match="nothing"):
         bad.decode_image({"llm_text_res": ["x"]})
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the video and audio decoders' directories (spider_decoder.py:122-166 -> base_model.py:207-219)
+
+def _roberta_bpe_files(d):
+    """A RoBERTa tokenizer with an empty merge table: specials, the byte alphabet, <mask>."""
+    from tokenizers.pre_tokenizers import ByteLevel
+    os.makedirs(d, exist_ok=True)
+    vocab = ["<s>", "<pad>", "</s>", "<unk>"] + sorted(ByteLevel.alphabet()) + ["<mask>"]
+    json.dump({t: i for i, t in enumerate(vocab)}, open(os.path.join(d, "vocab.json"), "w"))
+    open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"model_max_length": 32, "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>", "pad_token": "<pad>",
+               "cls_token": "<s>", "sep_token": "</s>", "mask_token": "<mask>", "tokenizer_class": "RobertaTokenizer"},
+              open(os.path.join(d, "tokenizer_config.json"), "w"))
+    return len(vocab)
+
+
+def _half(w):
+    return {k: v.to(torch.float16).contiguous() for k, v in w.items()}
+
+
+def _write_component(root, name, config, weights, as_bin=False):
+    os.makedirs(os.path.join(root, name))
+    json.dump(config, open(os.path.join(root, name, "config.json"), "w"))
+    stem = "diffusion_pytorch_model" if name in ("unet", "vae") else ("pytorch_model" if as_bin else "model")
+    if as_bin:
+        torch.save(weights, os.path.join(root, name, stem + ".bin"))
+    else:
+        save_file(weights, os.path.join(root, name, stem + ".safetensors"))
+
+
+_DDIM = {"_class_name": "DDIMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+         "num_train_timesteps": 1000, "clip_sample": False, "set_alpha_to_one": False, "steps_offset": 1}
+
+
+def test_video_directory_bin_only_loads_and_equals_direct_assembly(dev, tmp_path):
+    """cerspense/zeroscope_v2_576w ships torch pickles only (unet/diffusion_pytorch_model.bin, vae/…bin, text_encoder/pytorch_model.bin)."""
+    from transformers import CLIPTokenizer
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from oracle.unet3d import UNet3DCfg, random_unet3d_weights
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.pipelines import TextToVideoSDPipeline
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    root = str(tmp_path / "vd")
+    n_vocab = _clip_bpe_files(os.path.join(root, "tokenizer"))
+    uc = UNet3DCfg(4, 4, (64, 128, 128), (True, True, False), (False, True, True), 32, 1, 64, 32, 8)   # transformer_in: always 8 heads in diffusers
+    vc, cc = VAECfg.tiny(), CLIPCfg(n_vocab, 64, 2, 2, 128, 77)
+    wu, wv, wc = _half(random_unet3d_weights(uc, 6)), _half(random_weights(vae_param_shapes(vc), 8)), _half(random_weights(clip_param_shapes(cc), 7))
+    _write_component(root, "unet", {"_class_name": "UNet3DConditionModel", "in_channels": 4, "out_channels": 4, "block_out_channels": [64, 128, 128],
+                                    "down_block_types": ["CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"],
+                                    "up_block_types": ["UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"], "attention_head_dim": 32,
+                                    "layers_per_block": 1, "cross_attention_dim": 64, "norm_num_groups": 32, "sample_size": 8}, wu, as_bin=True)
+    _write_component(root, "vae", {"_class_name": "AutoencoderKL", "latent_channels": vc.latent, "out_channels": vc.out_ch,
+                                   "block_out_channels": list(vc.block_out), "layers_per_block": vc.layers_per_block,
+                                   "norm_num_groups": vc.groups, "scaling_factor": 0.18215}, wv, as_bin=True)
+    _write_component(root, "text_encoder", {"vocab_size": cc.vocab, "hidden_size": cc.hidden, "num_hidden_layers": cc.layers,
+                                            "num_attention_heads": cc.heads, "intermediate_size": cc.inter, "max_position_embeddings": cc.max_pos,
+                                            "layer_norm_eps": 1e-5, "hidden_act": "quick_gelu"}, wc, as_bin=True)
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump(_DDIM, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    pipe = TextToVideoSDPipeline.from_pretrained(root, torch_dtype=torch.float16, device=dev)
+    assert pipe.unet.stream32 and isinstance(pipe.scheduler, DDIMScheduler) and pipe.sample_size == 8
+    ref = TextToVideoSDPipeline(UNet3DEngine(UNet3DConfig(**uc.__dict__), wu, dev, dtype=torch.float16, stream32=True),
+                                VAEDecoderEngine(VAEConfig(**vc.__dict__), wv, dev, dtype=torch.float16),
+                                CLIPTextEngine(CLIPTextConfig(cc.vocab, cc.hidden, cc.layers, cc.heads, cc.inter, cc.max_pos), wc, dev,
+                                               dtype=torch.float16),
+                                CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer")), DDIMScheduler(**{k: v for k, v in _DDIM.items() if not k.startswith("_")}),
+                                sample_size=8)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(3))
+    kw = dict(prompt=["a boat at sea"], num_frames=4, num_inference_steps=4, height=32, width=32, latents=lat, output_type="pt")
+    a, b = pipe(**kw).frames, ref(**kw).frames
+    assert torch.isfinite(a).all() and float(a.std()) > 1e-3 and torch.equal(a, b)
+
+
+def test_audio_directory_loads_and_equals_direct_assembly(dev, tmp_path):
+    """cvssp/audioldm-l-full layout: unet/ (class-conditioned, per-block cross_attention_dim list), vae/ (mel), text_encoder/
+    (ClapTextModelWithProjection), tokenizer/ (RoBERTa BPE), vocoder/ (SpeechT5HifiGan), scheduler/."""
+    from transformers import RobertaTokenizer
+    from oracle.audio import ClapTextCfg, HifiGanCfg, clap_param_shapes, hifigan_param_shapes, random_weights
+    from oracle.clip_vae import VAECfg, vae_param_shapes
+    from oracle.unet import UNetCfg, random_unet_weights
+    from spider_amd.clap import ClapTextConfig, ClapTextEngine
+    from spider_amd.pipelines import AudioLDMPipeline
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.unet import UNetConfig, UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    from spider_amd.vocoder import HifiGanConfig, HifiGanEngine
+    root = str(tmp_path / "ad")
+    n_vocab = _roberta_bpe_files(os.path.join(root, "tokenizer"))
+    ccfg = ClapTextCfg(n_vocab + 3, 64, 2, 4, 128, 40, 48, 1e-12, 1)
+    ucfg = UNetCfg.tiny_audio()
+    vcfg = VAECfg(latent=8, out_ch=1, block_out=(64, 128, 128), layers_per_block=1, scaling=0.9227)
+    hcfg = HifiGanCfg(16, 16000, 64, (5, 4, 2), (16, 16, 8), (3, 7), ((1, 3, 5), (1, 3, 5)), 0.1, False)
+    wu, wv = _half(random_unet_weights(ucfg, 22)), _half(random_weights(vae_param_shapes(vcfg), 23))
+    wc, wh = _half(random_weights(clap_param_shapes(ccfg), 21)), _half(random_weights(hifigan_param_shapes(hcfg), 24))
+    _write_component(root, "unet", {"_class_name": "UNet2DConditionModel", "in_channels": 8, "out_channels": 8, "block_out_channels": [64, 128, 128],
+                                    "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+                                    "up_block_types": ["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], "attention_head_dim": [2, 4, 4],
+                                    "layers_per_block": 2, "cross_attention_dim": [64, 128, 128], "norm_num_groups": 32, "sample_size": 16,
+                                    "class_embed_type": "simple_projection", "projection_class_embeddings_input_dim": 48,
+                                    "class_embeddings_concat": True, "use_linear_projection": False}, wu)
+    _write_component(root, "vae", {"_class_name": "AutoencoderKL", "latent_channels": 8, "out_channels": 1, "block_out_channels": [64, 128, 128],
+                                   "layers_per_block": 1, "norm_num_groups": 32, "scaling_factor": 0.9227}, wv)
+    _write_component(root, "text_encoder", {"architectures": ["ClapTextModelWithProjection"], "vocab_size": ccfg.vocab, "hidden_size": 64,
+                                            "num_hidden_layers": 2, "num_attention_heads": 4, "intermediate_size": 128,
+                                            "max_position_embeddings": 40, "projection_dim": 48, "layer_norm_eps": 1e-12, "pad_token_id": 1}, wc)
+    _write_component(root, "vocoder", {"architectures": ["SpeechT5HifiGan"], "model_in_dim": 16, "sampling_rate": 16000,
+                                       "upsample_initial_channel": 64, "upsample_rates": [5, 4, 2], "upsample_kernel_sizes": [16, 16, 8],
+                                       "resblock_kernel_sizes": [3, 7], "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5]],
+                                       "leaky_relu_slope": 0.1, "normalize_before": False}, wh)
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump(_DDIM, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    pipe = AudioLDMPipeline.from_pretrained(root, torch_dtype=torch.float16, device=dev)
+    assert pipe.unet.stream32 and pipe.vae.cfg.scaling == 0.9227 and pipe.vocoder.cfg.sampling_rate == 16000
+    ref = AudioLDMPipeline(VAEDecoderEngine(VAEConfig(**vcfg.__dict__), wv, dev, dtype=torch.float16),
+                           ClapTextEngine(ClapTextConfig(**ccfg.__dict__), wc, dev, dtype=torch.float16),
+                           RobertaTokenizer.from_pretrained(os.path.join(root, "tokenizer")),
+                           UNetEngine(UNetConfig(**ucfg.__dict__), wu, dev, dtype=torch.float16, stream32=True),
+                           DDIMScheduler(**{k: v for k, v in _DDIM.items() if not k.startswith("_")}),
+                           HifiGanEngine(HifiGanConfig(**hcfg.__dict__), wh, dev, dtype=torch.float16), sample_size=16)
+    g = lambda: torch.Generator(device=dev).manual_seed(5)
+    a = pipe(prompt=["rain on a tin roof"], num_inference_steps=4, audio_length_in_s=0.5, generator=g()).audios
+    b = ref(prompt=["rain on a tin roof"], num_inference_steps=4, audio_length_in_s=0.5, generator=g()).audios
+    assert np.isfinite(a).all() and a.std() > 1e-4 and np.array_equal(a, b)
