@@ -242,3 +242,59 @@ def test_audio_directory_loads_and_equals_direct_assembly(dev, tmp_path):
     a = pipe(prompt=["rain on a tin roof"], num_inference_steps=4, audio_length_in_s=0.5, generator=g()).audios
     b = ref(prompt=["rain on a tin roof"], num_inference_steps=4, audio_length_in_s=0.5, generator=g()).audios
     assert np.isfinite(a).all() and a.std() > 1e-4 and np.array_equal(a, b)
+
+
+def test_sdxl_directory_loads_through_init_story_generation(dev, tmp_path):
+    """stabilityai/stable-diffusion-xl-base-1.0 layout (Comic_Generation.py:297-318): unet/ (text_time conditioning, per-block
+    transformer depth, linear projections), vae/ with force_upcast (diffusers runs that VAE in fp32: the engine takes bf16),
+    text_encoder/ (CLIPTextModel), text_encoder_2/ (CLIPTextModelWithProjection, gelu), tokenizer/ + tokenizer_2/ (pad token '!')."""
+    from transformers import CLIPTokenizer
+    from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
+    from oracle.unet import UNetCfg, random_unet_weights
+    from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
+    from spider_amd.schedulers import DDIMScheduler
+    from spider_amd.story import StableDiffusionXLPipeline, init_story_generation
+    from spider_amd.unet import UNetConfig, UNetEngine
+    from spider_amd.vae import VAEConfig, VAEDecoderEngine
+    root = str(tmp_path / "sdxl")
+    n_vocab = _clip_bpe_files(os.path.join(root, "tokenizer"))
+    _clip_bpe_files(os.path.join(root, "tokenizer_2"))
+    tc = json.load(open(os.path.join(root, "tokenizer_2", "tokenizer_config.json")))
+    tc["pad_token"] = "!"
+    json.dump(tc, open(os.path.join(root, "tokenizer_2", "tokenizer_config.json"), "w"))
+    uc = UNetCfg.tiny(sdxl_like=True)          # cross_dim 64 = 32 + 32 (two text encoders), pooled 64, 6 time ids x 32
+    c1 = CLIPCfg(n_vocab, 32, 2, 2, 64, 77)
+    vc = VAECfg(4, 3, (64, 64, 64, 128), 1, 32)
+    wu, wv = _half(random_unet_weights(uc, seed=9)), _half(random_weights(vae_param_shapes(vc), seed=3))
+    w1, w2 = _half(random_weights(clip_param_shapes(c1), seed=1)), _half(random_weights(clip_param_shapes(c1), seed=2))
+    w2["text_projection.weight"] = (torch.randn(64, 32, generator=torch.Generator().manual_seed(4)) * 0.1).half()
+    _write_component(root, "unet", {"_class_name": "UNet2DConditionModel", "in_channels": 4, "out_channels": 4, "block_out_channels": [64, 128, 128],
+                                    "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+                                    "up_block_types": ["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"], "attention_head_dim": [1, 2, 2],
+                                    "transformer_layers_per_block": [1, 2, 2], "layers_per_block": 2, "cross_attention_dim": 64,
+                                    "norm_num_groups": 32, "sample_size": 16, "use_linear_projection": True, "addition_embed_type": "text_time",
+                                    "addition_time_embed_dim": 32, "projection_class_embeddings_input_dim": 64 + 6 * 32}, wu)
+    _write_component(root, "vae", {"_class_name": "AutoencoderKL", "latent_channels": 4, "out_channels": 3, "block_out_channels": [64, 64, 64, 128],
+                                   "layers_per_block": 1, "norm_num_groups": 32, "scaling_factor": 0.13025, "force_upcast": True}, wv)
+    te = {"vocab_size": c1.vocab, "hidden_size": 32, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 64,
+          "max_position_embeddings": 77, "layer_norm_eps": 1e-5}
+    _write_component(root, "text_encoder", {**te, "architectures": ["CLIPTextModel"], "hidden_act": "quick_gelu"}, w1)
+    _write_component(root, "text_encoder_2", {**te, "architectures": ["CLIPTextModelWithProjection"], "hidden_act": "gelu", "projection_dim": 64}, w2)
+    pipe = init_story_generation(root, device=dev)
+    assert pipe.unet.freeu == (0.6, 0.4, 1.1, 1.2) and pipe.unet.stream32 and pipe.unet.dtype == torch.float16
+    assert pipe.vae.dtype == torch.bfloat16 and pipe.vae.cfg.scaling == 0.13025          # force_upcast -> the wide-range 16-bit format
+    assert pipe.text_encoder_2.text_projection is not None and pipe.text_encoder.text_projection is None
+    assert pipe.tokenizer_2.pad_token == "!" and pipe.tokenizer.pad_token == "<|endoftext|>"
+    vcfg = VAEConfig(**vc.__dict__)
+    vcfg.scaling = 0.13025
+    ref = StableDiffusionXLPipeline(UNetEngine(UNetConfig(**uc.__dict__), wu, dev, dtype=torch.float16, stream32=True),
+                                    VAEDecoderEngine(vcfg, wv, dev, dtype=torch.bfloat16),
+                                    CLIPTextEngine(CLIPTextConfig(c1.vocab, 32, 2, 2, 64, 77), w1, dev, dtype=torch.float16),
+                                    CLIPTextEngine(CLIPTextConfig(c1.vocab, 32, 2, 2, 64, 77, 1e-5, "gelu"), w2, dev, dtype=torch.float16),
+                                    CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer")),
+                                    CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer_2")), DDIMScheduler())
+    ref.enable_freeu(0.6, 0.4, 1.1, 1.2)
+    lat = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+    kw = dict(prompt=["a lighthouse"], num_inference_steps=5, height=64, width=64, latents=lat, output_type="np")
+    a, b = pipe(**kw).images, ref(**kw).images
+    assert np.isfinite(a).all() and a.std() > 1e-3 and np.array_equal(a, b)
