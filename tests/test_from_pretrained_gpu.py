@@ -298,3 +298,38 @@ def test_sdxl_directory_loads_through_init_story_generation(dev, tmp_path):
     kw = dict(prompt=["a lighthouse"], num_inference_steps=5, height=64, width=64, latents=lat, output_type="np")
     a, b = pipe(**kw).images, ref(**kw).images
     assert np.isfinite(a).all() and a.std() > 1e-3 and np.array_equal(a, b)
+
+
+def test_llama_directory_sharded_with_generation_config(dev, tmp_path):
+    """deepseek-ai/DeepSeek-R1-Distill-Llama-8B layout (r1_llama3_8B_infer.py:4, demo/inference_api.py:92-95): config.json with
+    GQA + llama3 rope scaling, model-0000x-of-0000y.safetensors behind model.safetensors.index.json, generation_config.json whose eos
+    list ends generation when the caller passes none. The loaded engine generates what an engine built on the tensors generates."""
+    from oracle.llama import LlamaCfg, LlamaOracle
+    from spider_amd.llm import LlamaEngine, LLMConfig
+    d = str(tmp_path / "llm")
+    os.makedirs(d)
+    rs = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=64)
+    ocfg = LlamaCfg(256, 2, 4, 2, 128, 512, 331, 500000.0, rs, 1e-5, False, 512)
+    w = {k: v.bfloat16() for k, v in LlamaOracle.random_weights(ocfg, seed=2, std=0.08).items()}
+    json.dump({"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2,
+               "num_attention_heads": 4, "num_key_value_heads": 2, "head_dim": 128, "intermediate_size": 512, "vocab_size": 331,
+               "rope_theta": 500000.0, "rope_scaling": rs, "rms_norm_eps": 1e-5, "max_position_embeddings": 512,
+               "tie_word_embeddings": False, "attention_bias": False, "bos_token_id": 1, "eos_token_id": 2, "torch_dtype": "bfloat16"},
+              open(os.path.join(d, "config.json"), "w"))
+    names = sorted(w)
+    shard = {n: f"model-0000{1 + (i % 2)}-of-00002.safetensors" for i, n in enumerate(names)}
+    for f in set(shard.values()):
+        save_file({n: w[n].contiguous() for n in names if shard[n] == f}, os.path.join(d, f))
+    json.dump({"metadata": {"total_size": 0}, "weight_map": shard}, open(os.path.join(d, "model.safetensors.index.json"), "w"))
+    ref = LlamaEngine(LLMConfig(**ocfg.__dict__), w, dev, max_batch=1, max_len=96)
+    ids = torch.randint(3, 331, (1, 11), generator=torch.Generator().manual_seed(6))
+    full = ref.generate(input_ids=ids, max_new_tokens=12)
+    stop_at = int(full[0, 11 + 5])                       # the 6th generated token becomes an EOS of the checkpoint's generation config
+    json.dump({"bos_token_id": 1, "eos_token_id": [2, stop_at], "pad_token_id": 0, "max_new_tokens": 12},
+              open(os.path.join(d, "generation_config.json"), "w"))
+    eng = LlamaEngine.from_pretrained(d, dev, max_batch=1, max_len=96)
+    assert eng.cfg == LLMConfig(**ocfg.__dict__) and eng.generation_config["eos_token_id"] == [2, stop_at]
+    got = eng.generate(input_ids=ids)                    # no max_new_tokens / eos passed: the checkpoint's defaults apply
+    first = next(i for i in range(12) if int(full[0, 11 + i]) == stop_at)
+    assert torch.equal(got[0, :11 + first + 1], full[0, :11 + first + 1]) and got.shape[1] == 11 + first + 1
+    assert torch.equal(eng.generate(input_ids=ids, max_new_tokens=12, eos_token_id=[]), full)
