@@ -1,7 +1,12 @@
 """Long fp32 ORACLE loops, run once in the build container, so that the GPU suite can compare full denoising loops without spending
 its time budget on CPU work:
 
-    python tests/golden/make_oracle_loops.py [sdxl] [zeroscope]      # sdxl: ~5 min, zeroscope: ~1.5 h on 8 cores
+    python tests/golden/make_oracle_loops.py [sd15] [audioldm] [sdxl] [zeroscope]    # 8 cores: ~2, ~2, ~5, ~45 minutes
+
+  oracle_loop_sd15_pndm40.npz      SD-v1.5 UNet (UNetCfg.sd15(), weights seed 0), [1, 4, 64, 64] latent, 40 PNDM steps = 41 evaluations,
+                           guidance 7.5 (configs[1]; custom_sd.py:627-652): latents in / out.
+  oracle_loop_audioldm_l_ddim40.npz  AudioLDM-L UNet (UNetCfg.audioldm_l(), weights seed 2), class-label conditioning, [1, 8, 125, 16]
+                           latent of 5 s of audio, 40 DDIM steps, guidance 2.5 (custom_ad.py:568-594): latents in / out.
 
   oracle_loop_sdxl50.npz   SDXL UNet (oracle.unet.UNetCfg.sdxl(), weights random_unet_weights(seed=4)), CFG batch 2 on a
                            [1, 4, 64, 64] latent (512^2), 50 DDIM steps, guidance 5.0 -- the scheduler / step count / guidance
@@ -62,6 +67,49 @@ def sdxl_loop(steps=50, guidance=5.0, keep=(1, 10, 25)):
                         latents_out=x.numpy(), steps=steps, guidance=guidance, weights_seed=4, **kept)
 
 
+def sd15_inputs():
+    """the seeded case of tests/test_fullsize_parity.py::sd15_case (prompt states) + the loop's starting latent"""
+    g = torch.Generator().manual_seed(1)
+    torch.randn(2, 4, 64, 64, generator=g)                       # (the single-evaluation test's sample: same generator stream)
+    enc = torch.randn(2, 77, 768, generator=g).bfloat16().float()
+    lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(11))
+    return lat, enc
+
+
+@torch.no_grad()
+def sd15_loop(steps=40, guidance=7.5):
+    """configs[1]'s image decoder: SD-v1.5 UNet, 40 PNDM steps = 41 evaluations, guidance 7.5 (custom_sd.py:627-652)."""
+    from oracle.unet import PNDMOracle, denoise_loop
+    ocfg = UNetCfg.sd15()
+    lat, enc = sd15_inputs()
+    t0 = time.time()
+    ref = denoise_loop(UNetOracle(ocfg, random_unet_weights(ocfg, seed=0)), PNDMOracle(), lat, enc, guidance, steps)
+    print(f"sd15 loop: {time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "oracle_loop_sd15_pndm40.npz"), latents_in=lat.numpy(), enc_sum=float(enc.double().sum()),
+                        latents_out=ref.numpy(), steps=steps, guidance=guidance, weights_seed=0)
+
+
+def audioldm_inputs():
+    g = torch.Generator().manual_seed(13)
+    lat = torch.randn(1, 8, 125, 16, generator=g)
+    cl = torch.nn.functional.normalize(torch.randn(2, UNetCfg.audioldm_l().class_in, generator=g), dim=-1).bfloat16().float()
+    return lat, cl
+
+
+@torch.no_grad()
+def audioldm_loop(steps=40, guidance=2.5):
+    """configs[3] / [4]'s audio decoder: AudioLDM-L UNet, class-label conditioning, 40 DDIM steps, guidance 2.5 on the
+    [1, 8, 125, 16] latent of 5 s of audio (custom_ad.py:568-594)."""
+    from oracle.unet import denoise_loop
+    ocfg = UNetCfg.audioldm_l()
+    lat, cl = audioldm_inputs()
+    t0 = time.time()
+    ref = denoise_loop(UNetOracle(ocfg, random_unet_weights(ocfg, seed=2)), DDIMOracle(), lat, None, guidance, steps, class_labels=cl)
+    print(f"audioldm loop: {time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "oracle_loop_audioldm_l_ddim40.npz"), latents_in=lat.numpy(), class_labels=cl.numpy(),
+                        latents_out=ref.numpy(), steps=steps, guidance=guidance, weights_seed=2)
+
+
 def zeroscope_inputs(frames=16):
     g = torch.Generator().manual_seed(23)
     lat = torch.randn(1, 4, frames, 40, 72, generator=g)
@@ -99,7 +147,11 @@ def zeroscope_loop(frames=16, steps=40, guidance=9.0, keep=(1, 20)):
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 8)))
-    which = sys.argv[1:] or ["sdxl", "zeroscope"]
+    which = sys.argv[1:] or ["sd15", "audioldm", "sdxl", "zeroscope"]
+    if "sd15" in which:
+        sd15_loop()
+    if "audioldm" in which:
+        audioldm_loop()
     if "sdxl" in which:
         sdxl_loop()
     if "zeroscope" in which:

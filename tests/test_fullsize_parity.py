@@ -84,14 +84,23 @@ def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype, stream32)
 LOOP41_BOUND = 1.55e-3         # measured on MI355X (round 4): 1.26e-3 -- the loop does not amplify the per-evaluation 1.21e-3
 
 
-@pytest.mark.timeout(900)
-def test_sd15_full_41_step_loop_latents_match_oracle(dev, sd15_case):
-    from oracle.unet import PNDMOracle, UNetOracle, denoise_loop
+def _loop_fixture(golden_dir, name):
+    """an fp32 oracle loop run once in the build container (tests/golden/make_oracle_loops.py): the GPU suite spends its time on the
+    engines, not on minutes of host arithmetic"""
+    import numpy as np
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_sd15_full_41_step_loop_latents_match_oracle(dev, sd15_case, golden_dir):
+    import numpy as np
     from spider_amd.schedulers import PNDMScheduler
     from spider_amd.unet import UNetConfig, UNetEngine, denoise
     ocfg, w, x, enc, t, ref1 = sd15_case
+    fx = _loop_fixture(golden_dir, "oracle_loop_sd15_pndm40.npz")
     lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(11))
-    ref = denoise_loop(UNetOracle(ocfg, w), PNDMOracle(), lat, enc, 7.5, 40)
+    assert np.array_equal(lat.numpy(), fx["latents_in"]) and abs(float(enc.double().sum()) - float(fx["enc_sum"])) < 1e-6
+    assert int(fx["steps"]) == 40 and float(fx["guidance"]) == 7.5 and int(fx["weights_seed"]) == 0
+    ref = torch.from_numpy(fx["latents_out"])          # = denoise_loop(UNetOracle(ocfg, w), PNDMOracle(), lat, enc, 7.5, 40)
     eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=torch.float16, stream32=True)
     got = denoise(eng, PNDMScheduler(), lat.to(dev), enc.to(dev), 7.5, 40)
     r = _rel(got, ref)
@@ -125,12 +134,12 @@ def test_audioldm_l_unet_step_fullsize_matches_oracle(dev, dtype):
     _free()
 
 
-@pytest.mark.timeout(900)
-def test_audioldm_l_full_40_step_loop_latents_match_oracle(dev):
+def test_audioldm_l_full_40_step_loop_latents_match_oracle(dev, golden_dir):
     """configs[3]/[4]'s audio decoder at full size: the whole AudioLDM denoising loop (custom_ad.py:568-594: CFG batch 2, class-label
     conditioning, no encoder_hidden_states; 40 DDIM steps, guidance 2.5) on the `[1, 8, 125, 16]` latent of 5 s of audio, engine in the
     mode AudioLDMPipeline.from_pretrained loads (f16 + fp32 residual stream), against the fp32 oracle loop."""
-    from oracle.unet import DDIMOracle, UNetCfg, UNetOracle, denoise_loop, random_unet_weights
+    import numpy as np
+    from oracle.unet import UNetCfg, random_unet_weights
     from spider_amd.schedulers import DDIMScheduler
     from spider_amd.unet import UNetConfig, UNetEngine, denoise
     ocfg = UNetCfg.audioldm_l()
@@ -138,7 +147,10 @@ def test_audioldm_l_full_40_step_loop_latents_match_oracle(dev):
     g = torch.Generator().manual_seed(13)
     lat = torch.randn(1, 8, 125, 16, generator=g)
     cl = torch.nn.functional.normalize(torch.randn(2, ocfg.class_in, generator=g), dim=-1).bfloat16().float()
-    ref = denoise_loop(UNetOracle(ocfg, w), DDIMOracle(), lat, None, 2.5, 40, class_labels=cl)
+    fx = _loop_fixture(golden_dir, "oracle_loop_audioldm_l_ddim40.npz")
+    assert np.array_equal(lat.numpy(), fx["latents_in"]) and np.array_equal(cl.numpy(), fx["class_labels"])
+    assert int(fx["steps"]) == 40 and float(fx["guidance"]) == 2.5 and int(fx["weights_seed"]) == 2
+    ref = torch.from_numpy(fx["latents_out"])   # = denoise_loop(UNetOracle(ocfg, w), DDIMOracle(), lat, None, 2.5, 40, class_labels=cl)
     eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=torch.float16, stream32=True)
     got = denoise(eng, DDIMScheduler(), lat.to(dev), None, 2.5, 40, class_labels=cl.to(dev))
     r = _rel(got, ref)
@@ -264,10 +276,12 @@ def test_zeroscope_unet3d_step_fullsize_matches_oracle(dev, zeroscope_case, dtyp
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("frames", [16])        # measured: 8 frames 1.34e-3, 16 frames 1.24e-3
+# measured: 8 frames 1.34e-3, 16 frames 1.24e-3. The live oracle runs the 8-frame case (50 s of host time); the full 16 frames are compared over
+# the whole loop against the committed oracle-loop fixture (test_zeroscope_full_40_step_loop_latents_match_oracle_fixture).
+@pytest.mark.parametrize("frames", [8])
 def test_zeroscope_unet3d_step_full_frames_matches_oracle(dev, frames):
-    """The video decoder at 8 and at the full 16 frames of 40 x 72 that configs[3]/[4] decode (custom_vd.py:671-676 with num_frames=16,
-    spider_decoder.py:122; the CPU oracle needs 1.5 / 3 min), in the mode TextToVideoSDPipeline.from_pretrained loads (f16 + fp32 residual
+    """The video decoder at 8 of the 16 frames of 40 x 72 that configs[3]/[4] decode (custom_vd.py:671-676 with num_frames=16,
+    spider_decoder.py:122; the CPU oracle needs 1.5 / 3 min for 8 / 16 frames), in the mode TextToVideoSDPipeline.from_pretrained loads (f16 + fp32 residual
     stream): the temporal convs and the frame attention see a real frame axis (the 2-frame cases above leave the (3,1,1) convs two thirds
     zero padding)."""
     from oracle.unet3d import UNet3DCfg, UNet3DOracle, random_unet3d_weights
@@ -290,7 +304,9 @@ def test_zeroscope_unet3d_step_full_frames_matches_oracle(dev, frames):
     _free()
 
 
-ZEROSCOPE_LOOP40_BOUND = {"after_1": 2.0e-3, "after_20": 2.5e-3, "latents_out": 2.5e-3}        # set from the first GPU run
+# measured on MI355X (round 4): 1.03e-3 / 1.91e-3 / 1.91e-3 (guidance 9.0 multiplies the error of eps_cond - eps_uncond by 9: per
+# evaluation 1.24e-3, see test_zeroscope_unet3d_step_full_frames_matches_oracle)
+ZEROSCOPE_LOOP40_BOUND = {"after_1": 1.25e-3, "after_20": 2.3e-3, "latents_out": 2.3e-3}
 
 
 def test_zeroscope_full_40_step_loop_latents_match_oracle_fixture(dev, golden_dir):
