@@ -14,6 +14,13 @@ elif which == "conv64":
 elif which == "conv64_320":   # the roofline_unet_conv shape of bench.py
     x = torch.randn(2, 64, 64, 320, device=dev).to(DT); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(DT)
     f = lambda: ops.conv2d(x, w)
+elif which == "conv64_320_res32":   # the same conv as a ResnetBlock2D.conv2 of the fp32 residual stream: fp32 master in (shortcut) and out
+    x = torch.randn(2, 64, 64, 320, device=dev).to(DT); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(DT)
+    r32 = torch.randn(2, 64, 64, 320, device=dev)
+    f = lambda: ops.conv2d(x, w, res32=r32, want32=True, gn_groups=32)
+elif which == "conv64_320_gn":      # ResnetBlock2D.conv1: 16-bit in / out, GroupNorm partials of the output from the epilogue
+    x = torch.randn(2, 64, 64, 320, device=dev).to(DT); w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(DT)
+    f = lambda: ops.conv2d(x, w, gn_groups=32)
 elif which == "conv48_640":   # SDXL 48^2 level (CFG batch 8): 18432 rows, input 23.6 MB
     x = torch.randn(8, 48, 48, 640, device=dev).to(DT); w = (torch.randn(640, 3, 3, 640, device=dev) * 0.02).to(DT)
     f = lambda: ops.conv2d(x, w)
