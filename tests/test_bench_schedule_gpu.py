@@ -81,6 +81,9 @@ def test_pipelined_soak_changing_geometry(dev, depth):
     overlapped -- it captures graphs), some answered twice in a row: the pipelined results equal `predict` of the same requests
     bit for bit (response text, token ids, image bytes), arrive in request order, and the device memory in use stops growing once
     every geometry has been seen."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     bench = _bench()
     resp = bench.Responder(_args(prompt_len=96, new_tokens=8, denoise_steps=3, pipeline_depth=depth), dev)
     infer = resp.infer
@@ -105,8 +108,9 @@ def test_pipelined_soak_changing_geometry(dev, depth):
         assert torch.equal(g[1], r[1]), f"request {i}: token ids differ"
         assert np.array_equal(g[2], r[2]), f"request {i}: image differs"
     assert len({g[0] for g in got}) > 3, "the requests are different requests"
-    # all three geometries were seen by request 10; allow the allocator one block of slack afterwards
-    assert max(mem[12:]) - min(mem[12:]) <= 64 << 20, [m >> 20 for m in mem]
+    # all three geometries were seen by request 10: no GROWTH afterwards beyond one allocator block (memory released by the garbage
+    # collection of earlier tests' engines in the middle of the run is not this test's business)
+    assert max(mem[12:]) - mem[12] <= 64 << 20, [m >> 20 for m in mem]
     # and a second sweep over the same requests (everything warm: every pass overlapped) is still identical
     torch.cuda.manual_seed(77)
     again = [key(r) for r in infer.pipelined(reqs)]
