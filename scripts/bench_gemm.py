@@ -35,6 +35,16 @@ if os.environ.get("SHAPES") == "deep":   # SD-v1.5 UNet, 16^2 / 8^2 maps (CFG ba
         ("u8 out", 128, 1280, 1280, 0, 0), ("u8 ff2", 128, 1280, 5120, 0, 0),
     ]
 
+if os.environ.get("SHAPES") == "b16":   # SD-v1.5 UNet at CFG batch 16 (8 prompts per GPU): 16^2 / 8^2 maps = 4096 / 1024 rows, between the tuned size classes
+    SHAPES = [
+        ("c16 1280>1280", 4096, 1280, 11520, 1280, 16), ("c16 2560>1280", 4096, 1280, 23040, 2560, 16), ("c16 640>1280", 4096, 1280, 5760, 640, 16),
+        ("c8 1280>1280", 1024, 1280, 11520, 1280, 8), ("c8 2560>1280", 1024, 1280, 23040, 2560, 8),
+        ("u16 qkv", 4096, 3840, 1280, 0, 0), ("u16 out", 4096, 1280, 1280, 0, 0), ("u16 ff2", 4096, 1280, 5120, 0, 0),
+        ("u8 out", 1024, 1280, 1280, 0, 0), ("u8 ff2", 1024, 1280, 5120, 0, 0),
+        ("c32 640>640", 16384, 640, 5760, 640, 32), ("c32 1280>640", 16384, 640, 11520, 1280, 32),
+        ("u32 out", 16384, 640, 640, 0, 0), ("u32 ff2", 16384, 640, 2560, 0, 0),
+    ]
+
 if os.environ.get("SHAPES") == "vae":    # SD-v1.5 VAE decoder, one 512^2 image (up blocks: 64^2 x 512 ... 512^2 x 128)
     SHAPES = [
         ("vae 64 512>512", 4096, 512, 4608, 512, 64), ("vae 128 512>512", 16384, 512, 4608, 512, 128),
