@@ -976,6 +976,20 @@ def text_image_extras(args, resp, device):
             resp.respond(tb)
         torch.cuda.synchronize(device)
         dtb = (time.perf_counter() - t1) / 2
+        curve = []
+        for b2 in (2, 4):                          # the same measurement at 2 and 4 prompts per GPU (requests answered together)
+            if b2 >= tb:
+                continue
+            resp.respond(b2)
+            resp.respond(b2)
+            torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            for _ in range(2):
+                resp.respond(b2)
+            torch.cuda.synchronize(device)
+            d2 = (time.perf_counter() - t2) / 2
+            curve.append({"prompts_per_gpu": b2, "responses_per_s": round(b2 / d2, 4), "ms_per_batch": round(d2 * 1e3, 1)})
+        extra["batched_throughput_curve"] = curve + [{"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1)}]
         extra["batched_throughput"] = {"prompts_per_gpu": tb, "responses_per_s": round(tb / dtb, 4), "ms_per_batch": round(dtb * 1e3, 1),
                                        "schedule": a.schedule,
                                        "note": "same workload, independent prompts batched on one GPU (BASELINE config 5 uses 8 per GPU), same "
