@@ -150,11 +150,94 @@ def case_groupnorm(r, g):
     return desc, e, why, dt
 
 
+def _rms(x, w, eps):
+    xf = x.float()
+    return ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16).float() * w.float()).to(torch.bfloat16)
+
+
+def case_llm(r, g):
+    """decode-side operators (bf16): LlamaRMSNorm (+ residual), weight-streaming GEMV with the norm / bias / residual fused,
+    gate-up GEMV with SwiGLU, lm_head + argmax, and the prefill GEMM's SwiGLU epilogue"""
+    bf = torch.bfloat16
+    kind = r.choice(["rmsnorm", "gemv", "gemv_swiglu", "lm_head", "gemm_swiglu"])
+    K = r.choice([64, 128, 256, 512, 1000, 1024, 3584, 4096])
+    B = r.choice([1, 1, 2, 3, 4, 8])
+    eps = r.choice([1e-5, 1e-6])
+    x = rnd(g, B, K, dt=bf)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(bf)
+    if kind == "rmsnorm":
+        rows = r.choice([1, 3, 64, 300])
+        x = rnd(g, rows, K, dt=bf)
+        res = rnd(g, rows, K, dt=bf) if r.random() < 0.5 else None
+        desc = f"rmsnorm rows={rows} H={K} eps={eps} res={res is not None}"
+        if res is None:
+            y = ops.rmsnorm(x.to(dev), nw.to(dev), eps)
+            ref = _rms(x, nw, eps)
+        else:
+            ro = torch.empty(rows, K, dtype=bf, device=dev)
+            y = ops.rmsnorm(x.to(dev), nw.to(dev), eps, res=res.to(dev), res_out=ro)
+            h = (x.float() + res.float()).to(bf)
+            ref = _rms(h, nw, eps)
+            if not torch.equal(ro.cpu(), h):
+                return desc, float("inf"), "residual sum differs from bf16(x + res)", bf
+        e, why = err(y, ref)
+        return desc, e, why, bf
+    if kind == "gemv":
+        N = r.choice([8, 64, 100, 512, 1000, 4608])
+        W = rnd(g, N, K, scale=K ** -0.5, dt=bf)
+        bias = rnd(g, N, dt=bf) if r.random() < 0.5 else None
+        res = rnd(g, B, N, dt=bf) if r.random() < 0.5 else None
+        fuse = r.random() < 0.5
+        desc = f"gemv B={B} N={N} K={K} bias={bias is not None} res={res is not None} norm={fuse}"
+        y = ops.gemv(W.to(dev), x.to(dev), bias=None if bias is None else bias.to(dev), res=None if res is None else res.to(dev),
+                     norm_w=nw.to(dev) if fuse else None, eps=eps)
+        xin = _rms(x, nw, eps) if fuse else x
+        ref = xin.float() @ W.float().T
+        if bias is not None:
+            ref = ref + bias.float()
+        if res is not None:
+            ref = ref + res.float()
+        e, why = err(y, ref)
+        return desc, e, why, bf
+    if kind in ("gemv_swiglu", "gemm_swiglu"):
+        I = r.choice([64, 256, 1000, 2048])
+        W = rnd(g, 2 * I, K, scale=K ** -0.5, dt=bf)
+        if kind == "gemm_swiglu":
+            M = r.choice([16, 100, 300, 1536])
+            x = rnd(g, M, K, dt=bf)
+            desc = f"gemm act=swiglu M={M} I={I} K={K}"
+            y = ops.gemm(x.to(dev), W.to(dev), act="swiglu")
+        else:
+            fuse = r.random() < 0.5
+            desc = f"gemv_swiglu B={B} I={I} K={K} norm={fuse}"
+            y = ops.gemv_swiglu(W.to(dev), x.to(dev), norm_w=nw.to(dev) if fuse else None, eps=eps)
+            x = _rms(x, nw, eps) if fuse else x
+        p_ = x.float() @ W.float().T
+        gate, up = p_[:, :I].to(bf).float(), p_[:, I:].to(bf).float()
+        ref = F.silu(gate).to(bf).float() * up
+        e, why = err(y, ref)
+        return desc, e, why, bf
+    V = r.choice([300, 1000, 32000])
+    W = rnd(g, V, K, scale=K ** -0.5, dt=bf)
+    desc = f"lm_head_argmax B={B} V={V} K={K}"
+    logits = torch.empty(B, V, dtype=bf, device=dev)
+    ids = ops.lm_head_argmax(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=eps, logits=logits)
+    ref = _rms(x, nw, eps).float() @ W.float().T
+    e, why = err(logits, ref)
+    top2 = ref.topk(2, -1).values
+    for b in range(B):        # the id must be the argmax wherever the decision is above bf16 resolution
+        if float(top2[b, 0] - top2[b, 1]) > 0.05 * float(ref[b].abs().max()) and int(ids[b]) != int(ref[b].argmax()):
+            why = f"row {b}: id {int(ids[b])} is not the argmax {int(ref[b].argmax())}"
+    if not why and not torch.equal(ids.cpu().long(), logits.float().cpu().argmax(-1)):
+        why = "ids differ from the argmax of the kernel's own logits"
+    return desc, e, why, bf
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     r, g = random.Random(seed), torch.Generator().manual_seed(seed)
-    kinds = [case_gemm] * 4 + [case_conv] * 4 + [case_attn] * 2 + [case_groupnorm]
+    kinds = [case_gemm] * 4 + [case_conv] * 4 + [case_attn] * 2 + [case_groupnorm] + [case_llm] * 3
     tol = {torch.float16: 4e-3, torch.bfloat16: 2.5e-2}
     bad, done, worst, refused = 0, 0, {}, {}
     for i in range(n):
