@@ -75,7 +75,8 @@ int spider_rope_kv_append_mrope_bf16(const void* qkv, const int* pos3, const int
 
 /* decode attention, one query token per sequence, GQA, fp32 online softmax, split over the KV length
  * (eager_attention_forward + repeat_kv, modeling_llama3.py:202-237). Valid cache slots per sequence:
- * [kv_beg[b], kv_end[b]) (kv_beg may be NULL = 0). ws_o: B*n_q*nsplit*d floats, ws_ml: B*n_q*nsplit*2. */
+ * [kv_beg[b], kv_end[b]) (kv_beg may be NULL = 0). ws_o: B*n_q*nsplit*d floats, ws_ml: B*n_q*nsplit*2.
+ * head_dim d = 128; GQA group n_q / n_kv = 1 ... 8 (Llama-3-8B: 4, Qwen2.5-Omni-7B: 7); other shapes return -1 with a message. */
 int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_cache, const int* kv_beg,
                             const int* kv_end, void* out, void* ws_o, void* ws_ml, int B, int n_q, int n_kv, int d,
                             int T_max, float scale, int nsplit, void* stream);

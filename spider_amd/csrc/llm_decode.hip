@@ -1509,10 +1509,13 @@ int spider_attn_decode_bf16(const void* q, const void* k_cache, const void* v_ca
     switch (G) {
         case 1: ATTN_DEC_LAUNCH(1); break;
         case 2: ATTN_DEC_LAUNCH(2); break;
-        case 4: ATTN_DEC_LAUNCH(4); break;
-        case 7: ATTN_DEC_LAUNCH(7); break;
-        case 8: ATTN_DEC_LAUNCH(8); break;
-        default: spider_set_error("attn_decode: GQA group size must be one of 1,2,4,7,8"); return -1;
+        case 3: ATTN_DEC_LAUNCH(3); break;      // (Llama-3.2-3B: 24 / 8)
+        case 4: ATTN_DEC_LAUNCH(4); break;      // Llama-3-8B, DeepSeek-R1-Distill-Llama-8B: 32 / 8
+        case 5: ATTN_DEC_LAUNCH(5); break;      // (Qwen2.5-14B / 32B: 40 / 8)
+        case 6: ATTN_DEC_LAUNCH(6); break;
+        case 7: ATTN_DEC_LAUNCH(7); break;      // Qwen2.5-Omni-7B thinker: 28 / 4
+        case 8: ATTN_DEC_LAUNCH(8); break;      // Qwen2.5-Omni-3B thinker: 16 / 2
+        default: spider_set_error("attn_decode: GQA group size must be 1 ... 8"); return -1;
     }
     SPIDER_LAUNCH_OK();
     if (nsplit > 1) {
@@ -1555,10 +1558,13 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
     switch (G) {
         case 1: ATTN_FUSED_LAUNCH(1); break;
         case 2: ATTN_FUSED_LAUNCH(2); break;
+        case 3: ATTN_FUSED_LAUNCH(3); break;
         case 4: ATTN_FUSED_LAUNCH(4); break;
+        case 5: ATTN_FUSED_LAUNCH(5); break;
+        case 6: ATTN_FUSED_LAUNCH(6); break;
         case 7: ATTN_FUSED_LAUNCH(7); break;
         case 8: ATTN_FUSED_LAUNCH(8); break;
-        default: spider_set_error("attn_decode_fused: GQA group size must be one of 1,2,4,7,8"); return -1;
+        default: spider_set_error("attn_decode_fused: GQA group size must be 1 ... 8"); return -1;
     }
     SPIDER_LAUNCH_OK();
     if (nsplit > 1 && !inline_combine) {
