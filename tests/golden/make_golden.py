@@ -14,6 +14,8 @@ Produces
   llama_ops_ref.npz          per-op vectors: LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, LlamaAttention
   routing_ref.json           SpiderDecoder.get_llm_text_res / get_llm_text_modality / generate (stub decoders)
                              and clean_prompt_array / extract_story_elements / extract_answer on 40+ strings
+  routing_ref_fuzz.json      the same reference functions on 400 + 250 strings drawn from a small grammar (random tag order / nesting /
+                             damage, regex metacharacters, unicode, <think> blocks, every clean_prompt_array fallback)
   moe_proj_ref.npz           the reference's own Mlp / TextFcLayerMoE bodies and preparing_output_embeds_infer on seeded inputs
   story_ref.npz              cal_attn_mask_xl masks (seeded) and SpatialAttnProcessor2_0 __call1__/__call2__ and a
                              7-step write-phase sequence with the coin flips recorded
@@ -237,7 +239,8 @@ STORY_TEXTS = [
 ]
 
 
-def gen_routing():
+def _routing_env():
+    """the reference's SpiderDecoder with stub decoders + its story / answer parsers (shared by gen_routing and gen_routing_fuzz)"""
     # stub everything spider_decoder.py imports except the real registry
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -281,7 +284,11 @@ def gen_routing():
         pass
     self_ = _Self()
     self_.clean_prompt_array = lambda s: ns["clean_prompt_array"](self_, s)
+    return dec, ns, self_, calls, fake, fake_box
 
+
+def gen_routing():
+    dec, ns, self_, calls, fake, fake_box = _routing_env()
     cases = []
     for none_mode in (False, True):
         for text in ROUTING_TEXTS:
@@ -304,6 +311,100 @@ def gen_routing():
                           answer=ns["extract_answer"](text)))
     json.dump(dict(cases=cases, story=story), open(f"{OUT}/routing_ref.json", "w"), indent=1, ensure_ascii=True)
     print("routing cases", len(cases), "story cases", len(story))
+
+
+def _random_routing_text(r):
+    """LLM-output-like strings from a small grammar: signal tags of the six modalities in random order and nesting, unterminated /
+    reversed / lower-case / mismatched tags, captions with regex metacharacters, quotes, unicode, newlines and tabs, <think> blocks."""
+    mods = ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX", "IMAGESTORY"]
+    words = ["a red car", "dog", "the cat on a mat", "rain, heavy", "caf\u00e9 \u732b", "x", "", " ", "(a|b)*", "[set]", "$^.+?", "line\nbreak", "tab\there",
+             "'quoted'", "\"double\"", "<b>bold</b>", "100% \\d+", "\U0001F600 smile", "A" * 40, "</think>", "<think>", "<IMAGE>", "</AUDIO>"]
+    def caption(depth=0):
+        parts = [r.choice(words) for _ in range(r.randint(0, 3))]
+        if depth < 2 and r.random() < 0.25:
+            parts.insert(r.randint(0, len(parts)), tag(depth + 1))
+        return " ".join(parts)
+    def tag(depth=0):
+        m = r.choice(mods)
+        k = r.random()
+        if k < 0.70:
+            return f"<{m}>{caption(depth)}</{m}>"
+        if k < 0.76:
+            return f"<{m}>{caption(depth)}"                        # unterminated
+        if k < 0.82:
+            return f"</{m}>{caption(depth)}<{m}>"                  # reversed
+        if k < 0.88:
+            return f"<{m.lower()}>{caption(depth)}</{m.lower()}>"   # wrong case
+        if k < 0.94:
+            return f"<{m}>{caption(depth)}</{r.choice(mods)}>"      # mismatched close
+        return f"< {m} >{caption(depth)}</ {m}>"                    # spaces inside the brackets
+    out = []
+    for _ in range(r.randint(0, 6)):
+        k = r.random()
+        out.append(tag() if k < 0.6 else (r.choice(words) if k < 0.9 else f"<think>{caption()}</think>"))
+    return r.choice(["", " ", "\n"]).join(out)
+
+
+def _random_story_text(r):
+    gens = ["'a man with a black suit'", "a cat", "  spaced  ", "", "\nmulti\nline\n", "\"dq\"", "<i>html</i>"]
+    arrays = ["['wake up', 'eat', 'sleep']", "[\"a\", \"b\"]", "['one']", "[]", "'a'\n'b'\n'c'", "[wake up', 'eat]", "{'k': 1}", "['', 'kept', 0]",
+              "[<b>'x'</b>, 'y']", "   ", "not a list", "['it\\'s', 'ok']", "[\"json \\\"q\\\"\", \"two\"]", "('t', 'u')", "['a',\n 'b',\n]", "[1, 2.5, None, True]"]
+    styles = ["'Comic book'", "Line art", "  'Japanese Anime'  ", "", "(No style)", "\"Photographic\""]
+    tags = [("GENERALPROMPT", gens), ("PROMPTARRAY", arrays), ("STYLENAME", styles)]
+    parts = []
+    for name, pool in tags:
+        for _ in range(r.choice([0, 1, 1, 1, 2])):
+            parts.append(f"<{name}>{r.choice([' ', '', chr(10)])}{r.choice(pool)}{r.choice([' ', ''])}</{name}>")
+    r.shuffle(parts)
+    text = r.choice(["", " ", "\n"]).join(parts)
+    k = r.random()
+    if k < 0.3:
+        text = f"<think>plan <GENERALPROMPT>ghost</GENERALPROMPT> {r.choice(arrays)}</think>" + text
+    elif k < 0.4:
+        text = "a</think>b</think>" + text
+    elif k < 0.5:
+        text = f"<IMAGESTORY>{text}</IMAGESTORY>"
+    return text
+
+
+def gen_routing_fuzz(n_route=400, n_story=250, seed=2047):
+    """A larger, randomly generated routing fixture through the SAME reference functions as gen_routing (routing_ref_fuzz.json)."""
+    import random
+    dec, ns, self_, calls, fake, fake_box = _routing_env()
+    r = random.Random(seed)
+    cases, seen = [], set()
+    while len(cases) < n_route:
+        text = _random_routing_text(r)
+        none_mode = r.random() < 0.3
+        if (text, none_mode) in seen:
+            continue
+        seen.add((text, none_mode))
+        calls.clear()
+        dec.decode_modality = dict(IMAGE=fake("IMAGE", none_mode), VIDEO=fake("VIDEO"), AUDIO=fake("AUDIO", none_mode),
+                                   MASK=fake("MASK"), BOX=fake_box, IMAGESTORY=None)
+        answers = []
+        predictions = dict(IMAGE=[], VIDEO=[], AUDIO=[], MASK=[], BOX=dict(bboxes=[], label_names=[], scores=[]), IMAGESTORY=[])
+        predictions_text = dict(IMAGE=[], VIDEO=[], AUDIO=[], MASK=[], BOX=[], IMAGESTORY=[], IMAGESTORY_prompts=[])
+        a, p, pt = dec.generate({"llm_text_all": [text]}, answers, predictions, predictions_text)
+        cases.append(dict(text=text, none_mode=none_mode, answers=a, predictions=p, predictions_text=pt, calls=[list(c) for c in calls],
+                          modality=dec.get_llm_text_modality(text, ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX"]),
+                          res={m: dec.get_llm_text_res(text, m) for m in ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX", "IMAGESTORY"]}))
+    story, seen = [], set()
+    while len(story) < n_story:
+        text = _random_story_text(r)
+        if text in seen:
+            continue
+        seen.add(text)
+        try:
+            gp, pa, sn = ns["extract_story_elements"](self_, text)
+            err = None
+        except Exception as ex:                      # the reference's own failure mode is part of the contract
+            gp = pa = sn = None
+            err = type(ex).__name__
+        story.append(dict(text=text, general_prompt=gp, prompt_array=pa, style_name=sn, raises=err, answer=ns["extract_answer"](text)))
+    json.dump(dict(cases=cases, story=story, seed=seed), open(f"{OUT}/routing_ref_fuzz.json", "w"), indent=0, ensure_ascii=True)
+    print("routing fuzz cases", len(cases), "story fuzz cases", len(story), "story cases that raise in the reference:",
+          sum(1 for s_ in story if s_["raises"]))
 
 
 # ----------------------------------------------------------------------------------------- StoryDiffusion
@@ -528,9 +629,13 @@ def gen_moe():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if sys.argv[1:] == ["routing_fuzz"]:          # only the random routing fixture (the other generators are unchanged)
+        gen_routing_fuzz()
+        sys.exit(0)
     gen_llama()
     gen_llama_d128()
     gen_routing()
+    gen_routing_fuzz()
     gen_story()
     gen_moe()
     gen_qformer()

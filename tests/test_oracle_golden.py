@@ -147,6 +147,20 @@ def test_routing_matches_reference(golden_dir):
         assert (gp, pa, sn) == (s["general_prompt"], s["prompt_array"], s["style_name"]), s["text"]
 
 
+def test_oracle_routing_matches_reference_on_random_grammar_strings(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "routing_ref_fuzz.json")))
+    for c in ref["cases"]:
+        text = c["text"]
+        assert orouting.get_llm_text_modality(text, ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX"]) == c["modality"], repr(text)
+        for m_, r in c["res"].items():
+            assert orouting.get_llm_text_res(text, m_) == r, repr(text)
+        if not c["none_mode"]:
+            answers, ptext, calls, _ = orouting.route(text)
+            assert answers == c["answers"] and ptext == c["predictions_text"] and [list(x) for x in calls] == c["calls"], repr(text)
+    for s in ref["story"]:
+        assert orouting.extract_story_elements(s["text"]) == (s["general_prompt"], s["prompt_array"], s["style_name"]), repr(s["text"])
+
+
 def test_routing_known_answers():
     # spider_decoder_infer.py:139-142 and spider_decoder.py:284-295
     answers, ptext, _, _ = orouting.route("<IMAGE>apple</IMAGE><VIDEO>dog</VIDEO><AUDIO>cat</AUDIO>")

@@ -31,6 +31,39 @@ def test_routing_matches_reference_golden(golden_dir):
         assert routing.extract_answer(s["text"]) == s["answer"]
 
 
+def test_routing_matches_reference_on_random_grammar_strings(golden_dir):
+    """400 routing strings + 250 story strings drawn from a grammar (random tag order, nesting and damage, regex metacharacters,
+    unicode, <think> blocks, every clean_prompt_array fallback), answered by the reference's own functions
+    (tests/golden/make_golden.py routing_fuzz): containers, decoder-call order, story triples and extract_answer all exact."""
+    ref = json.load(open(os.path.join(golden_dir, "routing_ref_fuzz.json")))
+    assert len(ref["cases"]) == 400 and len(ref["story"]) == 250
+    n_calls = 0
+    for c in ref["cases"]:
+        calls = []
+        def fake(mod, ret_none=False):
+            def f(samples, **kw):
+                calls.append([mod, samples["llm_text_res"][0]])
+                return None if ret_none else [f"{mod}:{samples['llm_text_res'][0]}"]
+            return f
+        def fake_box(samples):
+            calls.append(["BOX", samples["llm_text_res"][0]])
+            return dict(outputs_bboxes=[["bb"]], outputs_label_names=[["ln"]], outputs_scores=[[0.9]])
+        nm = c["none_mode"]
+        dm = dict(IMAGE=fake("IMAGE", nm), VIDEO=fake("VIDEO"), AUDIO=fake("AUDIO", nm), MASK=fake("MASK"), BOX=fake_box, IMAGESTORY=None)
+        answers, predictions, ptext = routing.new_outputs()
+        a, p, pt = routing.route({"llm_text_all": [c["text"]]}, answers, predictions, ptext, dm)
+        assert a == c["answers"] and pt == c["predictions_text"] and p == c["predictions"] and calls == c["calls"], repr(c["text"])
+        assert routing.get_llm_text_modality(c["text"], ["IMAGE", "VIDEO", "AUDIO", "MASK", "BOX"]) == c["modality"], repr(c["text"])
+        for m, want in c["res"].items():
+            assert routing.get_llm_text_res(c["text"], m) == want, (m, repr(c["text"]))
+        n_calls += len(calls)
+    assert n_calls > 300                                # the strings do exercise the decoders
+    for s in ref["story"]:
+        assert s["raises"] is None                      # (the reference never raised on these; a raise would be part of the contract)
+        assert routing.extract_story_elements(s["text"]) == (s["general_prompt"], s["prompt_array"], s["style_name"]), repr(s["text"])
+        assert routing.extract_answer(s["text"]) == s["answer"], repr(s["text"])
+
+
 def test_known_answers_and_registry():
     a, pt, calls = routing.route_text("<IMAGE>apple</IMAGE><VIDEO>dog</VIDEO><AUDIO>cat</AUDIO>")
     assert pt == {'IMAGE': ['apple'], 'VIDEO': ['dog'], 'AUDIO': ['cat'], 'MASK': [], 'BOX': [], 'IMAGESTORY': [],
