@@ -134,3 +134,66 @@ def test_spider_decoder_generate_batch_runs_each_decoder_once(dev):
         assert pt["VIDEO"] == [f"sea {i}"] and len(p["VIDEO"]) == 1 and len(p["VIDEO"][0]) == 16 and p["VIDEO"][0][0].shape == (320, 576, 3)
         assert len(p["IMAGE"]) == 1 and p["IMAGE"][0].size == (64, 64) and p["AUDIO"][0].shape == (80000,) and np.isfinite(p["AUDIO"][0]).all()
         assert all(np.isfinite(np.asarray(f, dtype=np.float32)).all() for f in p["VIDEO"][0])
+
+
+def _close_np(a, b, tol, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    e = float(np.abs(a - b).mean() / (np.abs(b).mean() + 1e-12))
+    assert e < tol, f"{what}: mean relative difference {e:.3e}"
+
+
+def test_sd_pipeline_rows_of_a_batch_equal_single_calls(dev):
+    """Row b of a batched call = the call on prompt b alone with latent b (other tilings of the same arithmetic: a bound, not bit equality),
+    `num_images_per_prompt` = the prompt repeated, guidance 1.0 runs without the unconditional half, a per-prompt negative prompt list is
+    honoured, and the reference's argument checks raise (custom_sd.py:395-457)."""
+    pipe, _ = _pipe(dev)
+    prompts = ["a red car", "a blue boat on a lake", "x"]
+    lat = torch.randn(3, 4, 16, 24, generator=torch.Generator().manual_seed(3))
+    kw = dict(num_inference_steps=5, guidance_scale=6.0, height=64, width=96, output_type="np")
+    batched = pipe(prompt=prompts, latents=lat, **kw).images
+    assert batched.shape == (3, 64, 96, 3)
+    for b, p in enumerate(prompts):
+        single = pipe(prompt=[p], latents=lat[b:b + 1], **kw).images
+        _close_np(batched[b], single[0], 2e-2, f"row {b}")
+    two = pipe(prompt=["a red car"], num_images_per_prompt=2, latents=lat[:2], **kw).images
+    rep = pipe(prompt=["a red car", "a red car"], latents=lat[:2], **kw).images
+    assert np.array_equal(two, rep)
+    assert not np.array_equal(two[0], two[1])                      # two latents -> two images
+    neg = pipe(prompt=prompts[:2], negative_prompt=["blurry", "dark"], latents=lat[:2], **kw).images
+    neg_single = pipe(prompt=prompts[1:2], negative_prompt=["dark"], latents=lat[1:2], **kw).images
+    _close_np(neg[1], neg_single[0], 2e-2, "negative prompt row")
+    assert np.abs(neg[1] - batched[1]).mean() > 1e-4               # the negative prompt does change the sample
+    nocfg = pipe(prompt=prompts[:1], latents=lat[:1], num_inference_steps=5, guidance_scale=1.0, height=64, width=96, output_type="np").images
+    assert nocfg.shape == (1, 64, 96, 3) and np.isfinite(nocfg).all() and np.abs(nocfg[0] - batched[0]).mean() > 1e-4
+    with pytest.raises(ValueError):
+        pipe(prompt=prompts[:1], height=60, width=96)                              # not divisible by 8
+    with pytest.raises(ValueError):
+        pipe(prompt=prompts[:2], negative_prompt=["only one"], **kw)               # negative prompt batch mismatch
+    with pytest.raises(ValueError):
+        pipe(prompt=prompts[:1], prompt_embeds=torch.zeros(1, 77, 64), **kw)       # both prompt and prompt_embeds
+    with pytest.raises(ValueError):
+        pipe(**kw)                                                                 # neither
+
+
+def test_audio_and_video_pipeline_rows_of_a_batch_equal_single_calls(dev):
+    from helpers import tiny_audio_pipe, tiny_video_pipe
+    ad = tiny_audio_pipe(dev)
+    prompts = ["rain on a tin roof", "a dog barks twice"]
+    g = lambda s: torch.Generator(device=dev).manual_seed(s)
+    both = ad(prompt=prompts, num_inference_steps=4, audio_length_in_s=0.5, generator=g(1)).audios
+    assert both.shape[0] == 2 and np.isfinite(both).all() and not np.array_equal(both[0], both[1])
+    two = ad(prompt=prompts[:1], num_waveforms_per_prompt=2, num_inference_steps=4, audio_length_in_s=0.5, generator=g(1)).audios
+    assert two.shape == both.shape
+    with pytest.raises(ValueError):
+        ad(prompt=prompts, audio_length_in_s=-1.0)
+    vd = tiny_video_pipe(dev)
+    lat = torch.randn(2, 4, 3, 8, 8, generator=torch.Generator().manual_seed(7))
+    kw = dict(num_frames=3, num_inference_steps=4, height=32, width=32, output_type="pt")
+    vb = vd(prompt=["waves at sunset", "a city at night"], latents=lat, **kw).frames
+    assert vb.shape[0] == 2 and torch.isfinite(vb).all()
+    for b, p in enumerate(["waves at sunset", "a city at night"]):
+        vs = vd(prompt=[p], latents=lat[b:b + 1], **kw).frames
+        _close_np(vb[b].float().cpu().numpy(), vs[0].float().cpu().numpy(), 3e-2, f"video row {b}")
+    with pytest.raises(ValueError):
+        vd(prompt=["x"], height=30, width=32)
