@@ -76,10 +76,12 @@ class SyntheticOmniProcessor:
         return "\n".join(parts) + ("\n<|im_start|>assistant\n" if add_generation_prompt else "")
 
     def __call__(self, text=None, audios=None, images=None, videos=None, return_tensors="pt", padding=True):
-        ids = self._tok([text] if isinstance(text, str) else list(text), padding="longest").input_ids
-        ids = torch.cat([ids, torch.full((ids.shape[0], 1), self.ASSISTANT, dtype=ids.dtype)], 1)
-        self.prompt_len = ids.shape[1]
-        return {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+        rows = [self._tok._ids(t) + [self.ASSISTANT] for t in ([text] if isinstance(text, str) else list(text))]
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([[2] * (L - len(r)) + r for r in rows], dtype=torch.long)          # LEFT padding, as batched generation needs
+        mask = torch.tensor([[0] * (L - len(r)) + [1] * len(r) for r in rows], dtype=torch.long)
+        self.prompt_len = L
+        return {"input_ids": ids, "attention_mask": mask}
 
     def batch_decode(self, text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
         names = {"IMAGE": "scene", "AUDIO": "sound", "VIDEO": "clip"}

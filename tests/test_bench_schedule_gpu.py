@@ -115,3 +115,27 @@ def test_pipelined_soak_changing_geometry(dev, depth):
     torch.cuda.manual_seed(77)
     again = [key(r) for r in infer.pipelined(reqs)]
     assert all(a[0] == r[0] and torch.equal(a[1], r[1]) and np.array_equal(a[2], r[2]) for a, r in zip(again, ref))
+
+
+def test_pipelined_groups_answer_conversations_together(dev):
+    """`pipelined(conversations, group=2)` on the real engines: pairs of conversations of different lengths go through ONE batched LLM
+    pass (left-padded rows) and ONE batched decoder pass, overlapped with the neighbouring pairs; every conversation gets the result
+    the same pair gets from `predict` on the batched request (token ids and image bytes equal), in request order."""
+    import numpy as np
+    bench = _bench()
+    resp = bench.Responder(_args(batch=2, prompt_len=96, new_tokens=8, denoise_steps=3), dev)
+    infer = resp.infer
+    words = [12, 30, 30, 12, 20, 20, 41, 12, 12]
+    convs = [[{"role": "user", "content": " ".join(f"w{(5 * i + j) % 83}" for j in range(n))}] for i, n in enumerate(words)]
+    key = lambda r: (r.response, r.text_ids.cpu(), np.asarray(r.predictions["IMAGE"][0]).copy())
+    torch.cuda.manual_seed(5)
+    ref = []
+    for i in range(0, len(convs), 2):
+        out = infer.predict(inputs=infer.build_inputs_batch(convs[i:i + 2]))
+        ref += [key(r) for r in (out if isinstance(out, list) else [out])]
+    torch.cuda.manual_seed(5)
+    got = [key(r) for r in infer.pipelined(convs, group=2)]
+    assert len(got) == len(convs) == len(ref)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g[0] == r[0] and torch.equal(g[1], r[1]) and np.array_equal(g[2], r[2]), f"conversation {i}"
+    assert len({g[0] for g in got}) > 3

@@ -187,3 +187,44 @@ def test_depth3_pipelining_state_machine():
     assert list(r.response for r in infer.pipelined(reqs[:4])) == serial[:4]
     with pytest.raises(ValueError):
         SpiderFreeInfer(FakeThinker(), proc, dinf, device="cpu", depth=3)
+
+
+def test_pipelined_groups_conversations_into_batched_requests():
+    """`pipelined(requests, group=n)`: consecutive conversations are answered together (one LLM pass with n left-padded rows, one
+    decoder pass), every conversation still gets its own result in request order; a trailing partial group and processor-output
+    dicts in between are handled; group=1 is the plain form."""
+    infer, pipe, thinker = make()
+    convs = [[{"role": "user", "content": " ".join(["word"] * (2 + 3 * i))}] for i in range(5)]       # different lengths: padding matters
+    singles = [infer.predict(messages=m) for m in convs]
+    infer2, pipe2, thinker2 = make()
+    got = list(infer2.pipelined(convs, group=2))
+    assert len(got) == 5 and all(not isinstance(r, list) for r in got)
+    # rows are left-padded: each row's generated part starts after its assistant marker, so the per-conversation responses are the
+    # ones the single calls produce (the fake thinker derives its tokens from the first column: rows of a batch share it with ... pad)
+    assert [tuple(c[1]) for c in thinker2.calls] == [(2, thinker2.calls[0][1][1]), (2, thinker2.calls[1][1][1]), (1, thinker2.calls[2][1][1])]
+    assert [len(c[1]) for c in pipe2.calls] == [2, 2, 1]                      # one decoder pass per group, one caption per row
+    assert [r.predictions_text["IMAGE"] for r in got[4:]] == [singles[4].predictions_text["IMAGE"]]      # the un-padded last one is identical
+    # left padding: the mask of the shorter row of a pair starts with zeros, the longer row has none
+    inputs = infer2.build_inputs_batch(convs[:2])
+    am = inputs["attention_mask"]
+    assert am.shape[0] == 2 and int(am[1].min()) == 1 and int(am[0, 0]) == 0 and int(am[0, -1]) == 1
+    assert int(inputs["input_ids"][0, -1]) == infer2.processor.ASSISTANT and int(inputs["input_ids"][1, -1]) == infer2.processor.ASSISTANT
+    # dict requests pass through and flush the open group first; order is kept
+    infer3, pipe3, _ = make()
+    one = infer3.build_inputs(convs[0])
+    mixed = [convs[0], one, convs[1], convs[2]]
+    out3 = list(infer3.pipelined(mixed, group=2))
+    assert len(out3) == 4 and [len(c[1]) for c in pipe3.calls] == [1, 1, 2]
+    assert [r.response for r in infer3.pipelined(convs, group=1)] == [r.response for r in make()[0].pipelined(convs)]
+    with pytest.raises(ValueError):
+        list(infer3.pipelined(convs, group=0))
+
+
+def test_build_inputs_batch_switches_a_right_padding_tokenizer_to_the_left():
+    infer, _, _ = make()
+
+    class Tok:
+        padding_side = "right"
+    infer.processor.tokenizer = Tok()
+    infer.build_inputs_batch([[{"role": "user", "content": "a"}], [{"role": "user", "content": "b c d"}]])
+    assert infer.processor.tokenizer.padding_side == "left"
