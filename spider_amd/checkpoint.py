@@ -94,8 +94,7 @@ def load_state_dict(path: str, variant: Optional[str] = None,
                         out[kk] = sf.get_tensor(k)
         else:
             sd = torch.load(f, map_location="cpu", weights_only=True)
-            if isinstance(sd, dict) and "state_dict" in sd and all(isinstance(v, dict) or torch.is_tensor(v) for v in sd.values()) \
-                    and isinstance(sd["state_dict"], dict):
+            if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):       # trainer-style wrapper around the tensors
                 sd = sd["state_dict"]
             for k, v in sd.items():
                 if not torch.is_tensor(v):
