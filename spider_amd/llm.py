@@ -194,7 +194,10 @@ class StoppingCriteriaSub:
 
 class LlamaEngine:
     DECODE_ROWS = 8     # sequences per decode graph (lm_head / split-KV workspaces are sized for 8)
-    FM_MIN_BATCH = 5    # from this many sequences on the decode GEMVs run as skinny MFMA GEMMs on fragment-major weight copies
+    # From this many sequences on the decode GEMVs run as skinny MFMA GEMMs on fragment-major weight copies (SPIDER_DECODE_FM_MIN).
+    # Measured on MI355X, Qwen2.5-7B shapes at context 1536 (scripts/exp/decode_vs_batch.py), ms per decode step by rows 1 / 2 / 3 / 4 / 5 / 8:
+    # row-major GEMVs 2.84 / 3.28 / 3.75 / 4.36 (then fragment-major 3.21 / 3.43); fragment-major from 2 rows: 2.99 / 3.09 / 3.16 / 3.23 / 3.43.
+    FM_MIN_BATCH = int(os.environ.get("SPIDER_DECODE_FM_MIN", "2"))
 
     def __init__(self, cfg: LLMConfig, weights: dict, device="cuda:0", max_batch: int = 1, max_len: int = 4096):
         self.cfg, self.device = cfg, torch.device(device)
@@ -380,7 +383,7 @@ class LlamaEngine:
         if hs is not None:
             hs[0].copy_(h)
         fm = self.fm_batch and B >= self.FM_MIN_BATCH
-        fuse_norm = B < 5      # >= 5 sequences use the skinny MFMA GEMM, which takes pre-normalised activations
+        fuse_norm = not fm and B < 5      # the row-major GEMV folds the RMSNorm for up to 4 rows; the skinny MFMA GEMM (fm) carries it in its weights
         for l, lw in enumerate(self.layers):
             if fuse_norm:
                 ops.gemv(lw["w_qkv"], h, bias=lw["b_qkv"], norm_w=lw["ln1"], eps=c.eps, out=st["qkv"])

@@ -95,7 +95,7 @@ class SpiderFreeInfer:
         generation needs LEFT padding (the prompt must end where generation starts): a processor whose tokenizer pads on the right is
         switched to the left, as HF's `generate` asks for. The rows are then answered together -- one batched LLM pass (the decode
         weight stream serves every row) and one batched decoder pass -- which is what lifts responses per second on one GPU from
-        1.94 (one request at a time) to 2.98 / 3.77 / 5.39 at 2 / 4 / 8 rows."""
+        1.95 (one request at a time) to 3.05 / 4.37 / 5.54 at 2 / 4 / 8 rows."""
         texts = [self.processor.apply_chat_template(m, add_generation_prompt=True, tokenize=False) for m in conversations]
         audios = images = videos = None
         if self.process_mm_info is not None:
