@@ -158,7 +158,16 @@ int spider_conv2d_nhwc_bf16(const void* x, const void* w, void* y, const void* b
  * the AudioLDM latent height 125 is not a multiple of 8: custom_ad.py:490-504), fused activation (1 silu, 2 gelu,
  * 3 quick-gelu, 5 leaky-relu(act_param), 6 relu, 7 tanh). 1-D convs (HiFi-GAN vocoder behind
  * custom_ad.py:293-300) are Hin = kh = 1; the (3,1,1) temporal convs of UNet3D (custom_vd.py:671-676) are
- * Hin = frames, Win = H*W, kh = 3, kw = 1. */
+ * Hin = frames, Win = H*W, kh = 3, kw = 1.
+ * w_tiled: 0 = w as stored (OHWI); 1 = its tile-major copy (see spider_gemm_bf16); 2 = its FRAGMENT-MAJOR copy
+ * [ceil(Cout/32)*2][(Cin/32)*9][64 lanes][8]: piece (rg, cb*9 + tap) holds at lane 16 g + r the 8 values
+ * w[16 rg + r, tap, 32 cb + 8 g .. + 8] (Cout zero-padded to a multiple of 32) -- operand of the weight-stationary streaming
+ * kernel that serves the weight-bound levels of the UNet (ResnetBlock2D convs / the 2x upsampler at <= 512 output pixels,
+ * custom_sd.py:634-639): 3x3, stride 1, pad 1, dil 1, Cin % 32 == 0, no activation, B*Hout*Wout <= 512 (and <= 128 input
+ * pixels when B*Hout*Wout <= 128); anything else with w_tiled = 2 is refused. With w_tiled = 2 the workspace must extend 4096
+ * bytes beyond ws_bytes, zero-initialised once: the arrival counters of the in-launch split-K combine (the block that arrives
+ * last at a strip's counter sums the partial slabs in split order and applies the epilogue; the counters are zero again when
+ * the call has completed, so graph replays and later calls need no reset). */
 int spider_conv_nhwc_ex_bf16(const void* x, const void* w, void* y, const void* bias, const void* res,
                              const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                              int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,

@@ -15,6 +15,7 @@
 // ds_read_b128 / ds_write_b128), double-buffered, with a 2-deep global->register prefetch ring.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace spider;
 
@@ -101,6 +102,11 @@ struct GemmArgs {
     const h16_t* gna_beta;
     int gna_nchunk, gna_G, gna_hw;
     float gna_eps;
+    // weight-stationary streaming conv (wstream_kernel, w_tiled == 2): ws_ncb = Cin / 32 channel blocks, ws_cpb of them per K split
+    // (blockIdx.y), ws_rows = rows of the activation slab (input pixels B * Hin * Win); ws_cnt: per-strip arrival counters of the
+    // in-launch split-K combine (zero when idle; null: partial slabs are left to splitk_reduce_kernel)
+    int ws_ncb, ws_cpb, ws_rows;
+    unsigned* ws_cnt;
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -1617,6 +1623,308 @@ __global__ __launch_bounds__(512, 1) void gemm_p8h_kernel(GemmArgs p) {
     write_out<4, 4, EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, split, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-stationary streaming 3x3 conv for the weight-bound levels of the UNet (M = B * Hout * Wout <= 512 output pixels against
+// 15 - 59 MB of weights that are read once per evaluation: the 16^2 / 8^2 maps of SD-v1.5 at CFG batch 2; ResnetBlock2D conv1 / conv2
+// and the 2x upsampler there, call site custom_sd.py:634-639). Built like the decode path, not like the tile kernels above:
+//   * W is a FRAGMENT-MAJOR copy (ops.repack_fm_conv): for every group of 16 output channels and every (32-channel block cb, tap)
+//     one 1 KiB piece = the A operand of mfma_f32_16x16x32, pieces of a channel block contiguous. Every wave streams its own pieces
+//     global -> registers, 16 B per lane, a whole channel block (9 taps x 2 column tiles = 18 KiB) ahead of its use.
+//   * the activations are the B operand: a channel block of ALL input pixels (the slab, 64 B per pixel, XOR-swizzled 16-byte
+//     chunks) sits in LDS and serves the 9 taps -- the taps are gathered by LDS addressing (a shifted row, or a zero row outside
+//     the image), so A travels L2 -> CU once per channel block instead of once per tap.
+//   * 8 waves = WM groups of 128 output rows x WK K-groups. Each K-group owns every WK-th channel block of the split's range and
+//     has its own double-buffered slab (wave-private at WM = 1: no barrier in the loop); a block = one 32-column strip x one K
+//     split, so N / 32 x splits ~ 200-256 blocks keep every CU pulling. The K-groups are summed through LDS in a fixed order.
+//   * split-K partials go to the fp32 workspace like the tile kernels' (write_out); combine: splitk_reduce_kernel, or in-launch by
+//     the block that arrives last at the strip's counter (GemmArgs::ws_cnt), slabs summed in split order either way.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WS_NTW = 2;          // 16-column tiles per wave (strip = 32 output channels)
+constexpr int WS_TAPS = 9;
+
+__device__ __forceinline__ uint32_t ws_swz(uint32_t row) {      // chunk permutation of slab row `row` (conflict-free ds_read_b128)
+    const uint32_t q = (row >> 2) & 3u;                         // {0, 1, 2, 3} -> {0, 3, 2, 1}
+    return (q ^ (q << 1)) & 3u;
+}
+constexpr int WS_ZERO = 7 * 1024 + 64;      // LDS bytes in front of the slabs: 64 zero bytes at every 1024 i (see the tap loop)
+
+template <int WM, int WK, bool UPS>
+__global__ __launch_bounds__(512, 1) void wstream_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTW = WS_NTW, T = WS_TAPS, TPF = 8 / WK;
+    constexpr int SLAB = 8192 * WM;                  // bytes: 128 * WM pixel rows x 64 B
+    constexpr int GS = 64 * WM;                      // threads of a K-group
+    constexpr int AUXW = WM == 1 ? 2 : 0;            // nt on weights only one wave reads
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, kg = wave / WM;
+    const int r = lane & 15, g = lane >> 4;
+    const int strip = blockIdx.x, split = blockIdx.y;
+    const int ncb = p.ws_ncb;
+    const int cb0 = split * p.ws_cpb, cb1 = min(ncb, cb0 + p.ws_cpb);
+    const int nit = (p.dbg & 16) ? 0 : (cb1 - cb0 + WK - 1) / WK;       // iterations of every K-group (a group past the range streams zeros)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16_t*>(p.W), 0, p.w_bytes, 0x00020000);
+
+    // zero fragments: lanes whose tap lies outside the image read 16 B at 16 g + 1024 i -- the same immediate offsets as the slab reads
+    if (tid < 128) reinterpret_cast<uint32_t*>(smem + 1024 * (tid >> 4))[tid & 15] = 0u;
+    const uint32_t slab_off = (uint32_t)WS_ZERO + (uint32_t)kg * 2u * SLAB;
+
+    // ---- per 16-row tile i (rows m = 128 wm + 16 i + r): one byte of flags -- 1 top row, 2 bottom row, 4 left column, 8 right column
+    // of the (upsampled) image, 16 row past M; a tap is outside the image iff its static mask meets the flags. Without the upsample
+    // the conv keeps the map size (3 x 3, pad 1, stride 1: host-checked) and tap (dy, dx) of row m is slab row m + (dy-1) Win + dx-1.
+    uint32_t fl[2] = {0u, 0u};
+    int uyx[UPS ? 8 : 1];        // UPS: (oy - 1) | (ox - 1) << 8 (signed bytes: maps of <= 512 pixels) | image << 16
+    {
+        const float inv_hw = 1.f / (float)(p.Hout * p.Wout), inv_w = 1.f / (float)p.Wout;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = wm * 128 + 16 * i + r;
+            const int mc = m < p.M ? m : 0;
+            const int b = (int)(((float)mc + 0.5f) * inv_hw), rem = mc - b * (p.Hout * p.Wout);     // exact for these sizes (< 2^20)
+            const int oy = (int)(((float)rem + 0.5f) * inv_w), ox = rem - oy * p.Wout;
+            const uint32_t f = (oy == 0 ? 1u : 0u) | (oy == p.Hout - 1 ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox == p.Wout - 1 ? 8u : 0u) |
+                               (m < p.M ? 0u : 16u);
+            fl[i >> 2] |= f << (8 * (i & 3));
+            if (UPS) uyx[i] = ((oy - 1) & 0xff) | (((ox - 1) & 0xff) << 8) | (b << 16);
+        }
+    }
+
+    // ---- slab of channel block cb: 8 chunks of 16 B per thread of the K-group, global -> registers -> LDS, in two halves (the
+    // staging registers of a half are live for half an iteration)
+    const int tg = wm * 64 + lane;
+    u32x4 sreg[4];
+    auto slab_load = [&](int it, int half) {
+        const int cb = cb0 + kg + it * WK;
+        const uint32_t cinv = (uint32_t)((cb1 - 1 - cb) >> 31) | ((p.dbg & 4) ? 0xFFFFFFFFu : 0u);     // dbg 4: no slab traffic
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tg + (half * 4 + j) * GS, row = c >> 2, ch = c & 3;
+            const uint32_t rinv = (uint32_t)((p.ws_rows - 1 - row) >> 31);
+            const uint32_t off = ((uint32_t)row * (uint32_t)p.lda + (uint32_t)cb * 32u + (uint32_t)ch * 8u) * 2u;
+            sreg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off | cinv | rinv, 0, 0));
+        }
+    };
+    auto slab_store = [&](int buf, int half) {
+        char* dst = smem + slab_off + buf * SLAB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = (uint32_t)(tg + (half * 4 + j) * GS), row = c >> 2, ch = c & 3u;
+            *reinterpret_cast<u32x4*>(dst + row * 64u + ((ch ^ ws_swz(row)) << 4)) = sreg[j];
+        }
+    };
+    // ---- W pieces of (iteration it, tap t): one 16-byte load per lane and column tile
+    u32x4 wq[T][NTW];
+    const uint32_t piece0 = (uint32_t)(strip * NTW) * (uint32_t)(ncb * T);
+    auto w_load = [&](int it, int t) {
+        const int cb = cb0 + kg + it * WK;
+        const uint32_t cinv = (uint32_t)((cb1 - 1 - cb) >> 31) | ((p.dbg & 2) ? 0xFFFFFFFFu : 0u);     // dbg 2: no W stream (tuning aid)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const uint32_t off = (piece0 + (uint32_t)n * (uint32_t)(ncb * T) + (uint32_t)(cb * T + t)) * 1024u + (uint32_t)lane * 16u;
+            wq[t][n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off | cinv, 0, AUXW));
+        }
+    };
+
+    f32x4 acc[8][NTW];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    {   // first slab: both halves in flight ahead of the W pieces (loads return in order: the slab must not queue behind 18 KiB of W)
+        u32x4 s0[4];
+        slab_load(0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0[j] = sreg[j];
+        slab_load(0, 1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) w_load(0, t);
+        __syncthreads();                    // the zero fragments are written
+        slab_store(0, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sreg[j] = s0[j];
+        slab_store(0, 0);
+    }
+    if (WM > 1) __syncthreads();
+
+    const int Win = p.Win, hw_in = p.Hin * p.Win;
+    int row00 = wm * 128 + r - Win - 1;                 // slab row of tap (0, 0) of tile 0
+    const uint32_t zoff = (uint32_t)g * 16u;
+    // one channel block; PF: the next one is prefetched behind it (the last iteration issues no loads at all: every 16-byte wave load
+    // costs 16 cycles of the CU's address path whether or not its offset is in range)
+    auto iter = [&](int it, auto pf_tag) {
+        constexpr bool PF = decltype(pf_tag)::value;
+        const uint32_t cur_off = slab_off + (uint32_t)((it & 1) * SLAB);
+        // (the per-tap addresses and masks do not depend on `it`: keep them from being hoisted out of this loop into ~100 registers)
+        asm volatile("" : "+v"(row00), "+v"(fl[0]), "+v"(fl[1]));
+        if (UPS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(uyx[i]));
+        }
+        if (PF) slab_load(it + 1, 0);   // (a K-group past the range streams zeros: the load counters stay exact)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int dy = t / 3, dx = t % 3;
+            constexpr uint32_t M4 = 0x01010101u;
+            if (p.dbg & 1) {                // dbg 1: loads only (the W pieces are kept alive, nothing is read from LDS or multiplied)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) asm volatile("" ::"v"(wq[t][n]));
+                if (PF) {
+                    w_load(it + 1, t);
+                    if (t == 4) { slab_store((it + 1) & 1, 0); slab_load(it + 1, 1); }
+                }
+                continue;
+            }
+            const uint32_t tmask = (16u | (dy == 0 ? 1u : 0u) | (dy == 2 ? 2u : 0u) | (dx == 0 ? 4u : 0u) | (dx == 2 ? 8u : 0u)) * M4;
+            h16x8 xf[8];
+            if (UPS) {      // (4 tiles at a time: the per-tile source coordinates cost registers)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = hh * 4 + ii;
+                        const uint32_t bad = fl[i >> 2] & (tmask & (0xffu << (8 * (i & 3))));
+                        const int uy = ((int)(signed char)(uyx[i] & 0xff) + dy) >> 1, ux = ((int)(signed char)((uyx[i] >> 8) & 0xff) + dx) >> 1;
+                        const uint32_t row = (uint32_t)((uyx[i] >> 16) * hw_in + uy * Win + ux);
+                        const uint32_t a_ok = cur_off + row * 64u + (((uint32_t)g ^ ws_swz(row)) << 4);
+                        xf[ii] = *reinterpret_cast<const h16x8*>(smem + (bad ? zoff : a_ok));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int n = 0; n < NTW; ++n)
+                            acc[hh * 4 + ii][n] = mfma_16x16x32_h16(__builtin_bit_cast(h16x8, wq[t][n]), xf[ii], acc[hh * 4 + ii][n]);
+                    __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler hoists every tile's address arithmetic: spills)
+                }
+            } else {
+                // tile i reads slab row (row_t + 16 i): the swizzle term depends on bits 2-3 of the row, which + 16 i leaves alone
+                const uint32_t row_t = (uint32_t)(row00 + dy * Win + dx);
+                const uint32_t base_t = cur_off + row_t * 64u + (((uint32_t)g ^ ws_swz(row_t)) << 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t bad = fl[i >> 2] & (tmask & (0xffu << (8 * (i & 3))));
+                    const uint32_t sel = bad ? zoff : base_t;
+                    xf[i] = *reinterpret_cast<const h16x8*>(smem + sel + 1024 * i);
+                }
+            }
+            if (!UPS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n)
+                        acc[i][n] = mfma_16x16x32_h16(__builtin_bit_cast(h16x8, wq[t][n]), xf[i], acc[i][n]);
+            }
+            if (PF) {
+                w_load(it + 1, t);          // the same slot, one channel block ahead
+                if (t == 4) { slab_store((it + 1) & 1, 0); slab_load(it + 1, 1); }
+            }
+        }
+        if (PF) {
+            slab_store((it + 1) & 1, 1);
+            if (WM > 1) __syncthreads();
+        }
+    };
+    for (int it = 0; it + 1 < nit; ++it) iter(it, std::true_type{});
+    if (nit > 0) iter(nit - 1, std::false_type{});
+
+    // ---- K-groups summed through LDS in group order; the finalizer of tile i is K-group i / TPF
+    if (p.dbg & 8) {                    // tuning aid: no combine, no output
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+        return;
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem + WS_ZERO);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+            red[((((wm * 8 + i) * WK + kg) * NTW + n) << 6) + lane] = acc[i][n];
+    __syncthreads();
+    f32x4 fin[TPF][NTW];
+#pragma unroll
+    for (int j = 0; j < TPF; ++j)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < WK; ++kk) v += red[((((wm * 8 + kg * TPF + j) * WK + kk) * NTW + n) << 6) + lane];
+            fin[j][n] = v;
+        }
+    if (p.splits == 1 || p.ws_cnt == nullptr) {       // no split, or partial slabs for splitk_reduce_kernel
+        write_out<TPF, NTW, 0>(p, fin, wm * 128 + kg * TPF * 16, strip * (16 * NTW), split, lane);
+        return;
+    }
+
+    // ---- in-launch split-K combine. Publish: the partial tile goes out with WRITE-THROUGH (sc1) 16-byte stores, every wave drains
+    // them (vmcnt(0)), one barrier, then ONE lane adds to the strip's arrival counter -- no release fence (a fence per block writes the
+    // whole L2 back: measured + 6 us at 128 rows, + 21 us at 512). The block whose add came last reads the slabs of ALL splits with
+    // sc1 loads (served past L1 / the local L2's stale lines) in split order -- the same sum whichever block is last -- and applies the
+    // epilogue. The counter is zero whenever no launch is in flight: the last arriver resets it. (cdna guide, Guideline 16 R1 /
+    // MI355X_MICROARCH hand-off table row 1: one lane per storing workgroup adds after every wave's drain + a barrier; the other
+    // waves of the reducer load behind a barrier that the adding wave joins.)
+    const uint32_t ws_bytes_used = (uint32_t)((size_t)p.splits * p.M * p.N * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, ws_bytes_used, 0x00020000);
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, 0, 0, 0)) vec_t;
+    {
+        const int mb = wm * 128 + kg * TPF * 16, nb = strip * (16 * NTW);
+#pragma unroll
+        for (int j = 0; j < TPF; ++j)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int m = mb + j * 16 + (lane & 15), nn = nb + n * 16 + (lane >> 4) * 4;
+                const uint32_t inv = (uint32_t)(((p.M - 1 - m) | (p.N - 4 - nn)) >> 31);
+                const uint32_t off = (uint32_t)(((size_t)split * p.M + m) * p.N + nn) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vec_t, fin[j][n]), rsrc_ws, off | inv, 0, 16);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* lastflag = reinterpret_cast<uint32_t*>(smem + 64);          // LDS word outside the zero fragments
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.ws_cnt + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)p.splits - 1u;
+        if (last) __hip_atomic_store(p.ws_cnt + strip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lastflag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*lastflag == 0u) return;
+    {
+        const EpiRsrc er = make_epi_rsrc(p);
+        const int q = tid & 7, n = strip * (16 * NTW) + 4 * q;            // 8 column quads of the 32-column strip
+        const uint32_t slab_bytes = (uint32_t)((size_t)p.M * p.N * sizeof(float));
+        // every slab load of a batch of rows is in flight at once (a dependent loop of sc1 loads pays a memory round trip per step:
+        // measured + 4 us at 128 rows, + 18 us at 512); at most 8 splits (host-checked), slabs past the split count read as zeros
+        constexpr int RB = WM == 1 ? 2 : 4;
+#pragma unroll
+        for (int jb = 0; jb < 2 * WM; jb += RB) {
+            f32x4 t8[RB][8];
+#pragma unroll
+            for (int jj = 0; jj < RB; ++jj) {
+                const int m = (tid >> 3) + 64 * (jb + jj);
+                const uint32_t inv = (uint32_t)(((p.M - 1 - m) | (p.N - 4 - n)) >> 31);
+                const uint32_t off0 = (uint32_t)((size_t)m * p.N + n) * 4u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t sinv = (uint32_t)((p.splits - 1 - u) >> 31);
+                    t8[jj][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, (off0 + (uint32_t)u * slab_bytes) | inv | sinv, 0, 16));
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < RB; ++jj) {
+                const int m = (tid >> 3) + 64 * (jb + jj);
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[0] += t8[jj][u][0]; v[1] += t8[jj][u][1]; v[2] += t8[jj][u][2]; v[3] += t8[jj][u][3]; }
+                uint32_t rb_row = 0;
+                if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
+                epilogue_fast<false>(p, er, m, n, rb_row, v);
+            }
+        }
+    }
+}
+
 // {mean, rstd} of every row of A [M, K] (K % 8 == 0): one wave per row, fp32 sums -- the statistics the LN instantiations of
 // gemm_kernel accumulate while staging A (same formulas: var = max(E[x^2] - mean^2, 0)), for the kernel that stages by DMA
 __global__ __launch_bounds__(256) void ln_row_stats_kernel(const h16_t* __restrict__ A, float2* __restrict__ out, int M, int K, float eps) {
@@ -1734,6 +2042,13 @@ __global__ void splitk_reduce_gn_kernel(GemmArgs p, int cs) {
     }
 }
 
+#ifdef SPIDER_WS_DEV
+// development aid (scripts/exp/ws_isa.sh): only the streaming kernel is instantiated, for a quick look at its ISA
+template __global__ void wstream_kernel<1, 8, false>(GemmArgs);
+template __global__ void wstream_kernel<4, 2, false>(GemmArgs);
+template __global__ void wstream_kernel<4, 2, true>(GemmArgs);
+}  // namespace
+#else
 template <int BM, int BN>
 void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
@@ -1891,9 +2206,59 @@ int gn_reduce_slab(int cpg, int target) {
 }
 
 // gn_done (optional): set to true when the launch wrote GemmArgs::gn_part (the caller otherwise runs a statistics pass)
+template <int WM, int WK, bool UPS>
+void launch_ws_inst(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int smem = WS_ZERO + 16 * 8192;
+    static unsigned done = 0;
+    raise_dynamic_lds(&wstream_kernel<WM, WK, UPS>, smem, done);
+    wstream_kernel<WM, WK, UPS><<<grid, 512, smem, st>>>(a);
+}
+
+// is this problem one the weight-stationary streaming kernel serves? (mirrored by ops._ws_eligible: the caller packs W for it)
+bool ws_eligible(const GemmArgs& a) {
+    const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
+    if (!a.conv || a.kh != 3 || a.kw != 3 || a.stride != 1 || a.dil != 1 || a.pad_h != 1 || a.pad_w != 1 || a.Cin % 32 != 0 || a.act ||
+        a.geglu || a.ln_colsum || !fast_ok)
+        return false;
+    const int rows = a.M / (a.Hout * a.Wout) * a.Hin * a.Win;
+    if (a.M <= 128) return rows <= 128 && !a.ups;
+    return a.M <= 512 && rows <= 512;
+}
+
 int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     if (gn_done) *gn_done = 0;
+    static const int dbg = env_int("SPIDER_GEMM_DBG");
+    a.dbg = dbg;
+    if (a.w_tiled == 2) {
+        // weight-stationary streaming conv: strips of 32 columns x K splits of whole 32-channel blocks, ~200-256 blocks of 8 waves
+        const int WK = a.M <= 128 ? 8 : 2;
+        a.ws_ncb = a.Cin / 32;
+        a.ws_rows = a.M / (a.Hout * a.Wout) * a.Hin * a.Win;
+        const int strips = (a.N + 31) / 32;
+        static const int ws_blocks = env_int("SPIDER_WS_BLOCKS") ? env_int("SPIDER_WS_BLOCKS") : 256;
+        int S = (ws_blocks + strips / 2) / strips;
+        if (S < 1) S = 1;
+        int cpb = (a.ws_ncb + S - 1) / S;
+        cpb = (cpb + WK - 1) / WK * WK;                 // every K-group runs the same number of channel blocks
+        S = (a.ws_ncb + cpb - 1) / cpb;
+        if (!a.ws) { S = 1; cpb = a.ws_ncb; }
+        while (S > 1 && (size_t)S * a.M * a.N * sizeof(float) > (size_t)ws_bytes) { cpb += WK; S = (a.ws_ncb + cpb - 1) / cpb; }
+        a.ws_cpb = cpb;
+        a.splits = S;
+        a.kt_per_split = 0;
+        // in-launch combine by the last-arriving block of a strip: its arrival counters are the 4096 bytes BEHIND the declared
+        // workspace (zero when idle; contract of w_tiled = 2, see spider_hip.h)
+        static const int inl_env = getenv("SPIDER_WS_INLAUNCH") ? atoi(getenv("SPIDER_WS_INLAUNCH")) : 1;
+        a.ws_cnt = (inl_env && S > 1 && S <= 8 && strips <= 1024) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.ws) + ws_bytes) : nullptr;
+        dim3 grid(strips, S);
+        if (a.M <= 128) launch_ws_inst<1, 8, false>(a, grid, st);
+        else if (a.ups) launch_ws_inst<4, 2, true>(a, grid, st);
+        else launch_ws_inst<4, 2, false>(a, grid, st);
+        SPIDER_LAUNCH_OK();
+        if (a.ws_cnt) return 0;                                   // combined in the launch: no reduce kernel, no statistics
+        if (a.gn_part && a.splits == 1) a.gn_part = nullptr;      // no statistics epilogue here: the caller runs its own pass
+    } else {
     static const int force_tile = env_int("SPIDER_GEMM_TILE"), force_splits = env_int("SPIDER_GEMM_SPLITS");  // tuning aid
     const int nk = (a.K + BK - 1) / BK;
     const int ncols = a.geglu ? 2 * a.N : a.N;
@@ -1924,8 +2289,6 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     }
     if (force_tile) small = force_tile == 64;
     // SPIDER_GEMM_TILE = 160 / 161 (4-stage ring) / 129 (128 x 128 DMA tile): force the LDS-DMA kernel (tuning aid)
-    static const int dbg = env_int("SPIDER_GEMM_DBG");
-    a.dbg = dbg;
     static const int nfast_env = getenv("SPIDER_GEMM_NFAST") ? atoi(getenv("SPIDER_GEMM_NFAST")) : -1;
     a.n_fast = nfast_env >= 0 ? nfast_env : (a.M > ncols ? 1 : 0);
     int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : (force_tile == 65 ? 64 : 0));
@@ -2068,6 +2431,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     } else if (small) launch_tile<64, 64>(a, tiles, st);
     else launch_tile<128, 128>(a, tiles, st);
     SPIDER_LAUNCH_OK();
+    }
     if (a.splits > 1) {
         const int cs = (a.gn_part && a.splits <= 16 && a.gn_cpg > 0 && a.N % a.gn_cpg == 0 && a.N % 4 == 0 && a.M % 16 == 0 && !a.C32 &&
                         (!a.conv || a.rows_per_group % 16 == 0))
@@ -2209,9 +2573,10 @@ static int conv_impl(const void* x, const void* w, void* y, const void* bias, co
     a.hbits = (hb_env && a.cin64 && !ups && kh * kw <= 32) ? 1 : 0;
     SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
     a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
-    a.w_tiled = w_tiled ? 1 : 0;
-    a.w_bytes = w_tiled ? tiled_bytes(Cout, a.K) : (uint32_t)((size_t)Cout * a.K * 2);
+    a.w_tiled = w_tiled == 2 ? 2 : (w_tiled ? 1 : 0);
+    a.w_bytes = w_tiled == 2 ? (uint32_t)((size_t)((Cout + 31) / 32 * 32) * a.K * 2) : (w_tiled ? tiled_bytes(Cout, a.K) : (uint32_t)((size_t)Cout * a.K * 2));
     set_epilogue_ranges(a);
+    if (w_tiled == 2) SPIDER_CHECK(ws_eligible(a), "conv: w_tiled = 2 (fragment-major weights) needs a 3x3 stride-1 conv with <= 512 output pixels, Cin % 32 == 0");
     if (gn_part) {
         SPIDER_CHECK(gn_groups > 0 && Cout % gn_groups == 0, "conv_gn: Cout must be a multiple of the groups");
         a.gn_part = gn_part; a.gn_G = gn_groups; a.gn_cpg = Cout / gn_groups; a.gn_cr = 0;
@@ -2284,3 +2649,4 @@ int SPIDER_FN(spider_conv2d_nhwc)(const void* x, const void* w, void* y, const v
 }
 
 }  // extern "C"
+#endif  // SPIDER_WS_DEV

@@ -26,6 +26,7 @@ def _stream() -> int:
 
 _WS = {}
 WS_BYTES = 64 << 20
+WS_TAIL = 4096        # zero-initialised bytes behind the workspace: arrival counters of the streaming conv's in-launch combine
 
 
 import threading as _threading
@@ -62,7 +63,7 @@ def _workspace(device) -> torch.Tensor:
     engines run an eager warm-up pass before they capture)."""
     key = (device.type, device.index, _WS_SCOPE.names[-1])
     if key not in _WS:
-        _WS[key] = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
+        _WS[key] = torch.zeros((WS_BYTES + WS_TAIL) // 4, dtype=torch.float32, device=device)
     return _WS[key]
 
 
@@ -132,6 +133,55 @@ def prebuild_tiled(weights, max_rows: int = 64 << 20) -> int:
             t = _tiled(W, 1)
             n += 0 if t is None else t.numel() * t.element_size()
     return n
+
+
+# ---- fragment-major conv weights for the weight-stationary streaming kernel (csrc/gemm.hip: wstream_kernel, w_tiled == 2) ----
+WS_ENABLE = _os.environ.get("SPIDER_WS", "1") != "0"      # tuning aid: 0 = the tile kernels serve every conv
+WS_INLAUNCH = _os.environ.get("SPIDER_WS_INLAUNCH", "1") != "0"
+WS_MAX_M = int(_os.environ.get("SPIDER_WS_MAX_M", "128"))   # output pixels up to which the streaming kernel is used (it exists up to 512)
+
+
+def repack_fm_conv(W: torch.Tensor) -> torch.Tensor:
+    """W [Cout, 3, 3, Cin] 16-bit (OHWI, Cin % 32 == 0) -> [ceil(Cout / 32) * 2, (Cin / 32) * 9, 64, 8]: per group of 16 output
+    channels and per (32-channel block cb, tap) one 1 KiB piece whose lane 16 g + r holds W[16 rg + r, tap, 32 cb + 8 g : + 8] --
+    the A fragment of mfma_f32_16x16x32; the 9 taps of a channel block are contiguous. Output channels are zero-padded to a
+    multiple of 32 (one 2-tile strip per block). Pure data movement, once per weight."""
+    N, kh, kw, Cin = W.shape
+    assert kh == 3 and kw == 3 and Cin % 32 == 0
+    Np = (N + 31) // 32 * 32
+    if Np != N:
+        W = torch.cat([W, torch.zeros(Np - N, kh, kw, Cin, dtype=W.dtype, device=W.device)], 0)
+    # [rg, r, tap, cb, g, e] -> [rg, cb, tap, g, r, e]
+    return W.reshape(Np // 16, 16, 9, Cin // 32, 4, 8).permute(0, 3, 2, 4, 1, 5).contiguous().view(Np // 16, (Cin // 32) * 9, 64, 8)
+
+
+def _ws_eligible(B, Hin, Win, Cin, Cout, kh, kw, stride, pad, dil, up_size, Ho, Wo, act) -> bool:
+    """mirror of csrc/gemm.hip:ws_eligible -- 3 x 3 / stride 1 / pad 1 convs with <= 512 output pixels (and an input that fits the
+    LDS slab of the kernel's row-group form)"""
+    if not WS_ENABLE or (kh, kw) != (3, 3) or stride != 1 or dil != 1 or tuple(pad) != (1, 1) or Cin % 32 or Cout % 4 or act:
+        return False
+    M, rows = B * Ho * Wo, B * Hin * Win
+    if M > WS_MAX_M:
+        return False
+    if M <= 128:
+        return rows <= 128 and up_size is None
+    return M <= 512 and rows <= 512
+
+
+def _wsfm(W: torch.Tensor):
+    """the fragment-major copy of a marked conv weight (built on first use, outside stream capture), or None"""
+    if not getattr(W, "_spider_weight", False):
+        return None
+    t = getattr(W, "_spider_fm", None)
+    tag = (W._version, W.data_ptr())
+    if t is None or getattr(W, "_spider_fm_tag", None) != tag:
+        if torch.cuda.is_current_stream_capturing():
+            if t is not None:
+                raise RuntimeError("a marked weight was modified in place and is first used again under stream capture")
+            return None
+        t = repack_fm_conv(W)
+        W._spider_fm, W._spider_fm_tag = t, tag
+    return t
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -436,6 +486,10 @@ def conv2d(x, w, bias=None, res=None, rowbias=None, stride=1, pad=None, ups=Fals
     Cout, ks = w.shape[0], w.shape[1]
     if pad is None:
         pad = ks // 2
+    if ks == 3 and stride == 1 and pad == 1 and WS_ENABLE and B * H * Wd * (4 if ups else 1) <= WS_MAX_M and getattr(w, "_spider_weight", False):
+        # weight-bound maps (<= 512 output pixels): the general entry point picks the weight-stationary streaming kernel
+        return conv_ex(x, w, bias=bias, res=res, rowbias=rowbias, stride=1, pad=(1, 1), up_size=(2 * H, 2 * Wd) if ups else None,
+                       out_scale=out_scale, out=out, res32=res32, want32=want32)
     Hs, Ws = (H * 2, Wd * 2) if ups else (H, Wd)
     Ho, Wo = (Hs + 2 * pad - ks) // stride + 1, (Ws + 2 * pad - ks) // stride + 1
     if out is None:
@@ -489,18 +543,26 @@ def conv_ex(x, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x.device)
     uh, uw = up_size if up_size is not None else (0, 0)
-    wt = _tiled(w, B * Ho * Wo)
+    wt, wmode = None, 0
+    if _ws_eligible(B, H, Wd, Cin, Cout, kh, kw, stride, pad, dil, up_size, Ho, Wo, act):
+        wt = _wsfm(w)
+        wmode = 2 if wt is not None else 0
+    if wt is None:
+        wt = _tiled(w, B * Ho * Wo)
+        wmode = int(wt is not None)
     o32 = torch.empty(out.shape, dtype=torch.float32, device=x.device) if want32 else None
     if res32 is not None:
         _chk(res32, torch.float32, "res32")
     args = (_p(x), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
-            Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), int(wt is not None),
+            Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, ACT[act], float(act_param), float(out_scale), wmode,
             _p(res32), _p(o32), _p(_workspace(x.device)), WS_BYTES, _stream())
     part = None
     HWo = Ho * Wo
     # (every block of the consuming GroupNorm reduces the partials of its image: beyond ~256 chunks -- the UNet3D's temporal norms
     # over 16 frames x 2880 pixels would be 720 -- that prologue costs more than the statistics pass it replaces: measured +0.8 %)
-    if gn_groups and GN_PRODUCER and HWo % 16 == 0 and HWo <= 16384:
+    # (the streaming conv combines its K splits inside the launch and leaves no statistics: on its small maps the consumer's
+    # one-launch GroupNorm is cheaper than a reduce kernel that would make them)
+    if gn_groups and GN_PRODUCER and HWo % 16 == 0 and HWo <= 16384 and not (wmode == 2 and WS_INLAUNCH):
         buf = torch.empty(B * (HWo // 16) * gn_groups * 2, dtype=torch.float32, device=x.device)
         produced = C.c_int(0)
         _lib.call(f"spider_conv_nhwc_gn_{sfx}", *args, _p(buf), int(gn_groups), C.byref(produced))

@@ -796,3 +796,78 @@ def test_gemm_with_groupnorm_on_A_matches_groupnorm_then_gemm(dev, B, HW, C, N, 
     r = float((got.float() - ref.float()).norm() / ref.float().norm())
     assert r < 3e-4, r                                    # same math; the group mean / rstd differ in their last fp32 bits
     assert torch.equal(got, got32.to(dtype)), "the fp32 copy rounds to the 16-bit output"
+
+
+# ------------------------------------------------------------------------------------------ weight-stationary streaming conv (round 5)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [
+    (2, 8, 8, 64, 64, None),          # 128 output pixels: 8 wave-private K-groups, 2 channel blocks
+    (2, 8, 8, 1280, 1280, None),      # SD-v1.5 8^2 conv2: 40 channel blocks, 5 K splits
+    (2, 8, 8, 2560, 1280, None),      # up-block conv1 on the skip concat
+    (1, 8, 8, 96, 80, None),          # 64 pixels (rows past M are zero rows), Cout not a multiple of 32
+    (2, 7, 5, 160, 48, None),         # odd, non-square map
+    (2, 16, 16, 320, 96, None),       # 512 pixels: 4 row groups x 2 K-groups, shared slabs
+    (2, 16, 16, 1280, 1280, None),    # SD-v1.5 16^2 conv2
+    (2, 16, 16, 1920, 1280, None),    # 60 channel blocks: uneven K splits
+    (3, 12, 12, 64, 32, None),        # 432 pixels over three images
+    (2, 8, 8, 1280, 1280, (16, 16)),  # the 8^2 -> 16^2 upsampler (fused nearest 2x)
+    (2, 7, 8, 64, 64, (13, 16)),      # upsample to 2 * in - 1
+])
+def test_wstream_conv_matches_reference_and_tile_path(dev, B, H, W, Cin, Cout, up, dtype, monkeypatch):
+    """conv_ex on a MARKED weight with <= 512 output pixels runs wstream_kernel (w_tiled = 2) -- against torch fp32 and against the
+    tile kernels (same products, another summation order), with every epilogue operand of the resnet convs."""
+    from spider_amd import ops
+    monkeypatch.setattr(ops, "WS_MAX_M", 512)        # the 512-pixel form exists and is tested; the engines use it up to ops.WS_MAX_M
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g, device=dev).to(dtype)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g, device=dev) * (1.0 / (3 * Cin ** 0.5))).to(dtype)
+    bias = (torch.randn(Cout, generator=g, device=dev) * 0.1).to(dtype)
+    rb = (torch.randn(B, Cout, generator=g, device=dev) * 0.1).to(dtype)
+    Ho, Wo = up if up is not None else (H, W)
+    res32 = torch.randn(B, Ho, Wo, Cout, generator=g, device=dev)
+    wm = ops.mark_weight(w.clone())
+    assert ops._ws_eligible(B, H, W, Cin, Cout, 3, 3, 1, (1, 1), 1, up, Ho, Wo, None)
+    got, got32 = ops.conv_ex(x, wm, bias=bias, rowbias=rb, pad=(1, 1), up_size=up, res32=res32, want32=True)
+    assert getattr(wm, "_spider_fm", None) is not None, "the streaming kernel's weight copy was not built: wrong path"
+    xi = x.float().permute(0, 3, 1, 2)
+    if up is not None:
+        xi = F.interpolate(xi, size=up, mode="nearest")
+    ref = F.conv2d(xi, w.float().permute(0, 3, 1, 2), bias.float(), padding=1).permute(0, 2, 3, 1) + rb.float()[:, None, None, :] + res32
+    rel = float((got32 - ref).norm() / ref.norm())
+    assert rel < 1e-5 * max(1.0, (9 * Cin) ** 0.5 / 30), f"fp32 output vs torch fp32: {rel}"       # fp32 accumulation only
+    assert torch.equal(got, got32.to(dtype)), "the 16-bit output is the rounded fp32 output"
+    old, old32 = ops.conv_ex(x, w, bias=bias, rowbias=rb, pad=(1, 1), up_size=up, res32=res32, want32=True)   # unmarked weight: tile kernels
+    assert float((got32 - old32).norm() / old32.norm()) < 2e-6
+    # 16-bit residual + plain output, no fp32 stream
+    res = torch.randn(B, Ho, Wo, Cout, generator=g, device=dev).to(dtype)
+    a = ops.conv_ex(x, wm, bias=bias, pad=(1, 1), up_size=up, res=res)
+    b_ = ops.conv_ex(x, w, bias=bias, pad=(1, 1), up_size=up, res=res)
+    assert float((a.float() - b_.float()).norm() / b_.float().norm()) < (2e-4 if dtype == torch.float16 else 2e-3)
+    # statistics for the consumer GroupNorm still arrive (reduce kernel or the caller's pass)
+    if Cout % 32 == 0 and (Ho * Wo) % 16 == 0:
+        o2, part = ops.conv_ex(x, wm, bias=bias, pad=(1, 1), up_size=up, gn_groups=32)
+        assert torch.equal(o2, ops.conv_ex(x, wm, bias=bias, pad=(1, 1), up_size=up))
+        if part is not None:        # (none with the in-launch combine: the consumer GroupNorm runs its own one-launch kernel)
+            cr = (Ho * Wo) // part.nchunk
+            want = _group_sums(o2.cpu(), 32, cr)
+            assert float((part.t.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
+    # the in-launch combine and the reduce kernel sum the same slabs in the same order
+    monkeypatch.setenv("SPIDER_WS_INLAUNCH", "1")
+    cnt = ops._workspace(x.device)[ops.WS_BYTES // 4:]
+    assert int(cnt.view(torch.int32).abs().sum()) == 0, "arrival counters must be zero between calls"
+
+
+def test_wstream_graph_replay_is_bit_identical(dev, monkeypatch):
+    from spider_amd import ops
+    monkeypatch.setattr(ops, "WS_MAX_M", 512)
+    g = torch.Generator(device=dev).manual_seed(6)
+    x = torch.randn(2, 16, 16, 640, generator=g, device=dev).half()
+    w = ops.mark_weight((torch.randn(1280, 3, 3, 640, generator=g, device=dev) * 0.01).half())
+    eager = ops.conv_ex(x, w, pad=(1, 1))
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out = ops.conv_ex(x, w, pad=(1, 1))
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
