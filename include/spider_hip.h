@@ -15,8 +15,11 @@
  */
 #ifndef SPIDER_HIP_H
 #define SPIDER_HIP_H
-#define SPIDER_ABI_VERSION 3   /* 2: w_tiled argument of the GEMM / conv entry points; *_f16 instantiations
-                                * 3: producer-side GroupNorm statistics (spider_conv_nhwc_gn, spider_groupnorm_stats / _apply, spider_gemm_gn_in) */
+#define SPIDER_ABI_VERSION 4   /* 2: w_tiled argument of the GEMM / conv entry points; *_f16 instantiations
+                                * 3: producer-side GroupNorm statistics (spider_conv_nhwc_gn, spider_groupnorm_stats / _apply, spider_gemm_gn_in)
+                                * 4: w_tiled = 2 (fragment-major conv weights, in-launch split-K combine); the "precise" fp32-operand forms
+                                *    (spider_gemm_a32, spider_gemm_gn_in_a32, spider_conv_nhwc_a32, spider_groupnorm_f32in_nhwc,
+                                *    spider_conv2d_small_c{in,out}_f32in, spider_latent_to_nhwc_f32); act 9 = GEGLU rounded once */
 
 #ifdef __cplusplus
 extern "C" {
@@ -294,6 +297,38 @@ int spider_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, floa
  * the random per-key keep decision): bit j % 64 of word j / 64 = (u[j] < thr) for j < n_valid, 0 beyond. u [n] fp32 on the device. */
 int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, float thr, void* stream);
 
+
+/* ---- "precise" operand forms (ABI v4; UNetEngine(precise=True)) ----
+ * north_star asks for UNet latents within 1e-3 relative of the reference; with every MFMA operand rounded to 11 significand bits one
+ * evaluation sits at 1.2e-3. The per-site attribution (scripts/exp/precision_sites.py) puts ~70 % of that error variance on the few
+ * places where the fp32 MASTER of the residual stream exists but its 16-bit shadow is what a kernel reads: ResnetBlock2D.conv_shortcut,
+ * the Down / Upsample2D convs, conv_in / conv_out, Transformer2DModel.norm -> proj_in, proj_out, and every GroupNorm of the stream
+ * (diffusers 0.25 UNet2DConditionModel.forward; call site custom_sd.py:634-639). These entry points read the fp32 tensor instead:
+ *   spider_gemm_a32_*, spider_conv_nhwc_a32_*, spider_gemm_gn_in_a32_*: A (or the NHWC image) is fp32 and is split, on its way into
+ *       LDS, into hi = round16(x) and lo = round16(x - hi); every K step runs two MFMAs (W.hi + W.lo). Otherwise the contracts of
+ *       spider_gemm_* (no activation / GEGLU), spider_conv_nhwc_ex_* (no activation; w_tiled 0 / 1) and spider_gemm_gn_in_*.
+ *   spider_groupnorm_f32in_nhwc_*: GroupNorm (+ SiLU) of the fp32 tensor x32 [B, HW, C]; statistics from `partial` [B, nchunk, G, 2]
+ *       or (partial NULL) from a pass over x32 into ws (>= B * spider_groupnorm_nchunk(HW) * G * 2 floats); the result is rounded ONCE
+ *       into y (16-bit, optional) and / or stored unrounded into y32 (optional).
+ *   spider_conv2d_small_cin_f32in_* / spider_conv2d_small_cout_f32in_*: conv_in on the fp32 NHWC latents (y32: optional fp32 master of
+ *       its output) and conv_out on the fp32 GroupNorm + SiLU output.  spider_latent_to_nhwc_f32: fp32 NCHW latents -> fp32 NHWC. */
+int spider_gemm_a32_bf16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
+                         int ldc, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
+int spider_gemm_gn_in_a32_bf16(const float* A32, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                               const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                               float* c32d, void* stream);
+int spider_conv_nhwc_a32_bf16(const float* x32, const void* w, void* y, const void* bias, const void* res, const void* rowbias,
+                              int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil,
+                              int up_h, int up_w, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes,
+                              void* stream);
+int spider_groupnorm_f32in_nhwc_bf16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                     float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_conv2d_small_cin_f32in_bf16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
+                                       int Cin, int Cout, int ks, void* stream);
+int spider_conv2d_small_cout_f32in_bf16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,
+                                        int Cout, int ks, void* stream);
+int spider_latent_to_nhwc_f32(const float* lat, float* out, int B, int C, int HW, int reps, float scale, void* stream);
+
 /* ======================= IEEE-half (f16) instantiations of the diffusion-side operators =======================
  * The reference runs its diffusion decoders in torch.float16 (spider_decoder.py:109,114,130,136,153,159; base_model.py:211;
  * StoryDiffusion/Comic_Generation.py:313). Every operator above that the UNet / VAE / text-encoder engines use also exists with
@@ -364,6 +399,22 @@ int spider_conv2d_small_cout_f16(const void* x, const void* w, const void* bias,
                                   int W, int Cin, int Cout, int ks, void* stream);
 int spider_latent_to_nhwc_f16(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream);
 int spider_softmax_rows_f32_f16(const float* x, void* y, int rows, int n, int n_valid, float scale, void* stream);
+
+int spider_gemm_a32_f16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
+                         int ldc, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
+int spider_gemm_gn_in_a32_f16(const float* A32, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                               const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                               float* c32d, void* stream);
+int spider_conv_nhwc_a32_f16(const float* x32, const void* w, void* y, const void* bias, const void* res, const void* rowbias,
+                              int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil,
+                              int up_h, int up_w, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes,
+                              void* stream);
+int spider_groupnorm_f32in_nhwc_f16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                     float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_conv2d_small_cin_f32in_f16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
+                                       int Cin, int Cout, int ks, void* stream);
+int spider_conv2d_small_cout_f32in_f16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,
+                                        int Cout, int ks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from oracle.unet import UNetCfg, UNetOracle, random_unet_weights
 
 SITES = ["gn_in", "gn1", "conv1_out", "gn2", "shortcut", "tnorm", "ln1", "qkv1", "p1", "o1", "ln2", "q2", "kv2", "p2", "o2", "ln3", "geglu",
-         "proj_out_in", "sampler_in", "lnfold_w", "xfold_w", "temb"]
+         "proj_out_in", "sampler_in", "lnfold_w", "xfold_w", "temb", "mimic"]
 DESC = {
     "gn_in": "the stream's 16-bit shadow read by a GroupNorm (ResnetBlock2D.norm1, Transformer2DModel.norm, conv_norm_out)",
     "gn1": "ResnetBlock2D norm1 + SiLU output (conv1's A operand)",
@@ -39,6 +39,7 @@ DESC = {
     "sampler_in": "stream shadows read as conv operands by conv_in / down- / upsamplers / conv_out",
     "lnfold_w": "LayerNorm folded into q/k/v, to_q and the GEGLU projection: W * gamma re-rounded to 16 bits (ops.fold_layernorm)",
     "xfold_w": "fused cross-attention (>= 1024 token rows): the prompt's K / V folded into Mq = scale K Wq gamma and Mo = Wo V^T, both re-rounded",
+    "mimic": "op-boundary roundings the kernels add to mirror an f16 module: GroupNorm output before SiLU; GEGLU's value, gate and gelu(gate)",
     "temb": "time-embedding MLP and the per-resnet projections computed and stored in 16 bits (rowbias operand)",
 }
 
@@ -54,11 +55,11 @@ class SiteOracle(UNetOracle):
         return t if site in self.exact else t.to(self.fmt).float()
 
     def resnet(self, n, x, temb):
-        a = self.q(F.silu(self._gn(n + ".norm1", self.q(x, "gn_in"))), "gn1")
+        a = self.q(F.silu(self.q(self._gn(n + ".norm1", self.q(x, "gn_in")), "mimic")), "gn1")
         tp = self.q(self._lin(n + ".time_emb_proj", self.q(F.silu(temb), "temb")), "temb")
         h = UNetOracle._conv(self, n + ".conv1", a) + tp[:, :, None, None]
         h = self.q(h, "conv1_out")
-        a = self.q(F.silu(self._gn(n + ".norm2", h)), "gn2")
+        a = self.q(F.silu(self.q(self._gn(n + ".norm2", h), "mimic")), "gn2")
         h = UNetOracle._conv(self, n + ".conv2", a)
         if n + ".conv_shortcut.weight" in self.w:
             x = UNetOracle._conv(self, n + ".conv_shortcut", self.q(x, "shortcut"), pad=0)       # fp32 master of the shortcut kept (want32)
@@ -165,7 +166,7 @@ class SiteOracle(UNetOracle):
                 h = self.attention_q_folded(b, h, enc, heads) + h
             p = self.ln_lin(b, ".norm3", b + ".ff.net.0.proj", h, "ln3")
             a, gate = p.chunk(2, -1)
-            g = self.q(a * F.gelu(gate), "geglu")
+            g = self.q(self.q(a, "mimic") * self.q(F.gelu(self.q(gate, "mimic")), "mimic"), "geglu")
             h = self._lin(b + ".ff.net.2", g) + h
         hq = self.q(h, "proj_out_in")
         if self.cfg.linear_proj:

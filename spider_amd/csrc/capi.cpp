@@ -12,7 +12,7 @@ void spider_set_error(const char* msg) {
 
 const char* spider_last_error(void) { return g_err; }
 
-int spider_abi_version(void) { return 3; }
+int spider_abi_version(void) { return 4; }
 
 const char* spider_target_arch(void) { return "gfx950"; }
 

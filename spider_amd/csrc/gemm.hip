@@ -107,6 +107,9 @@ struct GemmArgs {
     // in-launch split-K combine (zero when idle; null: partial slabs are left to splitk_reduce_kernel)
     int ws_ncb, ws_cpb, ws_rows;
     unsigned* ws_cnt;
+    // "precise" operand: A is fp32 ([M, lda] floats, or the NHWC fp32 image of a conv) and is split into hi + lo 16-bit halves inside
+    // the register-staged kernel (gemm_kernel<..., A32>); a_bytes counts fp32 bytes
+    int a32;
 };
 
 __device__ __forceinline__ float apply_act(const GemmArgs& p, float v) {
@@ -369,7 +372,9 @@ __device__ __forceinline__ void geglu_out(const GemmArgs& p, f32x4 (&acc)[MT][2 
                     v = ms.y * (v - ms.x * cv[j][e]) + bv[j][e];
                     gt = ms.y * (gt - ms.x * cg[j][e]) + bg[j][e];
                 } else if (p.bias) { v += bv[j][e]; gt += bg[j][e]; }
-                if (p.geglu == 2) {      // SwiGLU (LlamaMLP, modeling_llama3.py:197-199): first half = gate rows, second = up rows
+                if (p.geglu == 3) {      // GEGLU, "precise" form: the product is rounded once (no 16-bit stops at value / gate / gelu)
+                    gt = gelu_erf_f(gt);
+                } else if (p.geglu == 2) {      // SwiGLU (LlamaMLP, modeling_llama3.py:197-199): first half = gate rows, second = up rows
                     v = h16_to_f32(f32_to_h16(silu_f(h16_to_f32(f32_to_h16(v)))));
                     gt = h16_to_f32(f32_to_h16(gt));
                 } else {
@@ -566,12 +571,16 @@ __device__ __forceinline__ void write_out(const GemmArgs& p, f32x4 (&acc)[MT][NT
 }
 
 // GNA (GemmArgs::gna_part): GroupNorm applied to the A operand between its global load and its LDS image (plain linears only).
-template <int BM, int BN, bool CONV, int EPI, bool LN = false, bool GNA = false>
+// A32 ("precise" operand): A is an fp32 tensor (the master of the residual stream, or a GroupNorm output kept in
+// fp32) and is split on its way into LDS into hi = round16(x) and lo = round16(x - hi); every K step runs two MFMAs, W.hi + W.lo --
+// the operand carries ~22 significand bits instead of 11 at the price of issue slots this latency-bound step does not use.
+template <int BM, int BN, bool CONV, int EPI, bool LN = false, bool GNA = false, bool A32 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool GEGLU = EPI == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16_t* lds = reinterpret_cast<h16_t*>(smem);
-    constexpr int TILE_ELEMS = (BM + BN) * LDS_STRIDE;  // [A tile BM rows | W tile BN rows]
+    constexpr int TILE_ELEMS = ((A32 ? 2 : 1) * BM + BN) * LDS_STRIDE;  // [A tile BM rows | W tile BN rows | A32: A lo tile BM rows]
+    constexpr uint32_t AE = A32 ? 4u : 2u;              // bytes per element of A
     constexpr int MT = BM / 32, NT = BN / 32;           // 16x16 MFMA tiles per wave (wave sub-tile BM/2 x BN/2)
     constexpr int AC = BM / 32, WC = BN / 32;           // 16-byte chunks per thread per K tile
 
@@ -610,11 +619,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             const int b = mc / hw, rem = mc % hw;
             a_oy[i] = (rem / p.Wout) * p.stride - p.pad_h;      // input row / column of tap (0, 0)
             a_ox[i] = (rem % p.Wout) * p.stride - p.pad_w;
-            a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * 2u;
-            a_lin[i] = a_base[i] + (uint32_t)(a_oy[i] * p.Win + a_ox[i]) * (uint32_t)p.Cin * 2u;   // + tap offset = the tap's pixel (no upsample)
+            a_base[i] = (uint32_t)b * (uint32_t)(p.Hin * p.Win * p.Cin) * AE;
+            a_lin[i] = a_base[i] + (uint32_t)(a_oy[i] * p.Win + a_ox[i]) * (uint32_t)p.Cin * AE;   // + tap offset = the tap's pixel (no upsample)
             a_hb[i] = 0u;
             if (p.hbits) {
-                a_lin[i] += chunk * 16u;                  // this thread's 16-byte chunk of the 64-channel block
+                a_lin[i] += chunk * 8u * AE;              // this thread's 8-element chunk of the 64-channel block
                 {
                     uint32_t hb = 0u;
                     for (int ky = 0; ky < p.kh; ++ky)
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             }
         } else {
             a_hb[i] = 0u;
-            a_base[i] = (uint32_t)mc * (uint32_t)p.lda * 2u + chunk * 16u;
+            a_base[i] = (uint32_t)mc * (uint32_t)p.lda * AE + chunk * 8u * AE;
             a_oy[i] = a_ox[i] = 0;
             a_lin[i] = 0;
         }
@@ -659,8 +668,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     TapWalk walk{0, 0, 0};
     if (CONV && p.cin64) walk.init(p, kt0);
     // global -> registers for K tile kt (two register sets R0/R1 form a 2-deep prefetch ring); branch-free
-    auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC]) {
-        const uint32_t kbyte = (uint32_t)kt * (BK * 2);
+    // (A32: ra holds the first 4 fp32 values of the lane's 8 elements, ra2 the other 4)
+    auto load_tile = [&](int kt, u32x4 (&ra)[AC], u32x4 (&rw)[WC], u32x4 (&ra2)[A32 ? AC : 1]) {
+        const uint32_t kbyte = (uint32_t)kt * (BK * AE);
+        auto lda = [&](int i, uint32_t lin, uint32_t inv) {      // inv: all ones = outside the problem (reads zeros)
+            ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, lin | inv, 0, 0));
+            if (A32) ra2[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (lin + 16u) | inv, 0, 0));
+        };
         // all ones when this lane's 8 k-elements lie beyond K (ragged last tile) or the tile is past this split's range:
         // such loads return zeros, so the K loop below needs no conditionals at all (the compiler then counts the
         // outstanding loads exactly and waits only for the register set it is about to store)
@@ -675,26 +689,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             uint32_t cbyte;
             if (p.cin64) {
                 ky = walk.ky; kx = walk.kx;
-                cbyte = (uint32_t)(walk.c + chunk * 8) * 2u;
+                cbyte = (uint32_t)(walk.c + chunk * 8) * AE;
                 ktw = walk.wtile(p);
                 walk.next(p);
             } else {
                 const int kk = kt * BK + chunk * 8;
                 const int tap = kk / p.Cin;
-                cbyte = (uint32_t)(kk - tap * p.Cin) * 2u;
+                cbyte = (uint32_t)(kk - tap * p.Cin) * AE;
                 ky = tap / p.kw; kx = tap - ky * p.kw;
             }
             const int hlim = p.lim_h, wlim = p.lim_w;
             const int dy = ky * p.dil, dx = kx * p.dil;                                   // wave-uniform tap displacement
-            const uint32_t tap_off = (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * 2u + cbyte;
+            const uint32_t tap_off = (uint32_t)(dy * p.Win + dx) * (uint32_t)p.Cin * AE + cbyte;
             if (p.hbits) {     // uniform tap offset + per-row masks (GemmArgs::hbits); cbyte's per-thread chunk is already in a_lin
                 const int tap = ky * p.kw + kx;
-                const uint32_t toff = tap_off - chunk * 16u;
+                const uint32_t toff = tap_off - chunk * 8u * AE;
 #pragma unroll
                 for (int i = 0; i < AC; ++i) {
                     const uint32_t halo = 0u - ((a_hb[i] >> tap) & 1u);
-                    const uint32_t off = (a_lin[i] + toff) | halo | a_inv[i] | k_inv;
-                    ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+                    lda(i, a_lin[i] + toff, halo | a_inv[i] | k_inv);
                 }
             } else
 #pragma unroll
@@ -703,15 +716,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 // sign bit set if any of iy, ix, hlim-1-iy, wlim-1-ix is negative -> halo mask
                 const uint32_t halo = (uint32_t)((iy | ix | (hlim - 1 - iy) | (wlim - 1 - ix)) >> 31);
                 uint32_t lin = a_lin[i] + tap_off;
-                if (p.ups) lin = a_base[i] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * 2u + cbyte;
-                const uint32_t off = lin | halo | a_inv[i] | k_inv;
-                ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+                if (p.ups) lin = a_base[i] + (uint32_t)((iy >> 1) * p.Win + (ix >> 1)) * (uint32_t)p.Cin * AE + cbyte;
+                lda(i, lin, halo | a_inv[i] | k_inv);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
-                const uint32_t off = (a_base[i] + kbyte) | a_inv[i] | k_inv;
-                ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, off, 0, 0));
+                lda(i, a_base[i] + kbyte, a_inv[i] | k_inv);
             }
         }
 #pragma unroll
@@ -727,12 +738,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // GNA: per-channel (scale, shift) of this tile's image, behind the two tile buffers (K float2; the tile lies in ONE image:
     // host-checked gna_hw % BM == 0). Group statistics are reduced from the producer's partials exactly like gn_apply_kernel does.
     float2* gna_tab = reinterpret_cast<float2*>(smem + (size_t)2 * TILE_ELEMS * sizeof(h16_t));
-    auto store_tile = [&](int buf, const u32x4 (&ra_)[AC], const u32x4 (&rw)[WC], int kt_ = 0) {
+    auto store_tile = [&](int buf, const u32x4 (&ra_)[AC], const u32x4 (&rw)[WC], const u32x4 (&ra2_)[A32 ? AC : 1], int kt_ = 0) {
         h16_t* base = lds + buf * TILE_ELEMS;
         u32x4 ra[AC];
+        u32x4 rlo[A32 ? AC : 1];
 #pragma unroll
         for (int i = 0; i < AC; ++i) ra[i] = ra_[i];
-        if (GNA) {   // y = round16(fma(x, a_c, b_c)): the value gn_apply_kernel writes for the same element
+        if (A32) {
+            // fp32 operand: (GroupNorm on A first, in fp32,) then hi = round16(x), lo = round16(x - hi)
+            float ca[8], cb[8];
+            if (GNA) {
+                int k0 = kt_ * BK + chunk * 8;
+                k0 = k0 + 8 <= p.K ? k0 : p.K - 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float2 t = gna_tab[k0 + j]; ca[j] = t.x; cb[j] = t.y; }
+            }
+#pragma unroll
+            for (int i = 0; i < AC; ++i) {
+                float x[8];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { x[d] = __uint_as_float(ra_[i][d]); x[4 + d] = __uint_as_float(ra2_[A32 ? i : 0][d]); }
+                if (GNA) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], ca[j], cb[j]);
+                }
+                uint32_t hi4[4], lo4[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    hi4[d] = pack_h16x2(x[2 * d], x[2 * d + 1]);
+                    lo4[d] = pack_h16x2(x[2 * d] - h16lo_to_f32(hi4[d]), x[2 * d + 1] - h16hi_to_f32(hi4[d]));
+                }
+                ra[i] = u32x4{hi4[0], hi4[1], hi4[2], hi4[3]};
+                rlo[A32 ? i : 0] = u32x4{lo4[0], lo4[1], lo4[2], lo4[3]};
+            }
+        } else if (GNA) {   // y = round16(fma(x, a_c, b_c)): the value gn_apply_kernel writes for the same element
             int k0 = kt_ * BK + chunk * 8;
             k0 = k0 + 8 <= p.K ? k0 : p.K - 8;         // tiles past K carry zero weights: any finite A value will do
             float ca[8], cb[8];
@@ -767,6 +806,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < WC; ++i)
             *reinterpret_cast<u32x4*>(base + (BM + lrow + 32 * i) * LDS_STRIDE + st_chunk * 8) = rw[i];
+        if (A32) {
+#pragma unroll
+            for (int i = 0; i < AC; ++i)
+                *reinterpret_cast<u32x4*>(base + (BM + BN + lrow + 32 * i) * LDS_STRIDE + st_chunk * 8) = rlo[A32 ? i : 0];
+        }
     };
 
     f32x4 acc[MT][NT];
@@ -792,12 +836,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = mfma_16x16x32_h16(wf[j], af[i], acc[i][j]);
+            if (A32) {      // the lo halves of the same rows, behind the W tile
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const h16x8*>(abase + ((BM + BN) + i * 16) * LDS_STRIDE + coff);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = mfma_16x16x32_h16(wf[j], af[i], acc[i][j]);
+            }
         }
     };
 
     u32x4 a0[AC], w0[WC], a1[AC], w1[WC];
-    load_tile(kt0, a0, w0);
-    load_tile(kt0 + 1, a1, w1);
+    u32x4 a0b[A32 ? AC : 1], a1b[A32 ? AC : 1];
+    load_tile(kt0, a0, w0, a0b);
+    load_tile(kt0 + 1, a1, w1, a1b);
     // (GNA: the statistics prologue runs with the first two K tiles already in flight)
     if (GNA) {
         float* g_mean = reinterpret_cast<float*>(gna_tab + p.K);          // [G], [G] behind the table
@@ -841,8 +895,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    store_tile(0, a0, w0, kt0);
-    load_tile(kt0 + 2, a0, w0);
+    store_tile(0, a0, w0, a0b, kt0);
+    load_tile(kt0 + 2, a0, w0, a0b);
     __syncthreads();
     // invariant at loop top: LDS buf0 = tile kt; R1 = tile kt+1 (in flight); R0 = tile kt+2 (in flight).
     // Tiles >= kt1 are all-zero (masked loads): an odd tail costs one wasted half-iteration, never a wrong sum.
@@ -850,14 +904,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // a full compute phase before they are needed (left alone, hipcc sinks both load groups to the end of the body).
     for (int kt = kt0; kt < kt1; kt += 2) {
         compute(0);
-        store_tile(1, a1, w1, kt + 1);
+        store_tile(1, a1, w1, a1b, kt + 1);
         __syncthreads();
-        load_tile(kt + 3, a1, w1);
+        load_tile(kt + 3, a1, w1, a1b);
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
-        store_tile(0, a0, w0, kt + 2);
+        store_tile(0, a0, w0, a0b, kt + 2);
         __syncthreads();
-        load_tile(kt + 4, a0, w0);
+        load_tile(kt + 4, a0, w0, a0b);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -2051,14 +2105,33 @@ template __global__ void wstream_kernel<4, 2, true>(GemmArgs);
 #else
 template <int BM, int BN>
 void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
-    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(h16_t);
+    const size_t smem = (size_t)2 * ((a.a32 ? 2 : 1) * BM + BN) * LDS_STRIDE * sizeof(h16_t);
     dim3 grid(tiles, a.splits);
     // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = a.geglu ? 2 : (!fast_ok ? 3 : (a.act ? 1 : 0));
+    if (a.a32) {           // fp32 A operand, hi / lo split (host-checked: epilogue 0, no LayerNorm fold)
+        static unsigned done_a = 0, done_b = 0, done_c = 0;
+        if (a.gna_part) {
+            if constexpr (BM == 64 && BN == 64) {
+                const size_t extra = (size_t)a.K * sizeof(float2) + (size_t)2 * a.gna_G * sizeof(float) + 2 * 256 * sizeof(float);
+                raise_dynamic_lds(&gemm_kernel<64, 64, false, 0, false, true, true>, (int)(smem + extra), done_c);
+                gemm_kernel<64, 64, false, 0, false, true, true><<<grid, 256, smem + extra, st>>>(a);
+            }
+        } else if (a.conv) {
+            raise_dynamic_lds(&gemm_kernel<BM, BN, true, 0, false, false, true>, (int)smem, done_a);
+            gemm_kernel<BM, BN, true, 0, false, false, true><<<grid, 256, smem, st>>>(a);
+        } else {
+            raise_dynamic_lds(&gemm_kernel<BM, BN, false, 0, false, false, true>, (int)smem, done_b);
+            gemm_kernel<BM, BN, false, 0, false, false, true><<<grid, 256, smem, st>>>(a);
+        }
+        return;
+    }
     if (a.gna_part) {      // GroupNorm applied to A on the way into LDS (host-checked: plain linear, 64^2 tiles, epilogue 0, no split-K)
         if constexpr (BM == 64 && BN == 64) {
             const size_t extra = (size_t)a.K * sizeof(float2) + (size_t)2 * a.gna_G * sizeof(float) + 2 * 256 * sizeof(float);
+            static unsigned done_g = 0;
+            raise_dynamic_lds(&gemm_kernel<64, 64, false, 0, false, true>, (int)(smem + extra), done_g);     // K > ~3.8k passes 64 KiB
             gemm_kernel<64, 64, false, 0, false, true><<<grid, 256, smem + extra, st>>>(a);
         }
         return;
@@ -2396,6 +2469,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         small = false; splits = 1; p8_splits = 1;
     }
     if (a.gna_part) { use_p8 = use_p8h = false; dma_bn = 0; small = true; splits = 1; }   // GroupNorm-on-A exists on the 64^2 register-staged kernel
+    if (a.a32) { use_p8 = use_p8h = false; dma_bn = 0; }                                   // the fp32 operand exists on the register-staged kernels
     if (use_p8h) { use_p8 = false; splits = 1; dma_bn = 0; }
     if (use_p8) { splits = p8_splits; dma_bn = 0; }
     if (a.ln_colsum) { dma_bn = 0; splits = 1; }      // the block must see whole rows of A (row statistics)
@@ -2472,11 +2546,11 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
                      float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     SPIDER_CHECK(K % 8 == 0 && lda % 8 == 0, "gemm: K and lda must be multiples of 8 (16-byte rows)");
-    const bool glu = act == 4 || act == 8;      // 4: GEGLU, 8: SwiGLU (fused gated-linear-unit epilogues: the output has N / 2 columns)
+    const bool glu = act == 4 || act == 8 || act == 9;      // 4: GEGLU, 8: SwiGLU, 9: GEGLU rounded once (fused epilogues: the output has N / 2 columns)
     SPIDER_CHECK(ldc % 4 == 0 && ldc >= (glu ? N / 2 : N), "gemm: ldc must be >= the output width and a multiple of 4");
     SPIDER_CHECK((C != nullptr) != (C32 != nullptr), "gemm: exactly one of C (bf16) / C32 (fp32) must be given");
     SPIDER_CHECK(!rowbias || rows_per_group > 0, "gemm: rowbias needs rows_per_group > 0");
-    SPIDER_CHECK(act >= 0 && act <= 8, "gemm: unknown activation");
+    SPIDER_CHECK(act >= 0 && act <= 9, "gemm: unknown activation");
     SPIDER_CHECK(!glu || (C && !res && !rowbias && N % 2 == 0), "gemm: GEGLU / SwiGLU epilogue needs bf16 output, even N, no res/rowbias");
     SPIDER_CHECK((!res32 && !c32d) || (C && !glu && !(res && res32) && (size_t)M * ldc * 4 < ((size_t)1 << 31)),
                  "gemm: the fp32 residual stream needs the 16-bit output, no GEGLU, at most one residual, and < 2 GiB of fp32 rows");
@@ -2485,7 +2559,7 @@ int SPIDER_FN(spider_gemm)(const void* A, const void* W, void* C, void* C32, con
     a.A = (const h16_t*)A; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.C32 = (float*)C32;
     a.bias = (const h16_t*)bias; a.res = (const h16_t*)res; a.rowbias = (const h16_t*)rowbias;
     a.rows_per_group = rows_per_group; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc;
-    a.geglu = act == 4 ? 1 : (act == 8 ? 2 : 0);
+    a.geglu = act == 4 ? 1 : (act == 8 ? 2 : (act == 9 ? 3 : 0));
     a.N = a.geglu ? N / 2 : N;      // N counts W rows; the GEGLU / SwiGLU output has N/2 columns
     a.act = a.geglu ? 0 : act;
     a.act_param = 0.1f;             // leaky-relu slope of the GEMM form (HiFi-GAN); the conv form takes it as an argument
@@ -2507,14 +2581,14 @@ int SPIDER_FN(spider_gemm_ln)(const void* A, const void* Wf, void* C, const floa
                         int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* ws, long ws_bytes, void* stream) {
     SPIDER_CHECK(M > 0 && N > 0 && K > 0, "gemm_ln: empty problem");
     SPIDER_CHECK(K % 8 == 0, "gemm_ln: K must be a multiple of 8 (16-byte rows)");
-    SPIDER_CHECK(act == 0 || act == 4, "gemm_ln: only the plain and the GEGLU epilogue are built");
+    SPIDER_CHECK(act == 0 || act == 4 || act == 9, "gemm_ln: only the plain and the GEGLU epilogues (4, 9 = rounded once) are built");
     SPIDER_CHECK(colsum && colbias && C, "gemm_ln: colsum, colbias and C are required");
-    SPIDER_CHECK(act != 4 || (!res && N % 2 == 0), "gemm_ln: GEGLU epilogue needs even N and no residual");
+    SPIDER_CHECK(act == 0 || (!res && N % 2 == 0), "gemm_ln: GEGLU epilogue needs even N and no residual");
     GemmArgs a{};
     a.A = (const h16_t*)A; a.W = (const h16_t*)Wf; a.C = (h16_t*)C; a.C32 = nullptr;
     a.bias = nullptr; a.res = (const h16_t*)res; a.rowbias = nullptr; a.rows_per_group = 0;
     a.M = M; a.K = K; a.lda = K; a.ldc = ldc;
-    a.geglu = act == 4;
+    a.geglu = act == 4 ? 1 : (act == 9 ? 3 : 0);
     a.N = a.geglu ? N / 2 : N;
     SPIDER_CHECK(a.N % 4 == 0 && ldc % 4 == 0 && ldc >= a.N, "gemm_ln: output width and ldc must be multiples of 4, ldc >= width");
     a.act = 0; a.act_param = 0.f; a.out_scale = 1.f; a.conv = 0; a.ws = (float*)ws;     // ws: row statistics of the 256^2 form
@@ -2537,7 +2611,7 @@ static int conv_impl(const void* x, const void* w, void* y, const void* bias, co
                      const void* rowbias, int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride,
                      int pad_h, int pad_w, int dil, int up_h, int up_w, int act, float act_param,
                      float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream,
-                     float* gn_part, int gn_groups, int* produced) {
+                     float* gn_part, int gn_groups, int* produced, int a32 = 0) {
     if (produced) *produced = 0;
     SPIDER_CHECK(B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0, "conv: empty problem");
     SPIDER_CHECK(kh >= 1 && kw >= 1 && kh * kw <= 64 && dil >= 1, "conv: kernel taps must be 1..64, dilation >= 1");
@@ -2571,8 +2645,9 @@ static int conv_impl(const void* x, const void* w, void* y, const void* bias, co
     a.kcm = (kcm_env && a.cin64 && kh * kw > 1) ? 1 : 0;
     static const int hb_env = getenv("SPIDER_CONV_HBITS") ? atoi(getenv("SPIDER_CONV_HBITS")) : 1;
     a.hbits = (hb_env && a.cin64 && !ups && kh * kw <= 32) ? 1 : 0;
-    SPIDER_CHECK((size_t)B * Hin * Win * Cin * 2 < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
-    a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * 2);
+    a.a32 = a32 ? 1 : 0;
+    SPIDER_CHECK((size_t)B * Hin * Win * Cin * (a32 ? 4 : 2) < ((size_t)1 << 32) && (size_t)Cout * a.K * 2 < ((size_t)1 << 32), "conv: operands must be < 4 GiB");
+    a.a_bytes = (uint32_t)((size_t)B * Hin * Win * Cin * (a32 ? 4 : 2));
     a.w_tiled = w_tiled == 2 ? 2 : (w_tiled ? 1 : 0);
     a.w_bytes = w_tiled == 2 ? (uint32_t)((size_t)((Cout + 31) / 32 * 32) * a.K * 2) : (w_tiled ? tiled_bytes(Cout, a.K) : (uint32_t)((size_t)Cout * a.K * 2));
     set_epilogue_ranges(a);
@@ -2634,6 +2709,64 @@ int SPIDER_FN(spider_gemm_gn_in)(const void* A, const void* W, void* C, const vo
     set_epilogue_ranges(a);
     SPIDER_CHECK(a.c_bytes != 0, "gemm_gn_in: output must be < 2 GiB");
     return launch(a, 0, stream);
+}
+
+// ---- "precise" operand forms (ABI v4): the A operand is FP32 -- the fp32 master of the residual stream
+// (UNetEngine(stream32=True)) or a GroupNorm output kept in fp32 -- and is split into hi = round16(x), lo = round16(x - hi) on its
+// way into LDS; every K step multiplies W by both halves (two MFMAs), so the operand carries ~22 significand bits instead of 11.
+// Used at the sites the per-site attribution names (scripts/exp/precision_sites.py): the stream read by conv_shortcut, the down- /
+// upsamplers, proj_out, and Transformer2DModel.norm -> proj_in. Same epilogue contract as spider_gemm / spider_conv_nhwc_ex
+// (16-bit output C + optional fp32 residual stream operands); no activation, no GEGLU, W row-major or tile-major.
+int SPIDER_FN(spider_gemm_a32)(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
+                         int ldc, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream) {
+    SPIDER_CHECK(M > 0 && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N && C && A32,
+                 "gemm_a32: K, lda multiples of 8; N, ldc multiples of 4; A and C required");
+    SPIDER_CHECK(!(res && res32) && (size_t)M * ldc * 4 < ((size_t)1 << 31) && (size_t)M * lda * 4 < ((size_t)1 << 32) &&
+                 (size_t)N * K * 2 < ((size_t)1 << 32), "gemm_a32: at most one residual; operands < 2 GiB");
+    GemmArgs a{};
+    a.a32 = 1; a.res32 = res32; a.c32d = c32d;
+    a.A = (const h16_t*)A32; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.bias = (const h16_t*)bias; a.res = (const h16_t*)res;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.out_scale = out_scale; a.ws = (float*)ws;
+    a.a_bytes = (uint32_t)((size_t)(M - 1) * lda * 4 + (size_t)K * 4);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
+    set_epilogue_ranges(a);
+    SPIDER_CHECK(a.c_bytes != 0, "gemm_a32: output must be < 2 GiB");
+    return launch(a, ws ? ws_bytes : 0, stream);
+}
+
+// GroupNorm(A) . W^T + bias as spider_gemm_gn_in, with A the FP32 tensor: normalised in fp32, then split hi / lo.
+int SPIDER_FN(spider_gemm_gn_in_a32)(const float* A32, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
+                               const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
+                               float* c32d, void* stream) {
+    SPIDER_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_gn_in_a32: K % 64, N % 4, ldc % 4");
+    SPIDER_CHECK(gn_part && gamma && beta && C && A32 && nchunk > 0, "gemm_gn_in_a32: statistics, gamma, beta, A and C are required");
+    SPIDER_CHECK(G > 0 && G <= 64 && 256 % G == 0 && K % G == 0 && HW % 64 == 0 && M % HW == 0, "gemm_gn_in_a32: G must divide 256 and K; HW % 64 == 0");
+    SPIDER_CHECK((size_t)M * K * 4 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 4 < ((size_t)1 << 31),
+                 "gemm_gn_in_a32: operands must be < 2 GiB");
+    GemmArgs a{};
+    a.a32 = 1;
+    a.A = (const h16_t*)A32; a.W = (const h16_t*)W; a.C = (h16_t*)C; a.bias = (const h16_t*)bias; a.c32d = c32d;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.out_scale = 1.f;
+    a.a_bytes = (uint32_t)((size_t)M * K * 4);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
+    a.gna_part = gn_part; a.gna_nchunk = nchunk; a.gna_G = G; a.gna_hw = HW; a.gna_eps = eps;
+    a.gna_gamma = (const h16_t*)gamma; a.gna_beta = (const h16_t*)beta;
+    set_epilogue_ranges(a);
+    SPIDER_CHECK(a.c_bytes != 0, "gemm_gn_in_a32: output must be < 2 GiB");
+    return launch(a, 0, stream);
+}
+
+// NHWC conv with the FP32 image x32 [B, Hin, Win, Cin] as the A operand (conv_shortcut, Downsample2D / Upsample2D convs reading the
+// stream's master); arguments as spider_conv_nhwc_ex without the activation.
+int SPIDER_FN(spider_conv_nhwc_a32)(const float* x32, const void* w, void* y, const void* bias, const void* res, const void* rowbias,
+                              int B, int Hin, int Win, int Cin, int Cout, int kh, int kw, int stride, int pad_h, int pad_w, int dil,
+                              int up_h, int up_w, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes,
+                              void* stream) {
+    SPIDER_CHECK(x32 && w_tiled != 2, "conv_a32: x32 is required; fragment-major weights are not an operand of this form");
+    return conv_impl(x32, w, y, bias, res, rowbias, B, Hin, Win, Cin, Cout, kh, kw, stride, pad_h, pad_w, dil, up_h, up_w, 0, 0.f,
+                     out_scale, w_tiled, res32, c32d, ws, ws_bytes, stream, nullptr, 0, nullptr, 1);
 }
 
 // Square-kernel form used by the SD / SDXL UNet and the VAE (ResnetBlock2D convs, Down/Upsample2D, shortcuts).

@@ -20,6 +20,8 @@ namespace {
 // Skip-concat form (x2 != nullptr): the input is the channel concatenation [x | x2] (UpBlock2D's cat([hidden, skip])) with
 // C1 channels in x; the kernel reads the two sources in place and writes the concatenated tensor to `cat` on the way (the
 // shortcut conv and pass 2 read it) -- the separate concat launch and its read pass are gone.
+// X32: the input is the fp32 master of the residual stream (precise mode: no cat form)
+template <bool X32>
 __global__ void gn_stats_kernel(const h16_t* __restrict__ x, float* __restrict__ partial, int HW, int C, int G,
                                 int nchunk, int KP, const h16_t* __restrict__ x2, int C1, h16_t* __restrict__ cat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,6 +41,23 @@ __global__ void gn_stats_kernel(const h16_t* __restrict__ x, float* __restrict__
     const h16_t* xb = (second ? x2 + (size_t)b * HW * ld + (v * 8 - C1) : x + (size_t)b * HW * ld + v * 8);
     // 4 independent 16-byte loads in flight per thread (a runtime-trip loop with one load per iteration would
     // serialise the L2/HBM round trips)
+    if (X32) {
+        const float* xf = reinterpret_cast<const float*>(x) + (size_t)b * HW * C + v * 8;
+        for (int px = p0 + pl; px < p1; px += 4 * KP) {
+            f32x4 a[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = px + u * KP;
+                const bool ok = pp < p1;
+                a[u][0] = ok ? *reinterpret_cast<const f32x4*>(xf + (size_t)pp * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                a[u][1] = ok ? *reinterpret_cast<const f32x4*>(xf + (size_t)pp * C + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = a[u][j >> 2][j & 3]; s[j] += t; q[j] += t * t; }
+        }
+    } else
     for (int px = p0 + pl; px < p1; px += 4 * KP) {
         u32x4 a[4];
 #pragma unroll
@@ -89,11 +108,13 @@ __global__ void gn_stats_kernel(const h16_t* __restrict__ x, float* __restrict__
 
 // GroupNorm, pass 2: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU; output bf16.
 // Rounds once after the affine (as torch's GroupNorm does) and once more after SiLU.
-template <bool SILU>
+// X32 (precise mode): x is the fp32 master, the value is rounded ONCE on the way out (no 16-bit stop between the affine and SiLU),
+// and y32 (optional) receives it unrounded for a consumer that splits it into hi / lo operand halves.
+template <bool SILU, bool X32 = false>
 __global__ void gn_apply_kernel(const h16_t* __restrict__ x, const float* __restrict__ partial,
                                 const h16_t* __restrict__ gamma, const h16_t* __restrict__ beta,
                                 h16_t* __restrict__ y, int HW, int C, int G, int nchunk,
-                                float eps, int pix_per_block, int KP) {
+                                float eps, int pix_per_block, int KP, float* __restrict__ y32 = nullptr) {
     // Block = (C/8)*KP threads like pass 1: a thread owns one 8-channel vector for all its pixels, so the per-channel
     // scale a_c = rstd_g * gamma_c and shift b_c = beta_c - mean_g * a_c live in 16 registers and the inner loop is one fma
     // (+ SiLU) per element -- no per-element group lookup (an integer division by a runtime C/G and two LDS reads before).
@@ -153,6 +174,43 @@ __global__ void gn_apply_kernel(const h16_t* __restrict__ x, const float* __rest
     const int p1 = min(HW, p0 + pix_per_block);
     const h16_t* xb = x + (size_t)b * HW * C + v * 8;
     h16_t* yb = y + (size_t)b * HW * C + v * 8;
+    if (X32) {
+        const float* xf = reinterpret_cast<const float*>(x) + (size_t)b * HW * C + v * 8;
+        float* y32b = y32 ? y32 + (size_t)b * HW * C + v * 8 : nullptr;
+        for (int px = p0 + pl; px < p1; px += 4 * KP) {
+            f32x4 a[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = px + u * KP;
+                const bool ok = pp < p1;
+                a[u][0] = ok ? *reinterpret_cast<const f32x4*>(xf + (size_t)pp * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                a[u][1] = ok ? *reinterpret_cast<const f32x4*>(xf + (size_t)pp * C + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = px + u * KP;
+                if (pp >= p1) break;
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = fmaf(a[u][j >> 2][j & 3], ca[j], cb[j]);
+                    if (SILU) t = silu_f(t);
+                    o[j] = t;
+                }
+                if (y32b) {
+                    *reinterpret_cast<f32x4*>(y32b + (size_t)pp * C) = f32x4{o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f32x4*>(y32b + (size_t)pp * C + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                }
+                if (y) {
+                    u32x4 ov;
+                    ov.x = pack_h16x2(o[0], o[1]); ov.y = pack_h16x2(o[2], o[3]);
+                    ov.z = pack_h16x2(o[4], o[5]); ov.w = pack_h16x2(o[6], o[7]);
+                    *reinterpret_cast<u32x4*>(yb + (size_t)pp * C) = ov;
+                }
+            }
+        }
+        return;
+    }
     for (int px = p0 + pl; px < p1; px += 4 * KP) {
         u32x4 a[4];
 #pragma unroll
@@ -585,9 +643,11 @@ __global__ __launch_bounds__(256) void add_kernel(const h16_t* __restrict__ a, c
 // Small convolutions that do not fit the MFMA tile (Cin = 4 conv_in, Cout = 3/4 conv_out).
 // ------------------------------------------------------------------------------------------
 // Cin <= 8: one thread per (pixel, 8 output channels). w [Cout, ks, ks, Cin] staged in LDS as fp32.
+// x32 (optional, precise mode): the input as fp32 NHWC instead of x; y32 (optional): fp32 copy of the result (the stream's master)
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                              const h16_t* __restrict__ bias, h16_t* __restrict__ y,
-                                                             int B, int H, int W, int Cin, int Cout, int ks) {
+                                                             int B, int H, int W, int Cin, int Cout, int ks,
+                                                             const float* __restrict__ x32 = nullptr, float* __restrict__ y32 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ws = reinterpret_cast<float*>(smem);
     const int kk = ks * ks * Cin;
@@ -609,9 +669,9 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const h16_t* __rest
             for (int kx = 0; kx < ks; ++kx) {
                 const int ix = ox + kx - pad;
                 if (ix < 0 || ix >= W) continue;
-                const h16_t* src = x + (((size_t)b * H + iy) * W + ix) * Cin;
+                const size_t so = (((size_t)b * H + iy) * W + ix) * Cin;
                 for (int c = 0; c < Cin; ++c) {
-                    const float xv = h16_to_f32(src[c]);
+                    const float xv = x32 ? x32[so + c] : h16_to_f32(x[so + c]);
                     const float* wk = ws + ((ky * ks + kx) * Cin + c) * Cout + v * 8;
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
                     acc[0] += xv * w0[0]; acc[1] += xv * w0[1]; acc[2] += xv * w0[2]; acc[3] += xv * w0[3];
@@ -623,6 +683,10 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const h16_t* __rest
         ov.x = pack_h16x2(acc[0], acc[1]); ov.y = pack_h16x2(acc[2], acc[3]);
         ov.z = pack_h16x2(acc[4], acc[5]); ov.w = pack_h16x2(acc[6], acc[7]);
         *reinterpret_cast<u32x4*>(y + pix * Cout + v * 8) = ov;
+        if (y32) {
+            *reinterpret_cast<f32x4*>(y32 + pix * Cout + v * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(y32 + pix * Cout + v * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
     }
 }
 
@@ -631,7 +695,7 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const h16_t* __rest
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const h16_t* __restrict__ x, const h16_t* __restrict__ w,
                                                               const h16_t* __restrict__ bias, float* __restrict__ y32,
                                                               h16_t* __restrict__ y16, int B, int H, int W, int Cin,
-                                                              int Cout, int ks) {
+                                                              int Cout, int ks, const float* __restrict__ x32 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16_t* ws = reinterpret_cast<h16_t*>(smem);  // [Cout][ks*ks*Cin]
     const int kk = ks * ks * Cin;
@@ -649,8 +713,18 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const h16_t* __res
             const int tap = i / cvn, cvi = i % cvn;
             const int iy = oy + tap / ks - pad, ix = ox + tap % ks - pad;
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            const u32x4 a = *reinterpret_cast<const u32x4*>(x + (((size_t)b * H + iy) * W + ix) * Cin + cvi * 8);
-            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+            const size_t xo = (((size_t)b * H + iy) * W + ix) * Cin + cvi * 8;
+            float xa[8];
+            if (x32) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(x32 + xo), a1 = *reinterpret_cast<const f32x4*>(x32 + xo + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xa[j] = a0[j]; xa[4 + j] = a1[j]; }
+            } else {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(x + xo);
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xa[2 * j] = h16lo_to_f32(aw[j]); xa[2 * j + 1] = h16hi_to_f32(aw[j]); }
+            }
 #pragma unroll
             for (int co = 0; co < 8; ++co) {
                 if (co < Cout) {
@@ -658,7 +732,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const h16_t* __res
                     const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[co] += h16lo_to_f32(aw[j]) * h16lo_to_f32(ww[j]) + h16hi_to_f32(aw[j]) * h16hi_to_f32(ww[j]);
+                        acc[co] += xa[2 * j] * h16lo_to_f32(ww[j]) + xa[2 * j + 1] * h16hi_to_f32(ww[j]);
                 }
             }
         }
@@ -694,6 +768,18 @@ __global__ __launch_bounds__(256) void latent_in_kernel(const float* __restrict_
 }
 
 // eps[b, c, px] = e_u + g * (e_c - e_u) from UNet output e [2, B, HW, C] (fp32 NHWC); out fp32 NCHW.
+__global__ __launch_bounds__(256) void latent_in32_kernel(const float* __restrict__ lat, float* __restrict__ out, int B, int C, int HW,
+                                                          int reps, float scale) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const size_t px = (idx / C) % HW;
+        const size_t b = idx / ((size_t)C * HW);
+        const float v = lat[(b * C + c) * HW + px] * scale;
+        for (int r = 0; r < reps; ++r) out[(size_t)r * total + idx] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* __restrict__ e, float* __restrict__ out, int B, int C,
                                                           int HW, float g) {
     const size_t total = (size_t)B * C * HW;
@@ -793,7 +879,7 @@ int SPIDER_FN(spider_groupnorm_stats_nhwc)(const void* x, void* partial, int B, 
     if (KP < 1) KP = 1;
     const int threads = cv * KP;
     SPIDER_CHECK(threads <= 1024, "groupnorm_stats: C too large");
-    gn_stats_kernel<<<dim3(nchunk, B), threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>(
+    gn_stats_kernel<false><<<dim3(nchunk, B), threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>(
         (const h16_t*)x, (float*)partial, HW, C, G, nchunk, KP, nullptr, C, nullptr);
     SPIDER_LAUNCH_OK();
     return 0;
@@ -817,6 +903,39 @@ int SPIDER_FN(spider_groupnorm_apply_nhwc)(const void* x, const void* partial, i
                                                                        (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
     else gn_apply_kernel<false><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x, (const float*)partial, (const h16_t*)gamma,
                                                                     (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// "precise" GroupNorm (ABI v4): x32 [B, HW, C] is the FP32 master of the residual stream (not its 16-bit
+// shadow); statistics from `partial` ([B, nchunk, G, 2], e.g. the producing conv's) or, partial == NULL, from a pass over x32 into ws
+// (>= B * spider_groupnorm_nchunk(HW) * G * 2 floats); the normalised (+ SiLU) value is rounded once into y (16-bit, optional) and /
+// or stored unrounded into y32 (fp32, optional: the A operand of spider_gemm_a32 / spider_conv_nhwc_a32).
+int SPIDER_FN(spider_groupnorm_f32in_nhwc)(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
+                                     float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm_f32in: G must divide 256 and be <= 64");
+    SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192 && x32 && (y || y32), "groupnorm_f32in: C % 8, C % G; x32 and an output are required");
+    const int cv = C / 8;
+    int KP = 256 / cv;
+    if (KP < 1) KP = 1;
+    const int threads = cv * KP;
+    SPIDER_CHECK(threads <= 1024 && (threads >= 128 || threads >= 2 * G), "groupnorm_f32in: unsupported channel count for the block layout");
+    if (!partial) {
+        SPIDER_CHECK(ws, "groupnorm_f32in: ws is required without partial statistics");
+        nchunk = gn_nchunk(HW);
+        gn_stats_kernel<true><<<dim3(nchunk, B), threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>(
+            (const h16_t*)x32, ws, HW, C, G, nchunk, KP, nullptr, C, nullptr);
+        SPIDER_LAUNCH_OK();
+        partial = ws;
+    }
+    SPIDER_CHECK(nchunk > 0, "groupnorm_f32in: nchunk");
+    int ppb = 4 * KP;
+    while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;
+    dim3 g2((HW + ppb - 1) / ppb, B);
+    if (silu) gn_apply_kernel<true, true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x32, partial, (const h16_t*)gamma,
+                                                                             (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP, y32);
+    else gn_apply_kernel<false, true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x32, partial, (const h16_t*)gamma,
+                                                                          (const h16_t*)beta, (h16_t*)y, HW, C, G, nchunk, eps, ppb, KP, y32);
     SPIDER_LAUNCH_OK();
     return 0;
 }
@@ -849,7 +968,7 @@ static int groupnorm_impl(const void* x, const void* x2, const void* gamma, cons
     const int threads = cv * KP;
     SPIDER_CHECK(threads <= 1024, "groupnorm: C too large");
     dim3 g1(nchunk, B);
-    gn_stats_kernel<<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const h16_t*)x, (float*)ws, HW, C,
+    gn_stats_kernel<false><<<g1, threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>((const h16_t*)x, (float*)ws, HW, C,
                                                                                        G, nchunk, KP, (const h16_t*)x2, C1, (h16_t*)cat);
     SPIDER_LAUNCH_OK();
     if (x2) x = cat;              // pass 2 reads the concatenated copy pass 1 has just written
@@ -1035,6 +1154,46 @@ int SPIDER_FN(spider_conv2d_small_cout)(const void* x, const void* w, const void
     SPIDER_LAUNCH_OK();
     return 0;
 }
+
+// "precise" forms of conv_in / conv_out (ABI v4): the input is fp32 NHWC (the un-rounded latents; the fp32 GroupNorm + SiLU output),
+// conv_in also leaves the fp32 master of its result.
+int SPIDER_FN(spider_conv2d_small_cin_f32in)(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
+                                       int Cin, int Cout, int ks, void* stream) {
+    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 8 && Cout % 8 == 0 && x32 && y, "conv_small_cin_f32in: Cin <= 8, Cout % 8 == 0");
+    SPIDER_CHECK(ks == 1 || ks == 3, "conv_small_cin_f32in: kernel size must be 1 or 3");
+    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(float);
+    SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cin_f32in: weights exceed LDS");
+    int grid = grid_for((size_t)B * H * W * (Cout / 8));
+    if (grid > 512) grid = 512;
+    conv_small_cin_kernel<<<grid, 256, smem, (hipStream_t)stream>>>(nullptr, (const h16_t*)w, (const h16_t*)bias, (h16_t*)y, B, H, W, Cin,
+                                                                    Cout, ks, x32, y32);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+int SPIDER_FN(spider_conv2d_small_cout_f32in)(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,
+                                        int Cout, int ks, void* stream) {
+    SPIDER_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 8 && x32 && y32, "conv_small_cout_f32in: Cout <= 8, Cin % 8 == 0");
+    SPIDER_CHECK((ks == 1 || ks == 3) && (Cout * ks * ks * Cin) % 8 == 0, "conv_small_cout_f32in: kernel size 1 or 3");
+    const size_t smem = (size_t)Cout * ks * ks * Cin * sizeof(h16_t);
+    SPIDER_CHECK(smem <= 160 * 1024, "conv_small_cout_f32in: weights exceed LDS");
+    size_t grid = ((size_t)B * H * W + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    conv_small_cout_kernel<<<(int)grid, 256, smem, (hipStream_t)stream>>>(nullptr, (const h16_t*)w, (const h16_t*)bias, y32, nullptr, B, H, W,
+                                                                         Cin, Cout, ks, x32);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+#ifndef SPIDER_F16
+// fp32 NCHW latents -> fp32 NHWC [reps * B, HW, C] (the un-rounded UNet input of the "precise" conv_in, ABI v4)
+int spider_latent_to_nhwc_f32(const float* lat, float* out, int B, int C, int HW, int reps, float scale, void* stream) {
+    SPIDER_CHECK(B > 0 && C > 0 && HW > 0 && reps >= 1, "latent_to_nhwc_f32: bad shape");
+    latent_in32_kernel<<<grid_for((size_t)B * C * HW), 256, 0, (hipStream_t)stream>>>(lat, out, B, C, HW, reps, scale);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+#endif
 
 int SPIDER_FN(spider_latent_to_nhwc)(const float* lat, void* out, int B, int C, int HW, int reps, float scale, void* stream) {
     SPIDER_CHECK(B > 0 && C > 0 && HW > 0 && reps >= 1, "latent_to_nhwc: bad shape");

@@ -15,7 +15,9 @@ import torch
 from . import lib as _lib
 
 BF16 = torch.bfloat16
-ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "leaky_relu": 5, "relu": 6, "tanh": 7, "swiglu": 8}
+ACT = {None: 0, "none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "geglu": 4, "leaky_relu": 5, "relu": 6, "tanh": 7, "swiglu": 8,
+       "geglu_exact": 9}       # 9: GEGLU with ONE final rounding (precise mode; 4 rounds value, gate and gelu(gate) like an f16 module)
+GLU_ACTS = ("geglu", "swiglu", "geglu_exact")
 
 
 def _stream() -> int:
@@ -402,7 +404,7 @@ def gemm(A, W, bias=None, res=None, rowbias=None, rows_per_group=0, act=None, ou
     assert A.shape[-1] == K, f"gemm: A[..., {A.shape[-1]}] vs W[{N},{K}]"
     M = A.numel() // K
     # GEGLU epilogue: W = [value rows | gate rows]; SwiGLU epilogue (LlamaMLP): W = [gate rows | up rows]; the output has N/2 columns
-    n_out = N // 2 if act in ("geglu", "swiglu") else N
+    n_out = N // 2 if act in GLU_ACTS else N
     if out is None:
         out = torch.empty(*A.shape[:-1], n_out, dtype=torch.float32 if out_f32 else dt, device=A.device)
     c16, c32 = (None, out) if out.dtype == torch.float32 else (out, None)
@@ -437,9 +439,9 @@ def gemm_ln(A, Wf, colsum, colbias, res=None, act=None, eps=1e-5, out=None):
     _chk(A, dt, "A"); _chk(Wf, dt, "Wf"); _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
     N, K = Wf.shape
     assert A.shape[-1] == K and colsum.numel() == N and colbias.numel() == N, "gemm_ln: shape mismatch"
-    assert act in (None, "geglu"), "gemm_ln: only the plain and GEGLU epilogues exist"
+    assert act in (None, "geglu", "geglu_exact"), "gemm_ln: only the plain and GEGLU epilogues exist"
     M = A.numel() // K
-    n_out = N // 2 if act == "geglu" else N
+    n_out = N // 2 if act in GLU_ACTS else N
     if out is None:
         out = torch.empty(*A.shape[:-1], n_out, dtype=dt, device=A.device)
     if res is not None:
@@ -733,6 +735,122 @@ def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=Non
               S * n_q * d, d, n_q * d, n_kv * T_max * d, T_max * d, d, n_kv * T_max * d, T_max * d, d,
               S * n_q * d, d, n_q * d,
               B, n_q, n_kv, S, Lk, d, float(scale), int(causal), int(kv_off), _p(kv_beg), None, 0, 0, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- "precise" fp32-operand forms (ABI v4)
+# The A operand (or the NHWC image) is an fp32 tensor -- the master of the residual stream, or a GroupNorm output kept in fp32 -- and
+# is split into hi / lo 16-bit halves inside the kernel (two MFMAs per K step): include/spider_hip.h, DESIGN.md section 4. The
+# 16-bit format of the call is that of W.
+def gemm_a32(A32, W, bias=None, res=None, out_scale=1.0, res32=None, want32=False):
+    dt, sfx = _h16(W)
+    _chk(A32, torch.float32, "A32"); _chk(W, dt, "W")
+    N, K = W.shape
+    assert A32.shape[-1] == K, f"gemm_a32: A[..., {A32.shape[-1]}] vs W[{N},{K}]"
+    M = A32.numel() // K
+    out = torch.empty(*A32.shape[:-1], N, dtype=dt, device=A32.device)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=A32.device) if want32 else None
+    if res32 is not None:
+        _chk(res32, torch.float32, "res32")
+    wt = _tiled(W, M)
+    _lib.call(f"spider_gemm_a32_{sfx}", _p(A32), _p(W if wt is None else wt), _p(out), _p(bias), _p(res), M, N, K, K, N, float(out_scale),
+              int(wt is not None), _p(res32), _p(o32), _p(_workspace(A32.device)), WS_BYTES, _stream())
+    return (out, o32) if want32 else out
+
+
+def gemm_gn_in_a32(A32, W, part: "GnPartial", gamma, beta, HW: int, eps: float, bias=None, want32=False):
+    """GroupNorm(A32) @ W^T + bias with A32 [B, HW, K] fp32, normalised in fp32 inside the GEMM and split hi / lo"""
+    dt, sfx = _h16(W)
+    _chk(A32, torch.float32, "A32"); _chk(W, dt, "W")
+    N, K = W.shape
+    M = A32.numel() // K
+    out = torch.empty(*A32.shape[:-1], N, dtype=dt, device=A32.device)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=A32.device) if want32 else None
+    wt = _tiled(W, M)
+    _lib.call(f"spider_gemm_gn_in_a32_{sfx}", _p(A32), _p(W if wt is None else wt), _p(out), _p(bias), M, N, K, N, int(wt is not None),
+              _p(part.t), part.nchunk, _p(gamma), _p(beta), part.groups, float(eps), HW, _p(o32), _stream())
+    return (out, o32) if want32 else out
+
+
+def conv_a32(x32, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), dil=1, up_size=None, out_scale=1.0, res32=None, want32=False):
+    """NHWC conv with the fp32 image x32 [B,H,W,Cin] as the A operand; w [Cout,kh,kw,Cin] 16-bit -> [B,Ho,Wo,Cout] 16-bit (+ fp32)."""
+    dt, sfx = _h16(w)
+    _chk(x32, torch.float32, "x32"); _chk(w, dt, "w")
+    B, H, Wd, Cin = x32.shape
+    Cout, kh, kw = w.shape[0], w.shape[1], w.shape[2]
+    assert w.shape[3] == Cin, f"conv_a32: x has {Cin} channels, w expects {w.shape[3]}"
+    Hs, Ws = up_size if up_size is not None else (H, Wd)
+    Ho = (Hs + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Ws + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
+    out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x32.device)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=x32.device) if want32 else None
+    if res32 is not None:
+        _chk(res32, torch.float32, "res32")
+    uh, uw = up_size if up_size is not None else (0, 0)
+    wt = _tiled(w, B * Ho * Wo)
+    _lib.call(f"spider_conv_nhwc_a32_{sfx}", _p(x32), _p(w if wt is None else wt), _p(out), _p(bias), _p(res), _p(rowbias), B, H, Wd, Cin,
+              Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, float(out_scale), int(wt is not None), _p(res32), _p(o32),
+              _p(_workspace(x32.device)), WS_BYTES, _stream())
+    return (out, o32) if want32 else out
+
+
+def groupnorm_f32in(x32, gamma, beta, groups=32, eps=1e-5, silu=False, partial: Optional["GnPartial"] = None, want16=True, want32=False):
+    """GroupNorm (+ SiLU) of the fp32 tensor x32 [B, ..., C]; returns the 16-bit result (rounded once), the fp32 result, or both."""
+    dt, sfx = _h16(gamma)
+    _chk(x32, torch.float32, "x32"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
+    B, Cn = x32.shape[0], x32.shape[-1]
+    HW = x32.numel() // (B * Cn)
+    y = torch.empty(x32.shape, dtype=dt, device=x32.device) if want16 else None
+    y32 = torch.empty_like(x32) if want32 else None
+    ws, pt, nch = None, None, 0
+    if partial is not None:
+        assert partial.groups == groups and tuple(partial.t.shape) == (B, partial.nchunk, groups, 2)
+        pt, nch = partial.t, partial.nchunk
+    else:
+        ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x32.device)
+    _lib.call(f"spider_groupnorm_f32in_nhwc_{sfx}", _p(x32), _p(pt), nch, _p(gamma), _p(beta), _p(y), _p(y32), _p(ws), B, HW, Cn, groups,
+              float(eps), int(silu), _stream())
+    return (y, y32) if (want16 and want32) else (y if want16 else y32)
+
+
+def conv2d_small_cin_f32in(x32, w, bias=None, want32=False):
+    dt, sfx = _h16(w)
+    _chk(x32, torch.float32, "x32"); _chk(w, dt, "w")
+    B, H, Wd, Cin = x32.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    out = torch.empty(B, H, Wd, Cout, dtype=dt, device=x32.device)
+    o32 = torch.empty(out.shape, dtype=torch.float32, device=x32.device) if want32 else None
+    _lib.call(f"spider_conv2d_small_cin_f32in_{sfx}", _p(x32), _p(w), _p(bias), _p(out), _p(o32), B, H, Wd, Cin, Cout, ks, _stream())
+    return (out, o32) if want32 else out
+
+
+def conv2d_small_cout_f32in(x32, w, bias=None):
+    dt, sfx = _h16(w)
+    _chk(x32, torch.float32, "x32"); _chk(w, dt, "w")
+    B, H, Wd, Cin = x32.shape
+    Cout, ks = w.shape[0], w.shape[1]
+    out = torch.empty(B, H, Wd, Cout, dtype=torch.float32, device=x32.device)
+    _lib.call(f"spider_conv2d_small_cout_f32in_{sfx}", _p(x32), _p(w), _p(bias), _p(out), B, H, Wd, Cin, Cout, ks, _stream())
+    return out
+
+
+def latent_to_nhwc_f32(lat, reps=1, scale=1.0):
+    """fp32 NCHW [B,C,H,W] -> fp32 NHWC [reps*B,H,W,C]"""
+    _chk(lat, torch.float32, "lat")
+    B, Cn, H, Wd = lat.shape
+    out = torch.empty(reps * B, H, Wd, Cn, dtype=torch.float32, device=lat.device)
+    _lib.call("spider_latent_to_nhwc_f32", _p(lat), _p(out), B, Cn, H * Wd, reps, float(scale), _stream())
+    return out
+
+
+def concat_channels_f32(a32, b32):
+    """channel concat of two fp32 NHWC tensors: a copy of bit patterns, done by the 16-bit concat kernel on the 2-halves-per-float view"""
+    _chk(a32, torch.float32, "a32"); _chk(b32, torch.float32, "b32")
+    C1, C2 = a32.shape[-1], b32.shape[-1]
+    out = torch.empty(*a32.shape[:-1], C1 + C2, dtype=torch.float32, device=a32.device)
+    rows = a32.numel() // C1
+    assert b32.numel() // C2 == rows
+    _lib.call("spider_concat_channels_bf16", _p(a32), _p(b32), _p(out), rows, 2 * C1, 2 * C2, _stream())
     return out
 
 

@@ -113,15 +113,25 @@ def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos=True, shift=0.
 
 
 class UNetEngine:
-    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False):
+    def __init__(self, cfg: UNetConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False,
+                 precise: bool = False):
         """dtype: torch.bfloat16 or torch.float16 -- the 16-bit storage / MFMA operand format of the whole engine (the reference
         loads its diffusion decoders with torch_dtype=torch.float16, spider_decoder.py:109; both instantiations of every kernel
         exist, see csrc/common.hpp).
         stream32: carry the residual stream (resnet outputs, the token stream of the transformer blocks) as an fp32 master beside
         its 16-bit shadow: every `x + f(x)` adds in fp32 (GEMM / conv epilogue operands res32 / c32d), every consumer (GroupNorm,
         folded LayerNorm, MFMA operands) reads the shadow. Removes the accumulating rounding of ~70 residual adds per evaluation
-        (the second precision lever next to dtype)."""
+        (the second precision lever next to dtype).
+        precise (implies stream32): the third lever, for north_star's 1e-3. Every kernel that consumes the residual stream reads its
+        fp32 MASTER instead of the 16-bit shadow -- the GroupNorms (ops.groupnorm_f32in), conv_shortcut, the down- / upsamplers and
+        proj_out through an fp32 A operand split into hi + lo halves inside the kernel (two MFMAs per K step: ops.conv_a32 /
+        gemm_a32), Transformer2DModel.norm -> proj_in the same way on the fp32 GroupNorm output, conv_in / conv_out on fp32 inputs;
+        conv1's output stays fp32 for norm2, and the GEGLU product is rounded once. These are the sites the per-site attribution
+        (scripts/exp/precision_sites.py) charges with ~75 % of the error variance of one evaluation; their cost is on small / latency-
+        bound launches (DESIGN.md section 4 for the measured ms and rel-L2)."""
         assert dtype in (torch.bfloat16, torch.float16), "UNetEngine: dtype must be bfloat16 or float16"
+        self.precise = bool(precise)
+        stream32 = bool(stream32) or self.precise
         self.cfg, self.device, self.dtype, self.stream32 = cfg, torch.device(device), dtype, bool(stream32)
         BF16 = dtype      # every 16-bit tensor this engine creates is of the engine dtype
         self.w: Dict[str, torch.Tensor] = {}
@@ -230,7 +240,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False):
+    def random_init(cls, cfg: UNetConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False, precise: bool = False):
         from_shapes = _param_shapes(cfg)
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
@@ -242,13 +252,17 @@ class UNetEngine:
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(torch.bfloat16)     # same values for either engine dtype (bf16-representable, exact in f16 too)
+        if precise:
+            return cls(cfg, w, device, dtype=dtype, precise=True)
         return cls(cfg, w, device, dtype=dtype, stream32=stream32) if stream32 else cls(cfg, w, device, dtype=dtype)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False, precise: bool = False):
         """diffusers layout: <path>/config.json + diffusion_pytorch_model.safetensors / .bin (spider_amd/checkpoint.py)."""
         from .checkpoint import load_state_dict, read_config
         cfg = UNetConfig.from_diffusers_dict(read_config(path))
+        if precise:
+            return cls(cfg, load_state_dict(path), device, dtype=dtype, precise=True)
         return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32)
 
     # ------------------------------------------------------------------ per-call preparation
@@ -357,6 +371,9 @@ class UNetEngine:
         """GroupNorm `n` of x; `partial` (or x._gnp): statistics its producing conv left behind (ops.conv_ex(gn_groups=...))"""
         if partial is None:
             partial = getattr(x, "_gnp", None)
+        x32 = getattr(x, "_s32", None) if self.precise else None
+        if x32 is not None:       # precise: the fp32 master, one rounding on the way out
+            return ops.groupnorm_f32in(x32, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu, partial=partial)
         return ops.groupnorm(x, self.w[n + ".weight"], self.w[n + ".bias"], self.cfg.groups, eps, silu, partial=partial)
 
     def _resnet(self, n, x, out_gn: bool = False):
@@ -366,6 +383,8 @@ class UNetEngine:
         its own (x._gnp), and with out_gn conv2 leaves those of the block's output for the GroupNorm that consumes it next."""
         w = self.w
         G = self.cfg.groups if self.gn_producer else None
+        if self.precise:
+            return self._resnet_precise(n, x, G, out_gn)
         if isinstance(x, tuple) and not self.gn_cat:
             x = ops.concat_channels(x[0], x[1])
         if isinstance(x, tuple):
@@ -395,6 +414,30 @@ class UNetEngine:
                        res32=sc32, want32=True, gn_groups=og)
         out, out32 = r[0], r[1]
         out._s32 = out32
+        if og:
+            out._gnp = r[2]
+        return out
+
+    def _resnet_precise(self, n, x, G, out_gn):
+        """ResnetBlock2D with every read of the stream on its fp32 master (UNetEngine(precise=True)): norm1 and the 1x1 shortcut read
+        x32 (the skip concat as an fp32 concat), conv1's output stays fp32 for norm2, the adds are fp32 as with stream32."""
+        w = self.w
+        if isinstance(x, tuple):
+            x32 = ops.concat_channels_f32(x[0]._s32, x[1]._s32)
+            xp = None
+        else:
+            x32, xp = x._s32, getattr(x, "_gnp", None)
+        a = ops.groupnorm_f32in(x32, w[n + ".norm1.weight"], w[n + ".norm1.bias"], self.cfg.groups, 1e-5, True, partial=xp)
+        r = ops.conv2d(a, w[n + ".conv1.weight"], bias=w[n + ".conv1.bias"], rowbias=self.tproj_view[n], want32=True, gn_groups=G)
+        h32, hp = r[1], (r[2] if G else None)
+        a = ops.groupnorm_f32in(h32, w[n + ".norm2.weight"], w[n + ".norm2.bias"], self.cfg.groups, 1e-5, True, partial=hp)
+        sc32 = x32
+        if n + ".conv_shortcut.weight" in w:
+            sc32 = ops.conv_a32(x32, w[n + ".conv_shortcut.weight"], bias=w[n + ".conv_shortcut.bias"], want32=True)[1]
+        og = G if out_gn else None
+        r = ops.conv2d(a, w[n + ".conv2.weight"], bias=w[n + ".conv2.bias"], res32=sc32, want32=True, gn_groups=og)
+        out = r[0]
+        out._s32 = r[1]
         if og:
             out._gnp = r[2]
         return out
@@ -436,7 +479,18 @@ class UNetEngine:
         rg = (lambda A_, W_w, bias, h_, h32_: ops.gemm(A_, W_w, bias=bias, res32=h32_, want32=True)) if s32 else \
              (lambda A_, W_w, bias, h_, h32_: (ops.gemm(A_, W_w, bias=bias, res=h_), None))
         xp = getattr(x, "_gnp", None)
-        if xp is not None and self.gn_fuse_in and (H * W_) % 64 == 0 and C % 64 == 0 and B * H * W_ < 16384 and w[n + ".proj_in.weight"].shape[0] % 4 == 0:
+        geglu = "geglu_exact" if self.precise else "geglu"
+        if self.precise:
+            # norm on the fp32 master, its fp32 output split hi / lo inside proj_in
+            x32 = x._s32
+            if xp is not None and self.gn_fuse_in and (H * W_) % 64 == 0 and C % 64 == 0 and w[n + ".proj_in.weight"].shape[0] % 4 == 0:
+                h, h32 = ops.gemm_gn_in_a32(x32.view(B, H * W_, C), w[n + ".proj_in.weight"], xp, w[n + ".norm.weight"], w[n + ".norm.bias"],
+                                            H * W_, 1e-6, bias=w[n + ".proj_in.bias"], want32=True)
+            else:
+                a32 = ops.groupnorm_f32in(x32, w[n + ".norm.weight"], w[n + ".norm.bias"], self.cfg.groups, 1e-6, False, partial=xp,
+                                          want16=False, want32=True)
+                h, h32 = ops.gemm_a32(a32.view(B, H * W_, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+        elif xp is not None and self.gn_fuse_in and (H * W_) % 64 == 0 and C % 64 == 0 and B * H * W_ < 16384 and w[n + ".proj_in.weight"].shape[0] % 4 == 0:
             # norm + proj_in in ONE launch: the statistics came with x (its producing conv), the normalisation is applied to the GEMM's
             # A operand on its way into LDS -- no statistics pass, no apply pass, no normalised copy of x
             r = ops.gemm_gn_in(x.view(B, H * W_, C), w[n + ".proj_in.weight"], xp, w[n + ".norm.weight"], w[n + ".norm.bias"], H * W_, 1e-6,
@@ -477,11 +531,16 @@ class UNetEngine:
                     o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
                 h, h32 = rg(o, w[b + ".attn2.to_out.0.weight"], w[b + ".attn2.to_out.0.bias"], h, h32)
             if fuse:       # norm3 + GEGLU projection: one launch
-                g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
+                g = ops.gemm_ln(h, *self.ln[b + ".ff"], act=geglu)
             else:
                 y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
-                g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")  # fused GEGLU
+                g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act=geglu)  # fused GEGLU
             h, h32 = rg(g, w[b + ".ff.net.2.weight"], w[b + ".ff.net.2.bias"], h, h32)
+        if self.precise:     # proj_out reads the stream's master
+            out, out32 = ops.gemm_a32(h32, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res32=x._s32.view(B, H * W_, C), want32=True)
+            outv = out.view(B, H, W_, C)
+            outv._s32 = out32.view(B, H, W_, C)
+            return outv
         if s32:
             x32 = getattr(x, "_s32", None)
             out, out32 = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], want32=True,
@@ -496,7 +555,14 @@ class UNetEngine:
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B2, h, w, in_ch] bf16 NHWC -> eps [B2, h, w, out_ch] fp32 NHWC (time step = current tproj_cur)."""
         cfg, w = self.cfg, self.w
-        h = ops.conv2d_small_cin(x, w["conv_in.weight"], w["conv_in.bias"])
+        P = self.precise
+        if P:                  # x: fp32 NHWC (ops.latent_to_nhwc_f32); conv_in leaves the master of the stream
+            if x.dtype != torch.float32:
+                x = x.float()
+            h, h32 = ops.conv2d_small_cin_f32in(x, w["conv_in.weight"], w["conv_in.bias"], want32=True)
+            h._s32 = h32
+        else:
+            h = ops.conv2d_small_cin(x, w["conv_in.weight"], w["conv_in.bias"])
         skips = [h]
         nb = len(cfg.block_out)
         for i in range(nb):
@@ -506,7 +572,13 @@ class UNetEngine:
                 if cfg.down_attn[i]:
                     h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cfg.heads[i], cfg.depth[i])
                 skips.append(h)
-            if i != nb - 1:
+            if i != nb - 1 and P:        # Downsample2D reads the stream's master; its output is stream too
+                dw = w[f"down_blocks.{i}.downsamplers.0.conv.weight"]
+                h32 = h._s32
+                h, o32 = ops.conv_a32(h32, dw, bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"], stride=2, pad=(1, 1), want32=True)
+                h._s32 = o32
+                skips.append(h)
+            elif i != nb - 1:
                 if self.gn_producer:     # the next block's first norm1 normalises this conv's output
                     h, hp = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
                                        stride=2, pad=1, gn_groups=cfg.groups)
@@ -524,6 +596,8 @@ class UNetEngine:
                 skip = skips.pop()
                 hh = h
                 if self.freeu is not None and i < 2:
+                    if self.precise:
+                        raise NotImplementedError("UNetEngine(precise=True) with FreeU: the story decoder runs the stream32 mode")
                     hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
                 h = self._resnet(f"up_blocks.{i}.resnets.{j}", (hh, skip), out_gn=cfg.up_attn[i])
                 if cfg.up_attn[i]:
@@ -532,8 +606,17 @@ class UNetEngine:
                 # Upsample2D to the size of the next skip connection (diffusers' forward_upsample_size rule; = exact 2x
                 # on latents that are multiples of 2^(levels-1), 2x-1 on e.g. the 125-row AudioLDM latent)
                 th, tw = skips[-1].shape[1], skips[-1].shape[2]
-                h = ops.conv_ex(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
-                                pad=(1, 1), up_size=(th, tw))
+                if P:
+                    h32 = h._s32
+                    h, o32 = ops.conv_a32(h32, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                                          pad=(1, 1), up_size=(th, tw), want32=True)
+                    h._s32 = o32
+                else:
+                    h = ops.conv_ex(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                                    pad=(1, 1), up_size=(th, tw))
+        if P:
+            a32 = ops.groupnorm_f32in(h._s32, w["conv_norm_out.weight"], w["conv_norm_out.bias"], cfg.groups, 1e-5, True, want16=False, want32=True)
+            return ops.conv2d_small_cout_f32in(a32, w["conv_out.weight"], w["conv_out.bias"])
         a = self._gn("conv_norm_out", h, True)
         return ops.conv2d_small_cout(a, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
 
@@ -697,7 +780,10 @@ def denoise(unet: "UNetEngine", scheduler, latents: torch.Tensor, enc: Optional[
     latents = (latents * scheduler.init_noise_sigma).contiguous()
     do_cfg = guidance > 1.0
     for i, t in enumerate(ts):
-        x2 = ops.latent_to_nhwc(latents, reps=2 if do_cfg else 1, dtype=unet.dtype)
+        if getattr(unet, "precise", False):
+            x2 = ops.latent_to_nhwc_f32(latents, reps=2 if do_cfg else 1)
+        else:
+            x2 = ops.latent_to_nhwc(latents, reps=2 if do_cfg else 1, dtype=unet.dtype)
         e = unet.step(x2, i, use_graph=use_graph)
         eps = ops.cfg_combine(e, guidance) if do_cfg else ops.nhwc_to_nchw(e)
         latents = scheduler.step(eps, t, latents)

@@ -37,7 +37,7 @@ def test_ctypes_table_mirrors_header():
 
 def test_identity_and_argument_validation():
     lib = slib.load()
-    assert lib.spider_abi_version() == 3
+    assert lib.spider_abi_version() == 4
     assert lib.spider_target_arch() == b"gfx950"
     assert lib.spider_lm_head_nparts(152064) == 2048 and lib.spider_groupnorm_nchunk(4096) == 128
     # validation happens on the host before any launch: bad shapes return -1 with a message, no GPU needed

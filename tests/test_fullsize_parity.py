@@ -78,6 +78,34 @@ def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype, stream32)
     _free()
 
 
+PRECISE_BOUND = 1.0e-3          # north_star's bound itself
+
+
+def test_sd15_unet_step_fullsize_precise_mode_inside_1e3(dev, sd15_case):
+    """UNetEngine(precise=True), f16: every read of the residual stream on its fp32 master (hi / lo operand split, fp32 GroupNorm
+    inputs), GEGLU rounded once -- one evaluation at the configs[1] size inside north_star's 1e-3 of the fp32 oracle."""
+    import time
+    from spider_amd.unet import UNetConfig, UNetEngine
+    ocfg, w, x, enc, t, ref = sd15_case
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=torch.float16, precise=True)
+    eng.prepare(torch.tensor([int(t)]), enc.to(dev))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)                 # fp32 NHWC: the precise conv_in reads the un-rounded latents
+    eager = eng.step(xn, 0, use_graph=False).permute(0, 3, 1, 2).clone()
+    graph = eng.step(xn, 0, use_graph=True).permute(0, 3, 1, 2)
+    assert torch.equal(eager, graph), "hipGraph replay must be bit-identical to eager launches"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.step(xn, 0, use_graph=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 100
+    r = _rel(eager, ref)
+    print(f"MEASURED fullsize sd15 unet_step precise f16 rel={r:.5f} ms_per_step={ms:.3f}")
+    assert r < PRECISE_BOUND, r
+    del eng
+    _free()
+
+
 # latents after the FULL denoising loop of configs[1] -- the quantity north_star names ("bf16 UNet latents agree within 1e-3
 # relative"): 40 PNDM steps = 41 UNet evaluations at CFG batch 2, guidance 7.5, [1,4,64,64] (custom_sd.py:627-652), engine in the
 # pipelines' default mode (f16 + fp32 residual stream) against the fp32 oracle loop (41 x 2.3 s of oracle on the box's host cores).
@@ -109,6 +137,25 @@ def test_sd15_full_41_step_loop_latents_match_oracle(dev, sd15_case, golden_dir)
     print(f"MEASURED fullsize sd15 41-step PNDM loop latents f16+stream32 rel={r:.5f} (loop displacement {moved:.3f})")
     assert moved > 0.05
     assert r < LOOP41_BOUND, r
+    del eng
+    _free()
+
+
+def test_sd15_full_41_step_loop_latents_precise_mode_inside_1e3(dev, sd15_case, golden_dir):
+    """the same loop with UNetEngine(precise=True): north_star's quantity inside north_star's bound"""
+    import numpy as np
+    from spider_amd.schedulers import PNDMScheduler
+    from spider_amd.unet import UNetConfig, UNetEngine, denoise
+    ocfg, w, x, enc, t, ref1 = sd15_case
+    fx = _loop_fixture(golden_dir, "oracle_loop_sd15_pndm40.npz")
+    lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(11))
+    assert np.array_equal(lat.numpy(), fx["latents_in"])
+    ref = torch.from_numpy(fx["latents_out"])
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), w, dev, dtype=torch.float16, precise=True)
+    got = denoise(eng, PNDMScheduler(), lat.to(dev), enc.to(dev), 7.5, 40)
+    r = _rel(got, ref)
+    print(f"MEASURED fullsize sd15 41-step PNDM loop latents precise f16 rel={r:.5f}")
+    assert r < PRECISE_BOUND, r
     del eng
     _free()
 
