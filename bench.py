@@ -172,7 +172,7 @@ class Responder:
         from spider_amd.llm import LlamaEngine, LLMConfig
         from spider_amd.pipelines import StableDiffusionPipeline
         from spider_amd.qwen_omni import QwenOmniThinker
-        from spider_amd.synthetic import FakeTokenizer, SyntheticOmniProcessor
+        from benchkit.synthetic import FakeTokenizer, SyntheticOmniProcessor
         from spider_amd.unet import UNetConfig, UNetEngine
         from spider_amd.vae import VAEConfig, VAEDecoderEngine
         self.args, self.dev = args, device
@@ -289,7 +289,7 @@ class AnyToManyResponder(Responder):
         from spider_amd.clip import CLIPTextConfig, CLIPTextEngine
         from spider_amd.pipelines import AudioLDMPipeline, TextToVideoSDPipeline
         from spider_amd.schedulers import DDIMScheduler
-        from spider_amd.synthetic import FakeRobertaTokenizer, FakeTokenizer
+        from benchkit.synthetic import FakeRobertaTokenizer, FakeTokenizer
         from spider_amd.unet import UNetConfig, UNetEngine
         from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
         from spider_amd.vae import VAEConfig, VAEDecoderEngine

@@ -142,6 +142,8 @@ class SiteOracle(UNetOracle):
         return self._lin(n + ".to_out.0", self._attn_core(q, k, v, heads, "2"))
 
     def time_embed(self, t, B, added=None, class_labels=None):
+        if self.cfg.addition_in or self.cfg.class_in:
+            return self.q(super().time_embed(t, B, added, class_labels), "temb")
         from oracle.unet import timestep_embedding
         te = self.q(timestep_embedding(t.expand(B) if t.ndim == 0 else t, self.cfg.block_out[0]), "temb")
         h1 = self.q(F.silu(self._lin("time_embedding.linear_1", te)), "temb")
@@ -191,11 +193,15 @@ def run(cfg, hw, subset=None, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(2, cfg.in_ch, hw, hw, generator=g).bfloat16().float()
     enc = torch.randn(2, 77, cfg.cross_dim, generator=g).bfloat16().float()
+    added = None
+    if cfg.addition_in:
+        added = dict(text_embeds=torch.randn(2, 1280, generator=g).bfloat16().float(),
+                     time_ids=torch.tensor([[512, 512, 0, 0, 512, 512]] * 2, dtype=torch.float32))
     t = torch.tensor(500)
     t0 = time.time()
-    ref = UNetOracle(cfg, w).forward(x, t, enc)
+    ref = UNetOracle(cfg, w).forward(x, t, enc, added)
     print(f"# fp32 oracle {time.time() - t0:.1f}s   latent {hw}x{hw}, CFG batch 2", flush=True)
-    rel = lambda exact: float((SiteOracle(cfg, w, exact).forward(x, t, enc) - ref).norm() / ref.norm())
+    rel = lambda exact: float((SiteOracle(cfg, w, exact).forward(x, t, enc, added) - ref).norm() / ref.norm())
     e_all = rel(())
     print(f"all sites rounded (the engine's design): rel-L2 {e_all:.3e}", flush=True)
     rows = []
@@ -223,5 +229,7 @@ if __name__ == "__main__":
             subset = a.split("=", 1)[1].split(",")
     if which == "tiny":
         run(UNetCfg.tiny8(), 16, subset, seed=1)
+    elif which == "sdxl":
+        run(UNetCfg.sdxl(), int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 64, subset, seed=4)
     else:
         run(UNetCfg.sd15(), int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 64, subset)

@@ -340,6 +340,11 @@ class LlamaEngine:
             w[first_row:first_row + rows.shape[0]] = rows.to(device=w.device, dtype=w.dtype)
         self._vocab_changed()
 
+    def would_capture(self, B: int, output_hidden_states: bool = False, return_logits: bool = False, cache_set: int = 0) -> bool:
+        """True when the decode loop of such a request would capture its hipGraph (state missing or not captured yet)"""
+        ent = self._graphs.get((int(B), bool(output_hidden_states), bool(return_logits), int(cache_set)))
+        return ent is None or ent[1] is None
+
     def _vocab_changed(self):
         """the lm_head moved or changed: drop what was derived from it (fragment-major copy, captured decode graphs, lm_head
         workspaces and logits buffers, all keyed in self._graphs)"""

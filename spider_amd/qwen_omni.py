@@ -319,6 +319,12 @@ class VisionTowerEngine:
 
     __call__ = forward
 
+    def has_graph(self, grid_thw) -> bool:
+        """is the hipGraph of this exact grid_thw captured (and still in the 8-entry cache)? A miss means forward() will capture."""
+        key = tuple(tuple(int(x) for x in g) for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw))
+        ent = self._cache.get(key)
+        return ent is not None and "graph" in ent
+
 
 # ---------------------------------------------------------------------------------------------- audio tower
 class AudioTowerEngine:
@@ -453,6 +459,11 @@ class AudioTowerEngine:
         return ent["out"].clone()
 
     __call__ = forward
+
+    def has_graph(self, feature_lens) -> bool:
+        lens = tuple(int(x) for x in (feature_lens.tolist() if hasattr(feature_lens, "tolist") else feature_lens))
+        ent = self._cache.get(lens)
+        return ent is not None and "graph" in ent
 
 
 # ---------------------------------------------------------------------------------------------- prompt assembly
@@ -662,6 +673,24 @@ class QwenOmniThinker:
         kw.pop("spk", None); kw.pop("return_audio", None)                          # talker options: no speech on this path
         h = self.llm.prefill_begin(inputs_embeds=emb, position_ids=pos, attention_mask=attention_mask, max_new_tokens=max_new_tokens, **kw)
         return (h, input_ids)
+
+    def would_capture(self, input_ids, attention_mask=None, cache_set: int = 0, pixel_values=None, image_grid_thw=None,
+                      pixel_values_videos=None, video_grid_thw=None, input_features=None, feature_attention_mask=None,
+                      audio_feature_lengths=None, output_hidden_states: bool = False, return_logits: bool = False, **_):
+        """Would `generate(**inputs)` capture a hipGraph -- a tower graph for these grid_thw VALUES / audio lengths, or the decode step
+        for this row count and KV cache set? Answered from the engines' own caches, so evictions and resets count. A pass that
+        captures must not run beside another host thread that enqueues or allocates (SpiderFreeInfer runs it alone)."""
+        if input_features is not None and self.audio is not None:
+            lens = feature_attention_mask.bool().sum(1).tolist() if feature_attention_mask is not None else audio_feature_lengths
+            if not self.audio.has_graph(lens):
+                return True
+        for pv, grid in ((pixel_values, image_grid_thw), (pixel_values_videos, video_grid_thw)):
+            if pv is not None and self.vision is not None and not self.vision.has_graph(grid):
+                return True
+        B = int(input_ids.shape[0])
+        if B > 8:          # grouped generate inside prefill_begin: graphs per group size
+            return True
+        return self.llm.would_capture(B, output_hidden_states, return_logits, cache_set)
 
     @torch.no_grad()
     def adopt(self, handle, cache_set: int = 0):

@@ -48,7 +48,8 @@ class SpiderFreeResult:
 
 class SpiderFreeInfer:
     def __init__(self, thinker, processor, decoder_infer=None, cfg=None, device="cuda:0", generate_kwargs: Optional[dict] = None,
-                 pipelined: bool = False, process_mm_info=None, streams=None, depth: int = 2):
+                 pipelined: bool = False, process_mm_info=None, streams=None, depth: int = 2, mode: str = "spider_free_qwen",
+                 story_pipe=None, story_kwargs: Optional[dict] = None, mask_box_inputs=None):
         """thinker: QwenOmniThinker (`model` of the reference); processor: the checkpoint's Qwen2_5OmniProcessor or an object with its
         three methods (apply_chat_template / __call__ / batch_decode); decoder_infer: SpiderDecoderInfer (built from `cfg` when
         omitted); generate_kwargs: extra arguments of every `thinker.generate` call (the reference passes spk / use_audio_in_video);
@@ -59,10 +60,22 @@ class SpiderFreeInfer:
         MI355X: depth 3 moves the prompt pass off the LLM stream (LLM pass 510 -> 461 ms) but the step stays at ~514 ms."""
         if depth not in (2, 3):
             raise ValueError("depth must be 2 or 3")
+        if mode not in ("spider_free_qwen", "spider_story_free_qwen"):
+            raise ValueError("mode must be 'spider_free_qwen' or 'spider_story_free_qwen' (MODEL_NAME of qwen2.5omni_spider_web.py:476,489)")
+        # mode = the reference's MODEL_NAME switch: "spider_free_qwen" -> Decoders-Controller (:489-520); "spider_story_free_qwen" ->
+        # extract_story_elements + story_generation straight from the response (:476-488; story_pipe = init_story_generation(...)).
+        # mask_box_inputs: optional callable(first input image as np.ndarray) -> {"IMAGE_SAM": [...], "Meta_info": {...}}: the SAM-side
+        # preprocessing of :497-518 is the caller's (SAM / Grounding-DINO are out of scope); its keys are forwarded in ask_info.
+        self.mode, self.story_diffusion, self.story_kwargs = mode, story_pipe, dict(story_kwargs or {})
+        self.mask_box_inputs = mask_box_inputs
+        if mode == "spider_story_free_qwen" and decoder_infer is None and cfg is None:
+            decoder_infer = False          # the story branch needs no Decoders-Controller
         if depth == 3 and not all(hasattr(thinker, m) for m in ("prefill_begin", "adopt", "decode_finish")):
             raise ValueError("depth=3 needs a thinker with prefill_begin / adopt / decode_finish (QwenOmniThinker)")
         self.depth = depth
-        if decoder_infer is None:
+        if decoder_infer is False:
+            decoder_infer = None
+        elif decoder_infer is None:
             if cfg is None:
                 raise ValueError("SpiderFreeInfer needs a SpiderDecoderInfer or the config to build one from")
             from .spider_decoder import SpiderDecoderInfer
@@ -87,8 +100,18 @@ class SpiderFreeInfer:
             audios, images, videos = self.process_mm_info(messages, True)
         inputs = self.processor(text=text, audios=audios, images=images, videos=videos, return_tensors="pt", padding=True)
         inputs = dict(inputs)
-        inputs["_images"] = images
+        inputs["_images"] = [images[0] if images else None]        # per row: the FIRST input image (qwen2.5omni_spider_web.py:495)
         return inputs
+
+    @staticmethod
+    def _n_images(messages) -> int:
+        """image items of one conversation, in the order process_mm_info walks them"""
+        n = 0
+        for m in messages:
+            c = m.get("content") if isinstance(m, dict) else None
+            if isinstance(c, (list, tuple)):
+                n += sum(1 for it in c if isinstance(it, dict) and (it.get("type") == "image" or "image" in it))
+        return n
 
     def build_inputs_batch(self, conversations: List) -> dict:
         """Several conversations as ONE request: one chat-template text per conversation, one processor call with padding. Batched
@@ -104,7 +127,13 @@ class SpiderFreeInfer:
         if tok is not None and getattr(tok, "padding_side", "left") != "left":
             tok.padding_side = "left"
         inputs = dict(self.processor(text=texts, audios=audios, images=images, videos=videos, return_tensors="pt", padding=True))
-        inputs["_images"] = images
+        # `images` is the flat list over all conversations: row i owns the next _n_images(conversation i) of them
+        per_row, k = [], 0
+        for conv in conversations:
+            n = self._n_images(conv)
+            per_row.append(images[k] if (images and n > 0 and k < len(images)) else None)
+            k += n
+        inputs["_images"] = per_row
         return inputs
 
     # ------------------------------------------------------------------ the two passes of a request
@@ -145,17 +174,44 @@ class SpiderFreeInfer:
 
     def decoder_pass(self, text_ids, responses: List[str], images=None) -> List[SpiderFreeResult]:
         """`ask_info` -> Decoders-Controller for every row of the request (qwen2.5omni_spider_web.py:489-520)."""
+        if self.mode == "spider_story_free_qwen":
+            return [self._story_result(r, text_ids[i]) for i, r in enumerate(responses)]
         asks = []
-        for r in responses:
+        for i, r in enumerate(responses):
             ask_info: Dict[str, Any] = {"llm_text_all": [routing.extract_answer(r)]}
-            if images is not None:     # inputs of the BOX / MASK decoders (:494-518; SAM / Grounding-DINO themselves are out of scope)
-                ask_info["Image_ori_array"] = [np.array(images[0])]
+            img = images[i] if (isinstance(images, (list, tuple)) and i < len(images)) else None
+            if img is not None:        # inputs of the BOX / MASK decoders (:494-518; SAM / Grounding-DINO themselves are out of scope)
+                arr = np.array(img)
+                ask_info["Image_ori_array"] = [arr]
+                if self.mask_box_inputs is not None:        # the caller's SAM-side preprocessing: IMAGE_SAM, Meta_info (:505-519)
+                    extra = self.mask_box_inputs(arr) or {}
+                    for k in ("IMAGE_SAM", "Meta_info"):
+                        if k in extra:
+                            ask_info[k] = extra[k]
             asks.append(ask_info)
         if len(asks) == 1:
             triples = [self.spider_decoder_infer(asks[0])]
         else:
             triples = self.spider_decoder_infer.spider_decoder.generate_batch(asks)
         return [SpiderFreeResult(r, a, p, pt, text_ids[i]) for i, (r, (a, p, pt)) in enumerate(zip(responses, triples))]
+
+    def _story_result(self, response: str, ids) -> SpiderFreeResult:
+        """the `spider_story_free_qwen` branch of predict (qwen2.5omni_spider_web.py:476-488): story elements from the response, then
+        story_generation when all three parsed; the reference's error line otherwise. Containers as SpiderStoryFreeInfer fills them."""
+        answers, predictions, predictions_text = routing.new_outputs()
+        answers.append(response)
+        predictions_text["IMAGESTORY"].append(response)
+        general_prompt, prompt_array, style_name = routing.extract_story_elements(response)
+        if self.story_diffusion is not None and general_prompt and prompt_array and isinstance(prompt_array, list) \
+                and len(prompt_array) > 0 and style_name:
+            from .story import story_generation
+            preds = story_generation(self.story_diffusion, general_prompt=general_prompt, prompt_array=prompt_array, style_name=style_name,
+                                     **self.story_kwargs)
+            predictions["IMAGESTORY"].append(preds)
+            predictions_text["IMAGESTORY_prompts"].append(prompt_array)
+        else:
+            print("Error: One or more required inputs for story_generation are empty!")
+        return SpiderFreeResult(response, answers, predictions, predictions_text, ids)
 
     def _inputs_of(self, messages, inputs):
         if (messages is None) == (inputs is None):
@@ -179,8 +235,19 @@ class SpiderFreeInfer:
                              if isinstance(v, torch.Tensor) and k not in ("input_ids", "attention_mask")))
         return (int(ids.shape[0]), extra)
 
-    @staticmethod
-    def _dec_key(pending):
+    def _llm_cold(self, inputs: dict, lkey, cache_set: int = 0) -> bool:
+        """would this LLM pass capture a hipGraph (tower per grid_thw / audio lengths, decode step per row count) -- i.e. must it run
+        alone? The engines answer from their own caches (values, evictions and resets included); a thinker without `would_capture`
+        falls back to the shapes seen before."""
+        wc = getattr(self.model, "would_capture", None)
+        if wc is None:
+            return lkey not in self._warm
+        kw = {k: v for k, v in inputs.items() if not k.startswith("_")}
+        return bool(wc(cache_set=cache_set, **kw))
+
+    def _dec_key(self, pending):
+        if self.mode == "spider_story_free_qwen":
+            return ("story", len(pending[1]))
         calls = [tuple(m for m, _ in routing.route_text(routing.extract_answer(r))[2]) for r in pending[1]]
         return (len(calls), tuple(sorted(calls)))
 
@@ -225,19 +292,23 @@ class SpiderFreeInfer:
             return None
         pending = self._pending
         dkey = self._dec_key(pending)
-        if lkey not in self._warm or dkey != self._last_dec:
+        if self._llm_cold(inputs, lkey) or dkey != self._last_dec or self.mode == "spider_story_free_qwen":
             out = self.decoder_pass(*pending)
             self._last_dec = dkey
             self._pending = self.llm_pass(inputs)
             self._warm.add(lkey)
             self.last_pass_ms = {}
             return self._unbatch(out)
-        out, self._pending = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
+        out, newpend, err = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
+        self._pending = newpend                       # the NEW request's LLM result survives a failed decoder pass of the old one
+        if err is not None:
+            raise err
         return self._unbatch(out)
 
     def _overlap(self, on_u, on_l):
         """run on_u() on the decoder stream from a helper host thread and on_l() on the LLM stream from this thread; both finished
-        (device included) on return. -> (result of on_u, result of on_l). The LLM pass's ~22 k launches fill its hardware queue, so its
+        (device included) on return. -> (result of on_u, result of on_l, the helper thread's exception or None): a failed decoder pass
+        must not lose the LLM result computed beside it -- the caller stores the new state first, then raises. The LLM pass's ~22 k launches fill its hardware queue, so its
         enqueue blocks the enqueueing thread for most of the pass: that is why the decoder pass has a thread of its own. (On a CPU
         device the two passes are simply two host threads: host-logic tests.)"""
         dev = self.device
@@ -274,14 +345,13 @@ class SpiderFreeInfer:
                 mark(3, sL)
         finally:
             th.join()
-        if "err" in box:
-            raise box["err"]
+            if gpu:                                   # nothing of this step is in flight when we return, error or not
+                sU.synchronize()
+                sL.synchronize()
         self.last_pass_ms = {"overlapped": True}
-        if gpu:
-            sU.synchronize()
-            sL.synchronize()
+        if gpu and "err" not in box:
             self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
-        return box["u"], box["l"]
+        return box.get("u"), box.get("l"), box.get("err")
 
     # ------------------------------------------------------------------ depth 3: the prompt pass rides on the decoder stream
     def _submit3(self, inputs: dict):
@@ -300,7 +370,8 @@ class SpiderFreeInfer:
             return None
         dgk = ("dg", pre[4], 0) if pre is not None else None           # decode graph of (rows, cache set 0)
         dkey = self._dec_key(pend) if pend is not None else None
-        warm = (pre is not None and pend is not None and lkey in self._warm and dgk in self._warm and dkey == self._last_dec)
+        warm = (pre is not None and pend is not None and not self._llm_cold(inputs, lkey, cset) and dgk in self._warm and
+                dkey == self._last_dec and self.mode != "spider_story_free_qwen")
         if not warm:                                 # some graph of this step does not exist yet: one pass after the other, one thread
             out = None
             if pend is not None:
@@ -314,13 +385,20 @@ class SpiderFreeInfer:
             self.last_pass_ms = {}
             return None if out is None else self._unbatch(out)
 
-        def on_u():
-            res = self.decoder_pass(*pend)
-            return res, self.prefill_pass(inputs, cset)
+        box = {}
 
-        (out, newpre), newpend = self._overlap(on_u, lambda: self.decode_pass(pre[0], pre[1]))
-        self._pending, self._prefilled = newpend, (*newpre, lkey, cset, B_new)
-        return self._unbatch(out)
+        def on_u():
+            box["res"] = self.decoder_pass(*pend)
+            return self.prefill_pass(inputs, cset)
+
+        newpre, newpend, err = self._overlap(on_u, lambda: self.decode_pass(pre[0], pre[1]))
+        self._pending = newpend
+        if newpre is None:          # the helper failed before / inside the new request's prompt pass: run it here, nothing is lost
+            newpre = self.prefill_pass(inputs, cset)
+        self._prefilled = (*newpre, lkey, cset, B_new)
+        if err is not None:
+            raise err
+        return self._unbatch(box["res"])
 
     @torch.no_grad()
     def flush(self):

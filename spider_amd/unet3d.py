@@ -96,13 +96,15 @@ def _param_shapes3d(c: UNet3DConfig) -> dict:
 
 
 class UNet3DEngine(UNetEngine):
-    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False):
+    def __init__(self, cfg: UNet3DConfig, weights: Dict[str, torch.Tensor], device="cuda:0", dtype=BF16, stream32: bool = False,
+                 precise: bool = False):
         """stream32: fp32 master of the residual stream beside its 16-bit shadow, as UNetEngine (the spatial resnets / transformers
-        are the base class's; the temporal convs and temporal transformers below carry the master through their own residual adds)."""
+        are the base class's; the temporal convs and temporal transformers below carry the master through their own residual adds).
+        precise: as UNetEngine(precise=True) -- every read of the stream on its master, here also in the temporal layers."""
         self.cfg3 = cfg
         # Conv3d (3,1,1) weights [O,I,3,1,1] -> [O,I,3,1]; the base class turns 4-D conv weights into OHWI = [O,3,1,I]
         w = {n: (t[..., 0] if t.ndim == 5 else t) for n, t in weights.items()}
-        super().__init__(cfg.as2d(), w, device, dtype=dtype, stream32=stream32)
+        super().__init__(cfg.as2d(), w, device, dtype=dtype, stream32=stream32, precise=precise)
         # Producer-side GroupNorm statistics (UNetEngine.gn_producer) are OFF for the video UNet: its large convs run on the 256^2 kernel
         # (no statistics epilogue -> the fallback pass costs what the norm's own pass costs) and its temporal norms span 16 frames
         # (720 chunks per image); measured on MI355X 50.4 ms per evaluation with them against 50.2 without. SPIDER_GN_PRODUCER_3D=1 turns
@@ -115,7 +117,7 @@ class UNet3DEngine(UNetEngine):
         self.frames = 1
 
     @classmethod
-    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False):
+    def random_init(cls, cfg: UNet3DConfig, device="cuda:0", seed=0, dtype=BF16, stream32: bool = False, precise: bool = False):
         gen = torch.Generator(device=device).manual_seed(seed)
         w = {}
         for n, shp in _param_shapes3d(cfg).items():
@@ -126,14 +128,14 @@ class UNet3DEngine(UNetEngine):
             else:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(BF16)
-        return cls(cfg, w, device, dtype=dtype, stream32=stream32)
+        return cls(cfg, w, device, dtype=dtype, stream32=stream32, precise=precise)
 
     @classmethod
-    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False):
+    def from_pretrained(cls, path: str, device="cuda:0", dtype=BF16, stream32: bool = False, precise: bool = False):
         """diffusers layout; cerspense/zeroscope_v2_576w publishes diffusion_pytorch_model.bin only (spider_amd/checkpoint.py)."""
         from .checkpoint import load_state_dict, read_config
         cfg = UNet3DConfig.from_diffusers_dict(read_config(path))
-        return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32)
+        return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32, precise=precise)
 
     def prepare(self, timesteps, enc, added=None, class_labels=None, frames: int = 1):
         """enc [B2, 77, cross]; the UNet input of step() is [B2*frames, h, w, C] (sample-major, frame-minor)."""
@@ -154,8 +156,12 @@ class UNet3DEngine(UNetEngine):
             hp = ops.GnPartial(hp.t.view(B, F_ * H * W_ // cr, hp.groups, 2), F_ * H * W_ // cr, hp.groups) if (F_ * H * W_) % cr == 0 else None
         G = self.cfg.groups if self.gn_producer else None
         for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
-            a = ops.groupnorm(h.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups, 1e-5, True,
-                              partial=hp)
+            if self.precise and i == 1:       # the stream's master, one rounding on the way out
+                a = ops.groupnorm_f32in(x._s32.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups,
+                                        1e-5, True, partial=hp)
+            else:
+                a = ops.groupnorm(h.view(B, F_ * H * W_, C), w[f"{n}.conv{i}.0.weight"], w[f"{n}.conv{i}.0.bias"], self.cfg.groups, 1e-5, True,
+                                  partial=hp)
             hp = None
             if i == 4 and self.stream32:     # x + conv4(...): the identity is added in fp32 and the new master handed on
                 x32 = getattr(x, "_s32", None)
@@ -187,9 +193,18 @@ class UNet3DEngine(UNetEngine):
         w, F_ = self.w, self.frames
         BF, H, W_, C = x.shape
         B, HW = BF // F_, H * W_
-        a = ops.groupnorm(x.view(B, F_ * HW, C), w[n + ".norm.weight"], w[n + ".norm.bias"], self.cfg.groups, 1e-6, False)
         s32, h32 = self.stream32, None
-        if s32:
+        P = self.precise
+        geglu = "geglu_exact" if P else "geglu"
+        if P:        # norm on the master, its fp32 output split hi / lo inside proj_in
+            a32 = ops.groupnorm_f32in(x._s32.view(B, F_ * HW, C), w[n + ".norm.weight"], w[n + ".norm.bias"], self.cfg.groups, 1e-6, False,
+                                      want16=False, want32=True)
+            h, h32 = ops.gemm_a32(a32.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
+        else:
+            a = ops.groupnorm(x.view(B, F_ * HW, C), w[n + ".norm.weight"], w[n + ".norm.bias"], self.cfg.groups, 1e-6, False)
+        if P:
+            pass
+        elif s32:
             h, h32 = ops.gemm(a.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"], want32=True)
         else:
             h = ops.gemm(a.view(BF * HW, C), w[n + ".proj_in.weight"], bias=w[n + ".proj_in.bias"])
@@ -205,11 +220,16 @@ class UNet3DEngine(UNetEngine):
             o = self._frame_attention(qkv, inner, heads, B, HW)
             h, h32 = rg(o, w[f"{b}.{at}.to_out.0.weight"], w[f"{b}.{at}.to_out.0.bias"], h, h32)
         if self.fuse_ln:
-            g = ops.gemm_ln(h, *self.ln[b + ".ff"], act="geglu")
+            g = ops.gemm_ln(h, *self.ln[b + ".ff"], act=geglu)
         else:
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
-            g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act="geglu")
+            g = ops.gemm(y, w[b + ".ff.net.0.proj.weight"], bias=w[b + ".ff.net.0.proj.bias"], act=geglu)
         h, h32 = rg(g, w[b + ".ff.net.2.weight"], w[b + ".ff.net.2.bias"], h, h32)
+        if P:
+            out, out32 = ops.gemm_a32(h32, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res32=x._s32.view(BF * HW, C), want32=True)
+            outv = out.view(BF, H, W_, C)
+            outv._s32 = out32.view(BF, H, W_, C)
+            return outv
         if s32:
             x32 = getattr(x, "_s32", None)
             out, out32 = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], want32=True,
@@ -239,7 +259,12 @@ class UNet3DEngine(UNetEngine):
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B2*F, h, w, in_ch] bf16 NHWC -> eps [B2*F, h, w, out_ch] fp32."""
         cfg, w = self.cfg, self.w
-        h = ops.conv2d_small_cin(x, w["conv_in.weight"], w["conv_in.bias"])
+        P = self.precise
+        if P:
+            h, h32 = ops.conv2d_small_cin_f32in(x if x.dtype == torch.float32 else x.float(), w["conv_in.weight"], w["conv_in.bias"], want32=True)
+            h._s32 = h32
+        else:
+            h = ops.conv2d_small_cin(x, w["conv_in.weight"], w["conv_in.bias"])
         h = self._temp_transformer("transformer_in", h, self.cfg3.tin_heads)
         skips = [h]
         nb = len(cfg.block_out)
@@ -252,8 +277,14 @@ class UNet3DEngine(UNetEngine):
                     h = self._temp_transformer(f"down_blocks.{i}.temp_attentions.{j}", h, cfg.heads[i])
                 skips.append(h)
             if i != nb - 1:
-                h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
-                               stride=2, pad=1)
+                if P:
+                    h32 = h._s32
+                    h, o32 = ops.conv_a32(h32, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
+                                          stride=2, pad=(1, 1), want32=True)
+                    h._s32 = o32
+                else:
+                    h = ops.conv2d(h, w[f"down_blocks.{i}.downsamplers.0.conv.weight"], bias=w[f"down_blocks.{i}.downsamplers.0.conv.bias"],
+                                   stride=2, pad=1)
                 skips.append(h)
         h = self._resnet("mid_block.resnets.0", h, out_gn=self._og(h))
         h = self._temp_conv("mid_block.temp_convs.0", h)
@@ -271,8 +302,17 @@ class UNet3DEngine(UNetEngine):
                     h = self._temp_transformer(f"up_blocks.{i}.temp_attentions.{j}", h, rheads[i])
             if i != nb - 1:
                 th, tw = skips[-1].shape[1], skips[-1].shape[2]
-                h = ops.conv_ex(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
-                                pad=(1, 1), up_size=(th, tw))
+                if P:
+                    h32 = h._s32
+                    h, o32 = ops.conv_a32(h32, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                                          pad=(1, 1), up_size=(th, tw), want32=True)
+                    h._s32 = o32
+                else:
+                    h = ops.conv_ex(h, w[f"up_blocks.{i}.upsamplers.0.conv.weight"], bias=w[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                                    pad=(1, 1), up_size=(th, tw))
+        if P:
+            a32 = ops.groupnorm_f32in(h._s32, w["conv_norm_out.weight"], w["conv_norm_out.bias"], cfg.groups, 1e-5, True, want16=False, want32=True)
+            return ops.conv2d_small_cout_f32in(a32, w["conv_out.weight"], w["conv_out.bias"])
         a = self._gn("conv_norm_out", h, True)
         return ops.conv2d_small_cout(a, w["conv_out.weight"], w["conv_out.bias"], out_f32=True)
 
@@ -289,7 +329,10 @@ def video_denoise(unet: UNet3DEngine, scheduler, latents: torch.Tensor, enc: tor
     lat = (latents.permute(0, 2, 1, 3, 4).reshape(B * F_, C, h, w) * scheduler.init_noise_sigma).contiguous()
     do_cfg = guidance > 1.0
     for i, t in enumerate(ts):
-        x2 = ops.latent_to_nhwc(lat, reps=2 if do_cfg else 1, dtype=unet.dtype)
+        if getattr(unet, "precise", False):
+            x2 = ops.latent_to_nhwc_f32(lat, reps=2 if do_cfg else 1)
+        else:
+            x2 = ops.latent_to_nhwc(lat, reps=2 if do_cfg else 1, dtype=unet.dtype)
         e = unet.step(x2, i, use_graph=use_graph)
         eps = ops.cfg_combine(e, guidance) if do_cfg else ops.nhwc_to_nchw(e)
         lat = scheduler.step(eps, t, lat)

@@ -1,5 +1,5 @@
-"""Test helpers: tiny seeded pipelines; the tokenizer stand-ins live in spider_amd/synthetic.py."""
-from spider_amd.synthetic import FakeRobertaTokenizer, FakeTokenizer  # noqa: F401
+"""Test helpers: tiny seeded pipelines; the tokenizer stand-ins live in benchkit/synthetic.py."""
+from benchkit.synthetic import FakeRobertaTokenizer, FakeTokenizer  # noqa: F401
 
 
 def tiny_audio_pipe(dev, dtype=None):

@@ -308,7 +308,7 @@ def test_spider_free_infer_with_an_image_in_the_request(dev):
     from spider_amd import SpiderDecoderInfer, SpiderFreeInfer
     from spider_amd.llm import LlamaEngine, LLMConfig
     from spider_amd.qwen_omni import OmniTokenIds, QwenOmniThinker, VisionTowerConfig, VisionTowerEngine
-    from spider_amd.synthetic import SyntheticOmniProcessor
+    from benchkit.synthetic import SyntheticOmniProcessor
     H = 256
     lcfg = LlamaCfg(H, 2, 4, 2, 128, 512, 400, 1000000.0, None, 1e-6, True, 512, False, (16, 24, 24))
     lw = LlamaOracle.random_weights(lcfg, seed=27, std=0.08)

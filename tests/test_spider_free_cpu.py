@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from spider_amd import SpiderDecoderInfer, SpiderFreeInfer
-from spider_amd.synthetic import SyntheticOmniProcessor
+from benchkit.synthetic import SyntheticOmniProcessor
 
 
 class FakeThinker:
@@ -228,3 +228,93 @@ def test_build_inputs_batch_switches_a_right_padding_tokenizer_to_the_left():
     infer.processor.tokenizer = Tok()
     infer.build_inputs_batch([[{"role": "user", "content": "a"}], [{"role": "user", "content": "b c d"}]])
     assert infer.processor.tokenizer.padding_side == "left"
+
+
+# ------------------------------------------------------------------------------------------ round 5: contract gaps + advisor items
+def test_story_mode_runs_story_generation_from_the_response(monkeypatch):
+    """MODEL_NAME == "spider_story_free_qwen" (qwen2.5omni_spider_web.py:476-488): extract_story_elements -> story_generation"""
+    import spider_amd.story as story
+    calls = []
+    monkeypatch.setattr(story, "story_generation", lambda pipe, general_prompt, prompt_array, style_name, **kw: calls.append(
+        (pipe, general_prompt, prompt_array, style_name, kw)) or [f"panel:{p}" for p in prompt_array])
+
+    class Proc(SyntheticOmniProcessor):
+        def batch_decode(self, ids, **kw):
+            return ["x\n<think>plan</think><GENERALPROMPT>a fox</GENERALPROMPT><PROMPTARRAY>['wakes up', 'eats']</PROMPTARRAY><STYLENAME>Comic book</STYLENAME>"]
+    infer = SpiderFreeInfer(FakeThinker(), Proc(vocab=500), device="cpu", mode="spider_story_free_qwen", story_pipe="PIPE",
+                            story_kwargs={"seed": 3})
+    res = infer([{"role": "user", "content": "a day of a fox"}])
+    assert calls == [("PIPE", "a fox", ["wakes up", "eats"], "Comic book", {"seed": 3})]
+    assert res.predictions["IMAGESTORY"] == [["panel:wakes up", "panel:eats"]] and res.predictions_text["IMAGESTORY_prompts"] == [["wakes up", "eats"]]
+    assert res.answers == [res.response]
+    # elements missing: the reference's error line, no story
+    infer.processor = SyntheticOmniProcessor(vocab=500, tags=("IMAGE",), head=3)
+    res = infer([{"role": "user", "content": "x"}])
+    assert res.predictions["IMAGESTORY"] == [] and len(calls) == 1
+    with pytest.raises(ValueError):
+        SpiderFreeInfer(FakeThinker(), Proc(vocab=500), device="cpu", mode="nope")
+
+
+def test_mask_box_inputs_are_forwarded_and_rows_get_their_own_image():
+    infer, pipe, _ = make(mask_box_inputs=lambda arr: {"IMAGE_SAM": [arr * 2], "Meta_info": {"original_shape": [arr.shape[:2]]}, "other": 1})
+    infer.process_mm_info = lambda messages, use_audio_in_video: (None, [[[1, 2, 3]]], None)
+    seen = {}
+    orig = infer.spider_decoder_infer.spider_decoder.generate
+    infer.spider_decoder_infer.spider_decoder.generate = lambda samples, *a: (seen.update(samples), orig(samples, *a))[1]
+    infer([{"role": "user", "content": [{"type": "image", "image": "a.png"}, {"type": "text", "text": "x"}]}])
+    assert seen["IMAGE_SAM"][0].tolist() == [[2, 4, 6]] and seen["Meta_info"] == {"original_shape": [(1, 3)]} and "other" not in seen
+    # a batch of three conversations: 2 images, none, 1 image -> every row its OWN first image, none for the row without
+    convs = [[{"role": "user", "content": [{"type": "image", "image": "a"}, {"type": "image", "image": "b"}]}],
+             [{"role": "user", "content": "no picture"}],
+             [{"role": "user", "content": [{"type": "image", "image": "c"}]}]]
+    infer.process_mm_info = lambda conversations, use_audio_in_video: (None, ["A", "B", "C"], None)
+    inputs = infer.build_inputs_batch(convs)
+    assert inputs["_images"] == ["A", None, "C"]
+    assert SpiderFreeInfer._n_images(convs[0]) == 2 and SpiderFreeInfer._n_images(convs[1]) == 0
+
+
+def test_overlap_decision_comes_from_the_engines_not_from_shapes():
+    """advisor (round 4): two audio clips of different lengths have the same tensor shapes; the thinker's graph caches are keyed by
+    values. A thinker that reports would_capture() keeps such a pass off the overlapped schedule."""
+    infer, pipe, thinker = make()
+    infer.processor.prompt_len = 4
+    cold = {"v": True}
+    thinker.would_capture = lambda cache_set=0, **kw: cold["v"]
+    threads = []
+    orig = thinker.generate
+    thinker.generate = lambda *a, **k: (threads.append(threading.current_thread().name), orig(*a, **k))[1]
+    dec_threads = []
+    orig_dec = infer.decoder_pass
+    infer.decoder_pass = lambda *a: (dec_threads.append(threading.current_thread().name), orig_dec(*a))[1]
+    mk = lambda i: {"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)}
+    for i in range(3):
+        infer.submit(inputs=mk(i))
+    assert all(t != "spider-decoder-enqueue" for t in dec_threads)          # cold every time: never overlapped, same shapes or not
+    cold["v"] = False
+    infer.submit(inputs=mk(3))
+    assert dec_threads[-1] == "spider-decoder-enqueue"                        # the engine says its graphs exist: overlapped
+    infer.flush()
+
+
+def test_failed_decoder_pass_does_not_lose_the_next_request():
+    infer, pipe, thinker = make()
+    infer.processor.prompt_len = 4
+    mk = lambda i: {"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)}
+    for i in range(3):                                                          # warm: request 2 is pending, overlap is on
+        infer.submit(inputs=mk(i))
+    boom = {"on": True}
+    orig = pipe.__class__.__call__
+
+    def failing(self, prompt=None, **kw):
+        if boom["on"]:
+            boom["on"] = False
+            raise RuntimeError("decoder blew up")
+        return orig(self, prompt=prompt, **kw)
+    pipe.__class__.__call__ = failing
+    try:
+        with pytest.raises(RuntimeError, match="decoder blew up"):
+            infer.submit(inputs=mk(3))                                          # decoder pass of request 2 fails beside the LLM pass of 3
+        nxt = infer.flush()                                                     # request 3's LLM result was kept: its decoder pass runs now
+        assert nxt is not None and nxt.text_ids[0] == 13
+    finally:
+        pipe.__class__.__call__ = orig
