@@ -214,6 +214,7 @@ class Responder:
         self.latents0 = torch.randn(self.max_batch, 4, 64, 64, generator=g, device=dev)
         self.enc_synth = torch.randn(2 * self.max_batch, 77, 768, generator=g, device=dev).to(D)
         self.overlap_ms, self.stage = None, {}
+        self.step_log = []          # one record per respond(): device span of each pass on its stream + host wall time of its pieces
         self._B = None
 
     def more_pipelines(self, dev, D):
@@ -255,6 +256,7 @@ class Responder:
         self.decoder.stage_events = {}
         out = self.pack(self.infer.predict(inputs=self.request(B)), B)
         self.stage = self.decoder.stage_ms_device()
+        self.step_log.append({**(self.infer.last_pass_ms or {}), **self.infer.host_ms})
         return out
 
     def respond(self, batch=None):
@@ -274,6 +276,7 @@ class Responder:
             res = self.infer.submit(inputs=self.request(B))
         self.overlap_ms = self.infer.last_pass_ms or None
         self.stage = self.decoder.stage_ms_device()
+        self.step_log.append({**(self.infer.last_pass_ms or {}), **self.infer.host_ms})
         return self.pack(res, B)
 
 
@@ -747,13 +750,19 @@ def run_timed(resp, args, rank, world, device):
     if world > 1:
         dist.barrier()
     sync()
+    if hasattr(resp, "step_log"):
+        resp.step_log.clear()
+    walls = []                      # host wall time of every timed step (a step ends with both streams synchronised)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         g = one_step()
+        walls.append((time.perf_counter() - ts) * 1e3)
     sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    resp.step_wall_ms = walls
     dist_info = {"world_size": 1, "backend": None}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
@@ -768,6 +777,36 @@ def run_timed(resp, args, rank, world, device):
 def dp_mod():
     from spider_amd import dp
     return dp
+
+
+def _dist4(xs):
+    xs = sorted(float(x) for x in xs)
+    if not xs:
+        return None
+    q = lambda f: xs[min(len(xs) - 1, int(round(f * (len(xs) - 1))))]
+    return {"min": round(xs[0], 2), "median": round(q(0.5), 2), "p90": round(q(0.9), 2), "max": round(xs[-1], 2), "n": len(xs)}
+
+
+def step_statistics(resp):
+    """What the timed region looked like, step by step (rank 0): the distribution of the steps' wall times, and per step the device
+    span of each pass on its own stream (HIP events recorded by SpiderFreeInfer), the idle time of each stream inside the step
+    (= wall - span: the stream had nothing to run), and the host wall time of the pieces of the LLM pass. Medians over the K timed
+    steps, so one odd step cannot describe the run."""
+    walls, log = getattr(resp, "step_wall_ms", []), list(getattr(resp, "step_log", []))
+    out = {"step_wall_ms": _dist4(walls)}
+    keys = sorted({k for r in log for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)})
+    out["per_step_median"] = {k: _dist4([r[k] for r in log if k in r])["median"] for k in keys}
+    if log and len(log) == len(walls):
+        idle = {"stream_llm_idle_ms": [w - r["llm_pass_ms"] for w, r in zip(walls, log) if "llm_pass_ms" in r],
+                "stream_decoder_idle_ms": [w - r["decoder_pass_ms"] for w, r in zip(walls, log) if "decoder_pass_ms" in r]}
+        out["gpu_idle_ms"] = {k: _dist4(v) for k, v in idle.items() if v}
+        # host work outside both device spans: a step's wall minus the longer of its two spans (chat inputs, batch_decode,
+        # tokenizer, PIL, thread start / join, the gather)
+        crit = [w - max(r.get("llm_pass_ms", 0.0), r.get("decoder_pass_ms", 0.0)) for w, r in zip(walls, log)
+                if "llm_pass_ms" in r or "decoder_pass_ms" in r]
+        if crit:
+            out["wall_minus_longest_span_ms"] = _dist4(crit)
+    return out
 
 
 def main():
@@ -907,6 +946,7 @@ def text_image_extras(args, resp, device):
     from spider_amd.unet import unet_flops, UNetConfig
     a = args
     extra = {"_includes": resp.includes()}
+    extra["timed_steps"] = step_statistics(resp)              # per-step distribution + per-stream spans / idle time (medians)
     if resp.overlap_ms:
         extra["overlap_last_step"] = resp.overlap_ms      # device time of the two concurrent passes of the last timed step
     torch.cuda.synchronize(device)
@@ -954,12 +994,23 @@ def text_image_extras(args, resp, device):
     # schedule when --schedule overlap)
     resp.respond_serial()
     torch.cuda.synchronize(device)
-    t1 = time.perf_counter()
-    for _ in range(2):
+    resp.step_log.clear()
+    sw = []
+    for _ in range(5):
+        t1 = time.perf_counter()
         resp.respond_serial()
-    torch.cuda.synchronize(device)
-    extra["serial_ms_per_response"] = round((time.perf_counter() - t1) / 2 * 1e3, 2)
+        torch.cuda.synchronize(device)
+        sw.append((time.perf_counter() - t1) * 1e3)
+    extra["serial_ms_per_response"] = round(sorted(sw)[len(sw) // 2], 2)          # median of 5
     extra["serial_responses_per_s"] = round(a.batch / (extra["serial_ms_per_response"] * 1e-3), 4)
+    resp.step_wall_ms = sw
+    ser = step_statistics(resp)
+    # the same host / GPU split for ONE request on one stream: device spans of its two passes (events), stage times inside the
+    # decoder pass (device), and what is left of the wall time = host work on the critical path + launch gaps
+    extra["serial_split"] = {"wall_ms": ser["step_wall_ms"], "per_response_median": ser["per_step_median"],
+                             "decoder_stage_ms_device_last": resp.stage,
+                             "wall_minus_device_spans_ms": _dist4([w - r.get("llm_pass_ms", 0.0) - r.get("decoder_pass_ms", 0.0)
+                                                                   for w, r in zip(sw, resp.step_log)])}
     tp, tok_s, frac = llm_phase(a.batch)
     extra["llm_prefill_ms"] = round(tp * 1e3, 1)
     extra["llm_decode_tokens_per_s"] = round(tok_s, 1)

@@ -676,7 +676,7 @@ class QwenOmniThinker:
 
     def would_capture(self, input_ids, attention_mask=None, cache_set: int = 0, pixel_values=None, image_grid_thw=None,
                       pixel_values_videos=None, video_grid_thw=None, input_features=None, feature_attention_mask=None,
-                      audio_feature_lengths=None, output_hidden_states: bool = False, return_logits: bool = False, **_):
+                      audio_feature_lengths=None, output_hidden_states: bool = False, return_logits: bool = False, decode: bool = True, **_):
         """Would `generate(**inputs)` capture a hipGraph -- a tower graph for these grid_thw VALUES / audio lengths, or the decode step
         for this row count and KV cache set? Answered from the engines' own caches, so evictions and resets count. A pass that
         captures must not run beside another host thread that enqueues or allocates (SpiderFreeInfer runs it alone)."""
@@ -690,6 +690,8 @@ class QwenOmniThinker:
         B = int(input_ids.shape[0])
         if B > 8:          # grouped generate inside prefill_begin: graphs per group size
             return True
+        if not decode:     # the prompt pass alone (SpiderFreeInfer depth 3): only the towers capture
+            return False
         return self.llm.would_capture(B, output_hidden_states, return_logits, cache_set)
 
     @torch.no_grad()

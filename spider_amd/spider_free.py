@@ -91,6 +91,7 @@ class SpiderFreeInfer:
         self._warm = set()               # LLM-pass geometries that have run (and captured their hipGraphs) on one thread already
         self._last_dec = None            # geometry of the most recent decoder pass (the one the decoders' graphs are captured for)
         self.last_pass_ms: Dict[str, float] = {}
+        self.host_ms: Dict[str, float] = {}     # host wall time of the pieces of the most recent passes (written by the passes' own threads)
 
     # ------------------------------------------------------------------ request -> processor output (:461-466)
     def build_inputs(self, messages) -> dict:
@@ -140,12 +141,18 @@ class SpiderFreeInfer:
     def llm_pass(self, inputs: dict):
         """`model.generate(**inputs)` + `batch_decode` + the last-line rule, on the CURRENT stream; ends with the one device->host copy
         of the generated ids. -> (text_ids [B, S + new] on the host, one response line per row, the request's input images)."""
+        import time
         inputs = dict(inputs)
         images = inputs.pop("_images", None)
+        t0 = time.perf_counter()
         with ops.workspace_scope("llm"):
             text_ids = self.model.generate(**inputs, **self.generate_kwargs)
         text_ids = text_ids.cpu()
+        t1 = time.perf_counter()
         resp = self.processor.batch_decode(text_ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        # host wall time of the two halves of the pass (generate ends with the device -> host copy of the ids): read by bench.py
+        self.host_ms["llm_generate_host_ms"] = round((t1 - t0) * 1e3, 2)
+        self.host_ms["llm_batch_decode_host_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
         return text_ids, [r.split("\n")[-1] for r in resp], images
 
     def prefill_pass(self, inputs: dict, cache_set: int):
@@ -174,6 +181,8 @@ class SpiderFreeInfer:
 
     def decoder_pass(self, text_ids, responses: List[str], images=None) -> List[SpiderFreeResult]:
         """`ask_info` -> Decoders-Controller for every row of the request (qwen2.5omni_spider_web.py:489-520)."""
+        import time
+        t_dec0 = time.perf_counter()
         if self.mode == "spider_story_free_qwen":
             return [self._story_result(r, text_ids[i]) for i, r in enumerate(responses)]
         asks = []
@@ -193,6 +202,7 @@ class SpiderFreeInfer:
             triples = [self.spider_decoder_infer(asks[0])]
         else:
             triples = self.spider_decoder_infer.spider_decoder.generate_batch(asks)
+        self.host_ms["decoder_pass_host_ms"] = round((time.perf_counter() - t_dec0) * 1e3, 2)
         return [SpiderFreeResult(r, a, p, pt, text_ids[i]) for i, (r, (a, p, pt)) in enumerate(zip(responses, triples))]
 
     def _story_result(self, response: str, ids) -> SpiderFreeResult:
@@ -235,7 +245,7 @@ class SpiderFreeInfer:
                              if isinstance(v, torch.Tensor) and k not in ("input_ids", "attention_mask")))
         return (int(ids.shape[0]), extra)
 
-    def _llm_cold(self, inputs: dict, lkey, cache_set: int = 0) -> bool:
+    def _llm_cold(self, inputs: dict, lkey, cache_set: int = 0, decode: bool = True) -> bool:
         """would this LLM pass capture a hipGraph (tower per grid_thw / audio lengths, decode step per row count) -- i.e. must it run
         alone? The engines answer from their own caches (values, evictions and resets included); a thinker without `would_capture`
         falls back to the shapes seen before."""
@@ -243,7 +253,7 @@ class SpiderFreeInfer:
         if wc is None:
             return lkey not in self._warm
         kw = {k: v for k, v in inputs.items() if not k.startswith("_")}
-        return bool(wc(cache_set=cache_set, **kw))
+        return bool(wc(cache_set=cache_set, decode=decode, **kw))
 
     def _dec_key(self, pending):
         if self.mode == "spider_story_free_qwen":
@@ -257,8 +267,19 @@ class SpiderFreeInfer:
         if self._prefilled is not None:
             raise RuntimeError("a prefilled request is in flight (depth-3 pipelining): flush() before calling predict()")
         inputs = self._inputs_of(messages, inputs)
+        gpu = self.device.type == "cuda"
+        if gpu:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         pending = self.llm_pass(inputs)
+        if gpu:
+            ev[1].record()
         out = self.decoder_pass(*pending)
+        if gpu:
+            ev[2].record()
+            ev[2].synchronize()
+            self.last_pass_ms = {"llm_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "decoder_pass_ms": round(ev[1].elapsed_time(ev[2]), 1),
+                                 "overlapped": False}
         self._warm.add(("llm", self._llm_key(inputs)))
         self._last_dec = self._dec_key(pending)
         return self._unbatch(out)
@@ -370,7 +391,8 @@ class SpiderFreeInfer:
             return None
         dgk = ("dg", pre[4], 0) if pre is not None else None           # decode graph of (rows, cache set 0)
         dkey = self._dec_key(pend) if pend is not None else None
-        warm = (pre is not None and pend is not None and not self._llm_cold(inputs, lkey, cset) and dgk in self._warm and
+        # (the new request's PROMPT pass captures tower graphs at most: decode loops always run from set 0, whose graph `dgk` names)
+        warm = (pre is not None and pend is not None and not self._llm_cold(inputs, lkey, cset, decode=False) and dgk in self._warm and
                 dkey == self._last_dec and self.mode != "spider_story_free_qwen")
         if not warm:                                 # some graph of this step does not exist yet: one pass after the other, one thread
             out = None

@@ -279,7 +279,7 @@ def test_overlap_decision_comes_from_the_engines_not_from_shapes():
     infer, pipe, thinker = make()
     infer.processor.prompt_len = 4
     cold = {"v": True}
-    thinker.would_capture = lambda cache_set=0, **kw: cold["v"]
+    thinker.would_capture = lambda cache_set=0, decode=True, **kw: cold["v"]
     threads = []
     orig = thinker.generate
     thinker.generate = lambda *a, **k: (threads.append(threading.current_thread().name), orig(*a, **k))[1]
