@@ -307,6 +307,8 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  *   spider_gemm_a32_*, spider_conv_nhwc_a32_*, spider_gemm_gn_in_a32_*: A (or the NHWC image) is fp32 and is split, on its way into
  *       LDS, into hi = round16(x) and lo = round16(x - hi); every K step runs two MFMAs (W.hi + W.lo). Otherwise the contracts of
  *       spider_gemm_* (no activation / GEGLU), spider_conv_nhwc_ex_* (no activation; w_tiled 0 / 1) and spider_gemm_gn_in_*.
+ *   spider_gemm_ln_a32_*: LayerNorm(A32) . W^T (+ GEGLU) on the fp32 rows with gamma applied to A and W kept exact (spider_gemm_ln's
+ *       fold re-rounds W * gamma); colsum[n] = sum_k gamma[k] W[n,k], colbias[n] = sum_k beta[k] W[n,k] + bias[n], both fp32.
  *   spider_groupnorm_f32in_nhwc_*: GroupNorm (+ SiLU) of the fp32 tensor x32 [B, HW, C]; statistics from `partial` [B, nchunk, G, 2]
  *       or (partial NULL) from a pass over x32 into ws (>= B * spider_groupnorm_nchunk(HW) * G * 2 floats); the result is rounded ONCE
  *       into y (16-bit, optional) and / or stored unrounded into y32 (optional).
@@ -314,6 +316,8 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  *       its output) and conv_out on the fp32 GroupNorm + SiLU output.  spider_latent_to_nhwc_f32: fp32 NCHW latents -> fp32 NHWC. */
 int spider_gemm_a32_bf16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
                          int ldc, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
+int spider_gemm_ln_a32_bf16(const float* A32, const void* W, void* C, const void* gamma, const float* colsum, const float* colbias,
+                            int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* stream);
 int spider_gemm_gn_in_a32_bf16(const float* A32, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
                                const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
                                float* c32d, void* stream);
@@ -402,6 +406,8 @@ int spider_softmax_rows_f32_f16(const float* x, void* y, int rows, int n, int n_
 
 int spider_gemm_a32_f16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
                          int ldc, float out_scale, int w_tiled, const float* res32, float* c32d, void* ws, long ws_bytes, void* stream);
+int spider_gemm_ln_a32_f16(const float* A32, const void* W, void* C, const void* gamma, const float* colsum, const float* colbias,
+                            int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* stream);
 int spider_gemm_gn_in_a32_f16(const float* A32, const void* W, void* C, const void* bias, int M, int N, int K, int ldc, int w_tiled,
                                const float* gn_part, int nchunk, const void* gamma, const void* beta, int G, float eps, int HW,
                                float* c32d, void* stream);

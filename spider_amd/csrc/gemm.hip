@@ -745,9 +745,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < AC; ++i) ra[i] = ra_[i];
         if (A32) {
-            // fp32 operand: (GroupNorm on A first, in fp32,) then hi = round16(x), lo = round16(x - hi)
+            // fp32 operand: (GroupNorm on A first, in fp32; or, LN form, the LayerNorm weight gamma_k applied to A so that W stays the
+            // exact un-folded weight) then hi = round16(x), lo = round16(x - hi)
             float ca[8], cb[8];
-            if (GNA) {
+            if (GNA || LN) {
                 int k0 = kt_ * BK + chunk * 8;
                 k0 = k0 + 8 <= p.K ? k0 : p.K - 8;
 #pragma unroll
@@ -758,7 +759,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 float x[8];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) { x[d] = __uint_as_float(ra_[i][d]); x[4 + d] = __uint_as_float(ra2_[A32 ? i : 0][d]); }
-                if (GNA) {
+                if (LN) {       // row statistics of the RAW fp32 values (every K tile passes here exactly once; masked tiles are zeros)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { ln_s[i] += x[j]; ln_q[i] = fmaf(x[j], x[j], ln_q[i]); }
+                }
+                if (GNA || LN) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], ca[j], cb[j]);
                 }
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                 ra[i] = u32x4{w4[0], w4[1], w4[2], w4[3]};
             }
         }
-        if (LN) {   // every K tile passes through here exactly once (masked tiles are zeros)
+        if (LN && !A32) {   // every K tile passes through here exactly once (masked tiles are zeros)
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
 #pragma unroll
@@ -852,6 +857,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     u32x4 a0b[A32 ? AC : 1], a1b[A32 ? AC : 1];
     load_tile(kt0, a0, w0, a0b);
     load_tile(kt0 + 1, a1, w1, a1b);
+    if (LN && A32) {      // gamma table of the LayerNorm applied on the A side: (gamma_k, 0)
+        for (int c = tid; c < p.K; c += 256) gna_tab[c] = float2{h16_to_f32(p.gna_gamma[c]), 0.f};
+        __syncthreads();
+    }
     // (GNA: the statistics prologue runs with the first two K tiles already in flight)
     if (GNA) {
         float* g_mean = reinterpret_cast<float*>(gna_tab + p.K);          // [G], [G] behind the table
@@ -2110,9 +2119,18 @@ void launch_tile(const GemmArgs& a, int tiles, hipStream_t st) {
     // epilogue instantiation: 2 GEGLU, 0/1 branch-free bf16 (without / with activation), 3 general (see epilogue_store)
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = a.geglu ? 2 : (!fast_ok ? 3 : (a.act ? 1 : 0));
-    if (a.a32) {           // fp32 A operand, hi / lo split (host-checked: epilogue 0, no LayerNorm fold)
-        static unsigned done_a = 0, done_b = 0, done_c = 0;
-        if (a.gna_part) {
+    if (a.a32) {           // fp32 A operand, hi / lo split (host-checked: epilogue 0 / GEGLU of the LN form)
+        static unsigned done_a = 0, done_b = 0, done_c = 0, done_d = 0, done_e = 0;
+        if (a.ln_colsum) {      // LayerNorm on the fp32 A operand, gamma applied to A (table behind the tiles), exact W
+            const size_t extra = (size_t)a.K * sizeof(float2);
+            if (a.geglu) {
+                raise_dynamic_lds(&gemm_kernel<BM, BN, false, 2, true, false, true>, (int)(smem + extra), done_d);
+                gemm_kernel<BM, BN, false, 2, true, false, true><<<grid, 256, smem + extra, st>>>(a);
+            } else {
+                raise_dynamic_lds(&gemm_kernel<BM, BN, false, 0, true, false, true>, (int)(smem + extra), done_e);
+                gemm_kernel<BM, BN, false, 0, true, false, true><<<grid, 256, smem + extra, st>>>(a);
+            }
+        } else if (a.gna_part) {
             if constexpr (BM == 64 && BN == 64) {
                 const size_t extra = (size_t)a.K * sizeof(float2) + (size_t)2 * a.gna_G * sizeof(float) + 2 * 256 * sizeof(float);
                 raise_dynamic_lds(&gemm_kernel<64, 64, false, 0, false, true, true>, (int)(smem + extra), done_c);
@@ -2733,6 +2751,36 @@ int SPIDER_FN(spider_gemm_a32)(const float* A32, const void* W, void* C, const v
     set_epilogue_ranges(a);
     SPIDER_CHECK(a.c_bytes != 0, "gemm_a32: output must be < 2 GiB");
     return launch(a, ws ? ws_bytes : 0, stream);
+}
+
+// LayerNorm(A32; gamma, beta, eps) . W^T + bias (+ its GEGLU form, act 4 / 9) on the FP32 rows A32 [M, K] (the master of the token
+// stream): the kernel takes the row statistics from the fp32 values, applies gamma to A (fp32) before the hi / lo split and keeps
+// W EXACT -- spider_gemm_ln's fold re-rounds W * gamma to 16 bits, the largest single error site of the SDXL evaluation
+// (scripts/exp/precision_sites.py: 24 % of the variance). colsum[n] = sum_k gamma[k] W[n,k] (fp32, of the unrounded products),
+// colbias[n] = sum_k beta[k] W[n,k] + bias[n], prepared once per layer by the caller (ops.fold_layernorm_exact).
+int SPIDER_FN(spider_gemm_ln_a32)(const float* A32, const void* W, void* C, const void* gamma, const float* colsum, const float* colbias,
+                            int M, int N, int K, int ldc, int act, float eps, int w_tiled, void* stream) {
+    SPIDER_CHECK(M > 0 && N > 0 && K > 0 && K % 8 == 0, "gemm_ln_a32: K must be a multiple of 8");
+    SPIDER_CHECK(act == 0 || act == 4 || act == 9, "gemm_ln_a32: plain or GEGLU (4, 9 = rounded once) epilogue");
+    SPIDER_CHECK(A32 && W && C && gamma && colsum && colbias, "gemm_ln_a32: A32, W, C, gamma, colsum and colbias are required");
+    SPIDER_CHECK(act == 0 || N % 2 == 0, "gemm_ln_a32: GEGLU needs even N");
+    GemmArgs a{};
+    a.a32 = 1;
+    a.A = (const h16_t*)A32; a.W = (const h16_t*)W; a.C = (h16_t*)C;
+    a.M = M; a.K = K; a.lda = K; a.ldc = ldc;
+    a.geglu = act == 4 ? 1 : (act == 9 ? 3 : 0);
+    a.N = a.geglu ? N / 2 : N;
+    SPIDER_CHECK(a.N % 4 == 0 && ldc % 4 == 0 && ldc >= a.N, "gemm_ln_a32: output width and ldc must be multiples of 4, ldc >= width");
+    a.out_scale = 1.f;
+    a.ln_colsum = colsum; a.ln_bias = colbias; a.ln_eps = eps; a.gna_gamma = (const h16_t*)gamma;
+    SPIDER_CHECK((size_t)M * K * 4 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32) && (size_t)M * ldc * 2 < ((size_t)1 << 31),
+                 "gemm_ln_a32: operands must be < 2 GiB");
+    SPIDER_CHECK(K <= 8192, "gemm_ln_a32: K <= 8192 (gamma table in LDS)");
+    a.a_bytes = (uint32_t)((size_t)M * K * 4);
+    a.w_tiled = w_tiled ? 1 : 0;
+    a.w_bytes = w_tiled ? tiled_bytes(N, K) : (uint32_t)((size_t)N * K * 2);
+    set_epilogue_ranges(a);
+    return launch(a, 0, stream);
 }
 
 // GroupNorm(A) . W^T + bias as spider_gemm_gn_in, with A the FP32 tensor: normalised in fp32, then split hi / lo.

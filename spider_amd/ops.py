@@ -758,6 +758,34 @@ def gemm_a32(A32, W, bias=None, res=None, out_scale=1.0, res32=None, want32=Fals
     return (out, o32) if want32 else out
 
 
+def fold_layernorm_exact(W, gamma, beta, bias=None):
+    """parameters of gemm_ln_a32 (once per layer): (W itself, gamma, colsum = sum_k gamma_k W[n,k] in fp32, colbias = W @ beta + bias)"""
+    W32 = W.float()
+    colsum = (W32 * gamma.float()[None, :]).sum(1).contiguous()
+    colbias = W32 @ beta.float()
+    if bias is not None:
+        colbias = colbias + bias.float()
+    return W, gamma.to(W.dtype).contiguous(), colsum, colbias.contiguous()
+
+
+def gemm_ln_a32(A32, W, gamma, colsum, colbias, act=None, eps=1e-5):
+    """LayerNorm(A32) @ W^T + bias (+ GEGLU) on the fp32 rows A32 [..., K]: statistics in fp32, gamma applied to A before the hi / lo
+    split, W exact (no re-rounded W * gamma). (W, gamma, colsum, colbias) = fold_layernorm_exact(W, gamma, beta, bias)."""
+    dt, sfx = _h16(W)
+    _chk(A32, torch.float32, "A32"); _chk(W, dt, "W"); _chk(gamma, dt, "gamma")
+    _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
+    N, K = W.shape
+    assert A32.shape[-1] == K and colsum.numel() == N and colbias.numel() == N and gamma.numel() == K
+    assert act in (None, "geglu", "geglu_exact")
+    M = A32.numel() // K
+    n_out = N // 2 if act in GLU_ACTS else N
+    out = torch.empty(*A32.shape[:-1], n_out, dtype=dt, device=A32.device)
+    wt = _tiled(W, M)
+    _lib.call(f"spider_gemm_ln_a32_{sfx}", _p(A32), _p(W if wt is None else wt), _p(out), _p(gamma), _p(colsum), _p(colbias), M, N, K, n_out,
+              ACT[act], float(eps), int(wt is not None), _stream())
+    return out
+
+
 def gemm_gn_in_a32(A32, W, part: "GnPartial", gamma, beta, HW: int, eps: float, bias=None, want32=False):
     """GroupNorm(A32) @ W^T + bias with A32 [B, HW, K] fp32, normalised in fp32 inside the GEMM and split hi / lo"""
     dt, sfx = _h16(W)

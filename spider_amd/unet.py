@@ -130,6 +130,10 @@ class UNetEngine:
         (scripts/exp/precision_sites.py) charges with ~75 % of the error variance of one evaluation; their cost is on small / latency-
         bound launches (DESIGN.md section 4 for the measured ms and rel-L2)."""
         assert dtype in (torch.bfloat16, torch.float16), "UNetEngine: dtype must be bfloat16 or float16"
+        # precise = 2: additionally the three LayerNorm-consuming projections of every BasicTransformerBlock (q/k/v, to_q, GEGLU) read
+        # the fp32 token stream with gamma applied on the A side and the EXACT weight (ops.gemm_ln_a32) -- the re-rounded W * gamma of
+        # the folded form is the largest error site of the transformer-heavy models (SDXL: 24 % of the variance)
+        self.precise_ln = int(precise) >= 2
         self.precise = bool(precise)
         stream32 = bool(stream32) or self.precise
         self.cfg, self.device, self.dtype, self.stream32 = cfg, torch.device(device), dtype, bool(stream32)
@@ -164,6 +168,15 @@ class UNetEngine:
             self.ln[b + ".attn2"] = ops.fold_layernorm(w2, W[b + ".norm2.weight"], W[b + ".norm2.bias"])
             self.ln[b + ".ff"] = ops.fold_layernorm(W[b + ".ff.net.0.proj.weight"], W[b + ".norm3.weight"], W[b + ".norm3.bias"],
                                                     W[b + ".ff.net.0.proj.bias"])
+        self.lnx: Dict[str, tuple] = {}
+        if self.precise_ln:
+            for b in [k[:-len(".attn1")] for k in self.ln if k.endswith(".attn1")]:
+                W = self.w
+                self.lnx[b + ".attn1"] = ops.fold_layernorm_exact(W[b + ".attn1.qkv"], W[b + ".norm1.weight"], W[b + ".norm1.bias"])
+                w2 = W[b + ".attn2.qkv"] if b + ".attn2.qkv" in W else W[b + ".attn2.to_q.weight"]
+                self.lnx[b + ".attn2"] = ops.fold_layernorm_exact(w2, W[b + ".norm2.weight"], W[b + ".norm2.bias"])
+                self.lnx[b + ".ff"] = ops.fold_layernorm_exact(W[b + ".ff.net.0.proj.weight"], W[b + ".norm3.weight"], W[b + ".norm3.bias"],
+                                                               W[b + ".ff.net.0.proj.bias"])
         # Fused cross-attention sub-block (ops.xattn_fused): weight-only halves of the per-prompt fold (prepare() finishes it
         # with the prompt's K / V): WqT_g[c, j] = gamma2[c] * Wq[j, c] and wqb[j] = sum_c Wq[j, c] * beta2[c].
         self.fuse_xattn = os.environ.get("SPIDER_XATTN_FUSE", "1") != "0"
@@ -253,7 +266,7 @@ class UNetEngine:
                 t = torch.randn(shp, generator=gen, device=device) * (1.0 / math.sqrt(math.prod(shp[1:])))
             w[n] = t.to(torch.bfloat16)     # same values for either engine dtype (bf16-representable, exact in f16 too)
         if precise:
-            return cls(cfg, w, device, dtype=dtype, precise=True)
+            return cls(cfg, w, device, dtype=dtype, precise=precise)
         return cls(cfg, w, device, dtype=dtype, stream32=stream32) if stream32 else cls(cfg, w, device, dtype=dtype)
 
     @classmethod
@@ -262,7 +275,7 @@ class UNetEngine:
         from .checkpoint import load_state_dict, read_config
         cfg = UNetConfig.from_diffusers_dict(read_config(path))
         if precise:
-            return cls(cfg, load_state_dict(path), device, dtype=dtype, precise=True)
+            return cls(cfg, load_state_dict(path), device, dtype=dtype, precise=precise)
         return cls(cfg, load_state_dict(path), device, dtype=dtype, stream32=stream32)
 
     # ------------------------------------------------------------------ per-call preparation
@@ -448,9 +461,15 @@ class UNetEngine:
         qkv = ops.gemm(y, self.w[b + ".attn1.qkv"])
         return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
 
-    def _proj2(self, b, y, ln_input: bool):
+    def _proj2(self, b, y, ln_input: bool, y32=None):
         """attn2's projection of the block input: y is the norm2 output (ln_input=False) or the un-normalised residual stream
-        (ln_input=True: norm2 folded into the GEMM)."""
+        (ln_input=True: norm2 folded into the GEMM). y32 (precise = 2): the stream's fp32 master, exact-weight form."""
+        if ln_input and y32 is not None and (b + ".attn2") in self.lnx:
+            W_, g_, cs, cb = self.lnx[b + ".attn2"]
+            C = y.shape[-1]
+            if not self.self_cross and W_.shape[0] != C:
+                W_, cs, cb = W_[:C], cs[:C], cb[:C]
+            return ops.gemm_ln_a32(y32, W_, g_, cs, cb)
         if ln_input:
             Wf, cs, cb = self.ln[b + ".attn2"]
             C = y.shape[-1]
@@ -459,14 +478,14 @@ class UNetEngine:
             return ops.gemm_ln(y, Wf, cs, cb)
         return ops.gemm(y, self.w[b + (".attn2.qkv" if self.self_cross else ".attn2.to_q.weight")])
 
-    def _cross_attn(self, b, y, heads, ln_input: bool = False):
+    def _cross_attn(self, b, y, heads, ln_input: bool = False, y32=None):
         """attn2 of a BasicTransformerBlock: K/V of the text tokens were projected in prepare(); with
         encoder_hidden_states=None (AudioLDM) it is a second self-attention."""
         C = y.shape[-1]
         if self.self_cross:
-            qkv = self._proj2(b, y, ln_input)
+            qkv = self._proj2(b, y, ln_input, y32)
             return ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
-        q = self._proj2(b, y, ln_input)
+        q = self._proj2(b, y, ln_input, y32)
         kv = self.kv[b]
         return ops.attention(q, kv[..., :C], kv[..., C:], heads)
 
@@ -508,13 +527,16 @@ class UNetEngine:
             if self.self_attn_hook is not None and self.self_attn_hook.wants(b + ".attn1"):
                 y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
                 o = self.self_attn_hook(self, b + ".attn1", y, heads)
+            elif fuse and self.precise_ln:      # the fp32 token stream, exact weight
+                qkv = ops.gemm_ln_a32(h32, *self.lnx[b + ".attn1"])
+                o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
             elif fuse:     # norm1 + q/k/v projection: one launch
                 qkv = ops.gemm_ln(h, *self.ln[b + ".attn1"])
                 o = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
             else:
                 o = self._self_attn(b, ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"]), heads)
             h, h32 = rg(o, w[b + ".attn1.to_out.0.weight"], w[b + ".attn1.to_out.0.bias"], h, h32)
-            xf = self.xf.get(b) if fuse else None
+            xf = self.xf.get(b) if (fuse and not self.precise_ln) else None     # (precise = 2: to_q reads the fp32 stream instead)
             # Fused where it wins (measured, scripts/bench_xattn.py: 17 vs 31 us at 2 x 4096 tokens / C = 320, 22 vs 29 us at
             # 2 x 1024 / 640): with fewer than ~64 row tiles (the 16^2 / 8^2 maps at C = 1280: 46 vs 34 us, 36 vs 29 us) one block's
             # serial chain of 20 + 20 dependent operand loads is longer than the three launches it replaces, which spread over the chip.
@@ -526,11 +548,13 @@ class UNetEngine:
                     h = ops.xattn_fused(h, xf["mq_fm"], xf["mo_fm"], xf["cs"], xf["cb"], w[b + ".attn2.to_out.0.bias"], B, heads, self._enc_len)
             else:
                 if fuse:
-                    o = self._cross_attn(b, h, heads, ln_input=True)
+                    o = self._cross_attn(b, h, heads, ln_input=True, y32=h32 if self.precise_ln else None)
                 else:
                     o = self._cross_attn(b, ops.layernorm(h, w[b + ".norm2.weight"], w[b + ".norm2.bias"]), heads)
                 h, h32 = rg(o, w[b + ".attn2.to_out.0.weight"], w[b + ".attn2.to_out.0.bias"], h, h32)
-            if fuse:       # norm3 + GEGLU projection: one launch
+            if fuse and self.precise_ln:
+                g = ops.gemm_ln_a32(h32, *self.lnx[b + ".ff"], act=geglu)
+            elif fuse:       # norm3 + GEGLU projection: one launch
                 g = ops.gemm_ln(h, *self.ln[b + ".ff"], act=geglu)
             else:
                 y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])

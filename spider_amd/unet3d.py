@@ -213,13 +213,17 @@ class UNet3DEngine(UNetEngine):
         inner = h.shape[-1]
         b = n + ".transformer_blocks.0"
         for at, nm in (("attn1", "norm1"), ("attn2", "norm2")):     # double_self_attention: both attend over the frames
-            if self.fuse_ln:   # norm + q/k/v projection in one launch (LayerNorm folded, see UNetEngine.__init__)
+            if self.fuse_ln and self.precise_ln:
+                qkv = ops.gemm_ln_a32(h32, *self.lnx[f"{b}.{at}"])
+            elif self.fuse_ln:   # norm + q/k/v projection in one launch (LayerNorm folded, see UNetEngine.__init__)
                 qkv = ops.gemm_ln(h, *self.ln[f"{b}.{at}"])
             else:
                 qkv = ops.gemm(ops.layernorm(h, w[f"{b}.{nm}.weight"], w[f"{b}.{nm}.bias"]), w[f"{b}.{at}.qkv"])
             o = self._frame_attention(qkv, inner, heads, B, HW)
             h, h32 = rg(o, w[f"{b}.{at}.to_out.0.weight"], w[f"{b}.{at}.to_out.0.bias"], h, h32)
-        if self.fuse_ln:
+        if self.fuse_ln and self.precise_ln:
+            g = ops.gemm_ln_a32(h32, *self.lnx[b + ".ff"], act=geglu)
+        elif self.fuse_ln:
             g = ops.gemm_ln(h, *self.ln[b + ".ff"], act=geglu)
         else:
             y = ops.layernorm(h, w[b + ".norm3.weight"], w[b + ".norm3.bias"])
@@ -241,11 +245,11 @@ class UNet3DEngine(UNetEngine):
         out = ops.gemm(h, w[n + ".proj_out.weight"], bias=w[n + ".proj_out.bias"], res=x.view(BF * HW, C))
         return out.view(BF, H, W_, C)
 
-    def _cross_attn(self, b, y, heads, ln_input: bool = False):
+    def _cross_attn(self, b, y, heads, ln_input: bool = False, y32=None):
         """y [B2*F, HW, C]: the F frames of a sample share its text K/V, so they form one query sequence of F*HW rows."""
         C = y.shape[-1]
         B2 = self.B2
-        q = self._proj2(b, y, ln_input).view(B2, -1, C)
+        q = self._proj2(b, y, ln_input, y32).view(B2, -1, C)
         kv = self.kv[b]
         return ops.attention(q, kv[..., :C], kv[..., C:], heads).view(y.shape)
 
