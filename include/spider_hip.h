@@ -312,6 +312,8 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  *   spider_groupnorm_f32in_nhwc_*: GroupNorm (+ SiLU) of the fp32 tensor x32 [B, HW, C]; statistics from `partial` [B, nchunk, G, 2]
  *       or (partial NULL) from a pass over x32 into ws (>= B * spider_groupnorm_nchunk(HW) * G * 2 floats); the result is rounded ONCE
  *       into y (16-bit, optional) and / or stored unrounded into y32 (optional).
+ *   spider_split_hilo_f32_*: the operand split as a pass of its own (hi = round16(x), lo = round16(x - hi)) for convs large enough to run
+ *       on the LDS-DMA / 256^2 kernels twice: conv(hi) (c32d out), then conv(lo) with res32 = that result -- the same fp32 sum.
  *   spider_conv2d_small_cin_f32in_* / spider_conv2d_small_cout_f32in_*: conv_in on the fp32 NHWC latents (y32: optional fp32 master of
  *       its output) and conv_out on the fp32 GroupNorm + SiLU output.  spider_latent_to_nhwc_f32: fp32 NCHW latents -> fp32 NHWC. */
 int spider_gemm_a32_bf16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
@@ -327,6 +329,7 @@ int spider_conv_nhwc_a32_bf16(const float* x32, const void* w, void* y, const vo
                               void* stream);
 int spider_groupnorm_f32in_nhwc_bf16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
                                      float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_split_hilo_f32_bf16(const float* x, void* hi, void* lo, long n, void* stream);
 int spider_conv2d_small_cin_f32in_bf16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
                                        int Cin, int Cout, int ks, void* stream);
 int spider_conv2d_small_cout_f32in_bf16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,
@@ -417,6 +420,7 @@ int spider_conv_nhwc_a32_f16(const float* x32, const void* w, void* y, const voi
                               void* stream);
 int spider_groupnorm_f32in_nhwc_f16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
                                      float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
+int spider_split_hilo_f32_f16(const float* x, void* hi, void* lo, long n, void* stream);
 int spider_conv2d_small_cin_f32in_f16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
                                        int Cin, int Cout, int ks, void* stream);
 int spider_conv2d_small_cout_f32in_f16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,

@@ -233,11 +233,109 @@ def case_llm(r, g):
     return desc, e, why, bf
 
 
+def case_wstream(r, g):
+    """round 5: the weight-stationary streaming conv (marked 3 x 3 weight, <= 512 output pixels) with the resnet epilogue operands"""
+    dt = r.choice(DTS)
+    B = r.choice([1, 2, 2, 3, 4])
+    H, W = r.choice([2, 3, 4, 5, 7, 8, 8, 11, 16]), r.choice([2, 3, 4, 6, 8, 8, 9, 16])
+    up = r.random() < 0.25
+    Ho, Wo = (2 * H - r.choice([0, 1]), 2 * W - r.choice([0, 1])) if up else (H, W)
+    if B * Ho * Wo > 512 or B * H * W > (128 if B * Ho * Wo <= 128 else 512) or (up and B * Ho * Wo <= 128):
+        return None
+    Cin, Cout = r.choice([32, 64, 96, 160, 320, 640, 1280]), r.choice([4, 8, 32, 36, 64, 80, 320, 1280])
+    x, w = rnd(g, B, H, W, Cin, dt=dt), rnd(g, Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5, dt=dt)
+    b, rb = rnd(g, Cout, dt=dt), rnd(g, B, Cout, dt=dt)
+    s32 = r.random() < 0.5
+    r32 = torch.randn(B, Ho, Wo, Cout, generator=g) if s32 else None
+    res = rnd(g, B, Ho, Wo, Cout, dt=dt) if (not s32 and r.random() < 0.5) else None
+    old = ops.WS_MAX_M
+    ops.WS_MAX_M = 512
+    try:
+        wm = ops.mark_weight(w.to(dev))
+        out = ops.conv_ex(x.to(dev), wm, bias=b.to(dev), rowbias=rb.to(dev), pad=(1, 1), up_size=(Ho, Wo) if up else None,
+                          res=None if res is None else res.to(dev), res32=None if r32 is None else r32.to(dev), want32=s32)
+    finally:
+        ops.WS_MAX_M = old
+    desc = f"wstream dt={dt} B={B} {H}x{W}->{Ho}x{Wo} Cin={Cin} Cout={Cout} s32={s32} res={res is not None}"
+    if getattr(wm, "_spider_fm", None) is None:
+        return desc, float("inf"), "the streaming kernel's weight copy was not built (wrong path)", dt
+    xi = x.float().permute(0, 3, 1, 2)
+    if up:
+        xi = F.interpolate(xi, size=(Ho, Wo), mode="nearest")
+    ref = F.conv2d(xi, w.float().permute(0, 3, 1, 2), b.float(), padding=1).permute(0, 2, 3, 1) + rb.float()[:, None, None, :]
+    if res is not None:
+        ref = ref.to(dt).float() + res.float()
+    if s32:
+        ref = ref + r32
+        e, why = err(out[0], ref)
+        e2, why2 = err(out[1], ref)
+        return desc, max(e, 100 * e2), why or why2, dt            # the fp32 master: accumulation error only
+    e, why = err(out, ref)
+    return desc, e, why, dt
+
+
+def case_a32(r, g):
+    """round 5: the fp32-operand (hi / lo split) forms -- gemm_a32, gemm_ln_a32 (+ GEGLU), conv_a32, groupnorm_f32in. The fp32 output
+    must sit at fp32-accumulation distance from the reference although W is 16-bit: the A operand carries ~22 bits."""
+    dt = r.choice(DTS)
+    kind = r.choice(["gemm", "ln", "ln_geglu", "conv", "gn"])
+    if kind == "gn":
+        B, HW, C = r.choice([1, 2, 3]), r.choice([16, 60, 64, 256, 1000, 4096]), r.choice([32, 64, 320, 640, 1280])
+        x = torch.randn(B, HW, C, generator=g) * 2 + 0.5
+        ga, be = rnd(g, C, dt=dt) * 0.1 + 1, rnd(g, C, dt=dt) * 0.1
+        silu = r.random() < 0.5
+        y, y32 = ops.groupnorm_f32in(x.to(dev), ga.to(dev), be.to(dev), 32, 1e-5, silu, want16=True, want32=True)
+        ref = F.group_norm(x.transpose(1, 2), 32, ga.float(), be.float(), 1e-5).transpose(1, 2)
+        ref = F.silu(ref) if silu else ref
+        e, why = err(y, ref)
+        e2, why2 = err(y32, ref)
+        return f"a32 groupnorm dt={dt} B={B} HW={HW} C={C} silu={silu}", max(e, 100 * e2), why or why2, dt
+    if kind == "conv":
+        B, H, W = r.choice([1, 2]), r.choice([4, 8, 9, 16, 32]), r.choice([4, 8, 11, 16, 32])
+        Cin, Cout, ks, stride = r.choice([8, 64, 320, 640]), r.choice([8, 64, 320]), r.choice([1, 3]), r.choice([1, 1, 2])
+        up = (2 * H, 2 * W) if (ks == 3 and stride == 1 and r.random() < 0.3) else None
+        x = torch.randn(B, H, W, Cin, generator=g)
+        w, b = rnd(g, Cout, ks, ks, Cin, scale=(ks * ks * Cin) ** -0.5, dt=dt), rnd(g, Cout, dt=dt)
+        y, y32 = ops.conv_a32(x.to(dev), w.to(dev), bias=b.to(dev), stride=stride, pad=(ks // 2, ks // 2), up_size=up, want32=True)
+        xi = x.permute(0, 3, 1, 2)
+        if up:
+            xi = F.interpolate(xi, size=up, mode="nearest")
+        ref = F.conv2d(xi, w.float().permute(0, 3, 1, 2), b.float(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
+        e, why = err(y, ref)
+        e2, why2 = err(y32, ref)
+        return f"a32 conv dt={dt} B={B} {H}x{W} Cin={Cin} Cout={Cout} ks={ks} s={stride} up={up}", max(e, 30 * e2), why or why2, dt
+    M, N, K = r.choice([16, 64, 100, 512, 2048, 8192]), r.choice([8, 64, 320, 640, 1280, 2560]), r.choice([64, 320, 640, 1280])
+    A = torch.randn(M, K, generator=g) * 1.5 + r.choice([0.0, 2.0])
+    W = rnd(g, N, K, scale=K ** -0.5, dt=dt)
+    b = rnd(g, N, dt=dt)
+    if kind == "gemm":
+        r32 = torch.randn(M, N, generator=g)
+        y, y32 = ops.gemm_a32(A.to(dev), W.to(dev), bias=b.to(dev), res32=r32.to(dev), want32=True)
+        ref = A @ W.float().T + b.float() + r32
+        e, why = err(y, ref)
+        e2, why2 = err(y32, ref)
+        return f"a32 gemm dt={dt} M={M} N={N} K={K}", max(e, 30 * e2), why or why2, dt
+    ga, be = rnd(g, K, dt=dt) * 0.1 + 1, rnd(g, K, dt=dt) * 0.1
+    geglu = kind == "ln_geglu"
+    if geglu and N % 8:
+        return None
+    fold = ops.fold_layernorm_exact(W.to(dev), ga.to(dev), be.to(dev), b.to(dev))
+    y = ops.gemm_ln_a32(A.to(dev), *fold, act="geglu_exact" if geglu else None)
+    ref = F.layer_norm(A, (K,), ga.float(), be.float(), 1e-5) @ W.float().T + b.float()
+    if geglu:
+        v, gt = ref.chunk(2, -1)
+        ref = v * F.gelu(gt)
+    e, why = err(y, ref)
+    return f"a32 {kind} dt={dt} M={M} N={N} K={K}", e, why, dt
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     r, g = random.Random(seed), torch.Generator().manual_seed(seed)
-    kinds = [case_gemm] * 4 + [case_conv] * 4 + [case_attn] * 2 + [case_groupnorm] + [case_llm] * 3
+    kinds = [case_gemm] * 4 + [case_conv] * 4 + [case_attn] * 2 + [case_groupnorm] + [case_llm] * 3 + [case_wstream] * 3 + [case_a32] * 3
+    if len(sys.argv) > 3:            # only the kinds named on the command line (comma separated: wstream,a32,...)
+        kinds = [globals()["case_" + k] for k in sys.argv[3].split(",")]
     tol = {torch.float16: 4e-3, torch.bfloat16: 2.5e-2}
     bad, done, worst, refused = 0, 0, {}, {}
     for i in range(n):

@@ -15,6 +15,7 @@
 // ds_read_b128 / ds_write_b128), double-buffered, with a 2-deep global->register prefetch ring.
 #include "common.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 using namespace spider;
@@ -2500,6 +2501,12 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     }
     a.kt_per_split = (nk + splits - 1) / splits;
     a.splits = (nk + a.kt_per_split - 1) / a.kt_per_split;
+    static const int trace = env_int("SPIDER_GEMM_TRACE");       // tuning aid: one line per dispatch decision on stderr
+    if (trace)
+        fprintf(stderr, "spider_gemm_dispatch M=%d N=%d K=%d conv=%d(%dx%d s%d ups%d) geglu=%d ln=%d a32=%d -> %s splits=%d\n", a.M, a.N, a.K, a.conv,
+                a.kh, a.kw, a.stride, a.ups, a.geglu, a.ln_colsum != nullptr, a.a32,
+                use_p8h ? "p8h(256x128)" : use_p8 ? "p8(256x256)" : (dma_bn && !a.geglu) ? (dma_bm == 64 ? "dma(64x160)" : "dma(128x160)")
+                                                                   : small ? "reg(64x64)" : "reg(128x128)", a.splits);
     if (use_p8h || (force_tile == 257 && !a.geglu && !a.ln_colsum)) {
         launch_p8h(a, st);
     } else if (use_p8 || (force_tile == 256 && !a.geglu && !a.ln_colsum)) {

@@ -514,6 +514,24 @@ __global__ __launch_bounds__(256) void act_kernel(const h16_t* __restrict__ x, h
 }
 
 // y = bf16((a + b) * scale) elementwise
+// "precise" operand split as its own pass: hi = round16(x), lo = round16(x - hi) of an fp32 tensor (8 values per thread). Lets the
+// LDS-DMA / 256^2 kernels -- which never see A in registers -- take the hi / lo halves as two ordinary 16-bit operands: conv(hi) and
+// conv(lo) accumulated in fp32 (res32 / c32d) is the same sum the A32 form makes with two MFMAs per K step.
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ x, h16_t* __restrict__ hi, h16_t* __restrict__ lo, size_t nvec) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + idx * 8), b = *reinterpret_cast<const f32x4*>(x + idx * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = pack_h16x2(v[2 * j], v[2 * j + 1]);
+            l[j] = pack_h16x2(v[2 * j] - h16lo_to_f32(h[j]), v[2 * j + 1] - h16hi_to_f32(h[j]));
+        }
+        *reinterpret_cast<u32x4*>(hi + idx * 8) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(lo + idx * 8) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
 __global__ __launch_bounds__(256) void add_scaled_kernel(const h16_t* __restrict__ a, const h16_t* __restrict__ b,
                                                          h16_t* __restrict__ y, size_t nvec, float scale) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
@@ -1050,6 +1068,15 @@ int SPIDER_FN(spider_act_ex)(const void* x, void* y, long n, int act, float para
 int SPIDER_FN(spider_act)(const void* x, void* y, long n, int act, void* stream) {
     SPIDER_CHECK(act >= 1 && act <= 3, "act: act in 1..3 (spider_act_ex_bf16 has the parameterised forms)");
     return SPIDER_FN(spider_act_ex)(x, y, n, act, 0.f, stream);
+}
+
+// hi[i] = round16(x[i]), lo[i] = round16(x[i] - hi[i]) (ABI v4, "precise" forms: the operand split as a pass of its own, for the
+// convs large enough to run on the LDS-DMA / 256^2 kernels twice -- conv(hi) then conv(lo) with res32 = the first result)
+int SPIDER_FN(spider_split_hilo_f32)(const float* x, void* hi, void* lo, long n, void* stream) {
+    SPIDER_CHECK(n > 0 && n % 8 == 0 && x && hi && lo, "split_hilo: n must be a positive multiple of 8");
+    split_hilo_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>(x, (h16_t*)hi, (h16_t*)lo, (size_t)n / 8);
+    SPIDER_LAUNCH_OK();
+    return 0;
 }
 
 int SPIDER_FN(spider_add_scaled)(const void* a, const void* b, void* y, long n, float scale, void* stream) {

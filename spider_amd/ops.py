@@ -810,6 +810,14 @@ def conv_a32(x32, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), di
     Hs, Ws = up_size if up_size is not None else (H, Wd)
     Ho = (Hs + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1
     Wo = (Ws + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
+    if 2.0 * B * Ho * Wo * Cout * kh * kw * Cin >= A32_SPLIT_MIN_FLOP and x32.numel() % 8 == 0 and rowbias is None and res is None and out_scale == 1.0:
+        # large conv (the UNet's down- / upsamplers at 64^2 / 32^2): the in-kernel hi / lo split lives on the register-staged tiles,
+        # 4-5x slower than the LDS-DMA / 256^2 kernels at this size -- split once, run the fast conv on each half, sum in fp32
+        hi, lo = split_hilo(x32, dt)
+        kw_ = dict(stride=stride, pad=pad, dil=dil, up_size=up_size)
+        _, y32 = conv_ex(hi, w, bias=bias, res32=res32, want32=True, **kw_)
+        r = conv_ex(lo, w, res32=y32, want32=True, **kw_)
+        return r if want32 else r[0]
     out = torch.empty(B, Ho, Wo, Cout, dtype=dt, device=x32.device)
     o32 = torch.empty(out.shape, dtype=torch.float32, device=x32.device) if want32 else None
     if res32 is not None:
@@ -820,6 +828,19 @@ def conv_a32(x32, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), di
               Cout, kh, kw, stride, pad[0], pad[1], dil, uh, uw, float(out_scale), int(wt is not None), _p(res32), _p(o32),
               _p(_workspace(x32.device)), WS_BYTES, _stream())
     return (out, o32) if want32 else out
+
+
+A32_SPLIT_MIN_FLOP = float(_os.environ.get("SPIDER_A32_SPLIT_GF", "4")) * 1e9      # conv_a32 above this: split pass + two fast convs
+
+
+def split_hilo(x32, dtype):
+    """fp32 tensor -> (hi, lo) 16-bit tensors with hi + lo == x to ~22 bits"""
+    _chk(x32, torch.float32, "x32")
+    hi = torch.empty(x32.shape, dtype=dtype, device=x32.device)
+    lo = torch.empty_like(hi)
+    _, sfx = _h16(hi)
+    _lib.call(f"spider_split_hilo_f32_{sfx}", _p(x32), _p(hi), _p(lo), x32.numel(), _stream())
+    return hi, lo
 
 
 def groupnorm_f32in(x32, gamma, beta, groups=32, eps=1e-5, silu=False, partial: Optional["GnPartial"] = None, want16=True, want32=False):

@@ -294,7 +294,9 @@ class SpiderFreeInfer:
         if self._streams is None:
             # the decoder pass is a dependent chain of short kernels: its stream gets the higher priority, so its workgroups are
             # dispatched as soon as a CU frees up; the LLM's long weight-streaming grids fill the rest of the chip
-            self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device, priority=-1))
+            import os
+            pl, pu = (int(v) for v in os.environ.get("SPIDER_STREAM_PRIO", "0,-1").split(","))      # tuning aid: "LLM,decoder" priorities
+            self._streams = (torch.cuda.Stream(device=self.device, priority=pl), torch.cuda.Stream(device=self.device, priority=pu))
         return self._streams
 
     @torch.no_grad()
