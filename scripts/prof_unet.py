@@ -11,10 +11,11 @@ PRECISE = int(os.environ.get("UNET_PRECISE", "0"))
 unet = UNetEngine.random_init(UNetConfig.sd15(), dev, seed=1, dtype=DT, stream32=os.environ.get("UNET_STREAM32", "0") == "1", precise=PRECISE)
 g = torch.Generator(device=dev).manual_seed(0)
 lat = torch.randn(1, 4, 64, 64, generator=g, device=dev)
-enc = torch.randn(2, 77, 768, generator=g, device=dev).to(DT)
+CB = int(os.environ.get("UNET_BATCH", "2"))          # CFG batch (2 = one prompt)
+enc = torch.randn(CB, 77, 768, generator=g, device=dev).to(DT)
 ts = PNDMScheduler().set_timesteps(40)
 unet.prepare(ts, enc)
-x2 = ops.latent_to_nhwc_f32(lat, reps=2) if PRECISE else ops.latent_to_nhwc(lat, reps=2, dtype=DT)
+x2 = ops.latent_to_nhwc_f32(lat, reps=CB) if PRECISE else ops.latent_to_nhwc(lat, reps=CB, dtype=DT)
 unet.step(x2, 0)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -73,15 +73,16 @@ class StableDiffusionPipeline:
             self.vae_scale_factor = 2 ** (len(vae.cfg.block_out) - 1)
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", precise: int = 0, **unused):
         """diffusers directory layout: unet/, vae/, text_encoder/, tokenizer/, scheduler/scheduler_config.json."""
         from transformers import CLIPTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         dt = engine_dtype(torch_dtype)
-        # stream32: fp32 master of the residual stream (+ 2.9 % per UNet evaluation, 26 % closer to the fp32 oracle: DESIGN.md section 4)
-        return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True),
+        # stream32: fp32 master of the residual stream (+ 2.9 % per UNet evaluation, 26 % closer to the fp32 oracle: DESIGN.md section 4);
+        # precise = 1 / 2 (an extra keyword of this loader, 0 = off): the stream's consumers read the master -- inside north_star's 1e-3
+        return cls(UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True, precise=precise),
                    VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, scaling=0.18215, dtype=dt),   # custom_sd.py:388
                    CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 64))
@@ -200,7 +201,7 @@ class AudioLDMPipeline:
         self.vae_scale_factor = 2 ** (len(vae.cfg.block_out) - 1)
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", precise: int = 0, **unused):
         """diffusers layout: unet/, vae/, text_encoder/, tokenizer/, vocoder/, scheduler/scheduler_config.json."""
         from transformers import RobertaTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
@@ -210,7 +211,7 @@ class AudioLDMPipeline:
         return cls(VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, dtype=dt),
                    ClapTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    RobertaTokenizer.from_pretrained(os.path.join(path, "tokenizer")),
-                   UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True), sched,
+                   UNetEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True, precise=precise), sched,
                    HifiGanEngine.from_pretrained(os.path.join(path, "vocoder"), device, dtype=dt), ucfg.get("sample_size", 128))
 
     def to(self, device=None, *a, **k):
@@ -359,13 +360,13 @@ class TextToVideoSDPipeline(StableDiffusionPipeline):
         super().__init__(unet, vae, text_encoder, tokenizer, scheduler or DDIMScheduler(), sample_size)
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", **unused):
+    def from_pretrained(cls, path: str, torch_dtype=None, device="cuda:0", precise: int = 0, **unused):
         from transformers import CLIPTokenizer
         sc = json.load(open(os.path.join(path, "scheduler", "scheduler_config.json")))
         sched = scheduler_from_config(sc)
         ucfg = json.load(open(os.path.join(path, "unet", "config.json")))
         dt = engine_dtype(torch_dtype)
-        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True),
+        return cls(UNet3DEngine.from_pretrained(os.path.join(path, "unet"), device, dtype=dt, stream32=True, precise=precise),
                    VAEDecoderEngine.from_pretrained(os.path.join(path, "vae"), device, dtype=dt),       # scaling_factor from the config (:382)
                    CLIPTextEngine.from_pretrained(os.path.join(path, "text_encoder"), device, dtype=dt),
                    CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer")), sched, ucfg.get("sample_size", 32))

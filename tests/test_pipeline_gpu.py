@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _pipe(dev, dtype=torch.float16, stream32=True):
+def _pipe(dev, dtype=torch.float16, stream32=True, precise=0):
     """default: the mode StableDiffusionPipeline.from_pretrained loads (f16 operands, fp32 residual stream in the UNet)"""
     from oracle.clip_vae import CLIPCfg, VAECfg, clip_param_shapes, random_weights, vae_param_shapes
     from oracle.unet import UNetCfg, random_unet_weights
@@ -17,7 +17,7 @@ def _pipe(dev, dtype=torch.float16, stream32=True):
     from spider_amd.vae import VAEConfig, VAEDecoderEngine
     from helpers import FakeTokenizer
     uc, cc, vc = UNetCfg.tiny(), CLIPCfg.tiny(), VAECfg.tiny()
-    return StableDiffusionPipeline(UNetEngine(UNetConfig(**uc.__dict__), random_unet_weights(uc, seed=1), dev, dtype=dtype, stream32=stream32),
+    return StableDiffusionPipeline(UNetEngine(UNetConfig(**uc.__dict__), random_unet_weights(uc, seed=1), dev, dtype=dtype, stream32=stream32, precise=precise),
                                    VAEDecoderEngine(VAEConfig(**vc.__dict__), random_weights(vae_param_shapes(vc), seed=2), dev, dtype=dtype),
                                    CLIPTextEngine(CLIPTextConfig(**cc.__dict__), random_weights(clip_param_shapes(cc), seed=3), dev, dtype=dtype),
                                    FakeTokenizer(), sample_size=16), (uc, cc, vc)
@@ -44,12 +44,13 @@ def test_pipeline_contract(dev):
     assert ids.shape == (1, 77)
 
 
-@pytest.mark.parametrize("dtype,stream32", [("bf16", False), ("f16", True)])
-def test_pipeline_matches_oracle_end_to_end(dev, dtype, stream32):
-    """text -> CLIP -> PNDM loop -> VAE, HIP engines vs the fp32 oracle pieces chained the same way."""
+@pytest.mark.parametrize("dtype,stream32,precise", [("bf16", False, 0), ("f16", True, 0), ("f16", True, 1), ("f16", True, 2)])
+def test_pipeline_matches_oracle_end_to_end(dev, dtype, stream32, precise):
+    """text -> CLIP -> PNDM loop -> VAE, HIP engines vs the fp32 oracle pieces chained the same way (precise = 1 / 2: the UNet's precise
+    modes through the pipeline's own denoising loop, fp32 latents in)."""
     from oracle.clip_vae import clip_text_forward, vae_decode
     from oracle.unet import PNDMOracle, UNetOracle, denoise_loop
-    pipe, (uc, cc, vc) = _pipe(dev, {"bf16": torch.bfloat16, "f16": torch.float16}[dtype], stream32)
+    pipe, (uc, cc, vc) = _pipe(dev, {"bf16": torch.bfloat16, "f16": torch.float16}[dtype], stream32, precise)
     prompt = ["a cozy cabin in the snow"]
     ids_c = pipe._tokenize(prompt)
     ids_u = pipe.tokenizer([""], padding="max_length", max_length=77, truncation=True).input_ids
@@ -63,7 +64,7 @@ def test_pipeline_matches_oracle_end_to_end(dev, dtype, stream32):
     ref = vae_decode(vc, random_weights(vae_param_shapes(vc), seed=2), lat).permute(0, 2, 3, 1).numpy()
     got = pipe(prompt=prompt, guidance_scale=7.5, num_inference_steps=6, latents=lat0, output_type="np").images
     err = np.abs(got - ref)
-    print(f"MEASURED sd_pipeline dtype={dtype} stream32={stream32} mean_abs={float(err.mean()):.5f}")
+    print(f"MEASURED sd_pipeline dtype={dtype} stream32={stream32} precise={precise} mean_abs={float(err.mean()):.5f}")
     assert err.mean() < {"bf16": 2e-2, "f16": 6e-4}[dtype] and got.shape == ref.shape, float(err.mean())
 
 
