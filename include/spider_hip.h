@@ -314,6 +314,12 @@ int spider_pack_keep_bits_f32(const float* u, void* words, int n, int n_valid, f
  *       into y (16-bit, optional) and / or stored unrounded into y32 (optional).
  *   spider_split_hilo_f32_*: the operand split as a pass of its own (hi = round16(x), lo = round16(x - hi)) for convs large enough to run
  *       on the LDS-DMA / 256^2 kernels twice: conv(hi) (c32d out), then conv(lo) with res32 = that result -- the same fp32 sum.
+ *   spider_row_split_f32_* / spider_groupnorm_f32in_split_nhwc_*: "split once, doubled K" -- the operand v (x32 itself, LayerNorm(x32)
+ *       * gamma + beta with fp32 two-pass row statistics, or GroupNorm(x32) (+ SiLU)) is written ONCE as y2 [M, 2K] = [round16(v) |
+ *       round16(v - round16(v))]; spider_gemm_* / spider_conv_nhwc_ex_* over y2 against the weight repeated along K ([W | W]: channels
+ *       [0, Cin) and [Cin, 2 Cin) of every tap for a conv) accumulate hi . W + lo . W in their fp32 accumulator -- the product of the
+ *       a32 entry points above on the LDS-DMA / 256^2 tile kernels, with every epilogue of those (GEGLU, rowbias, res32, c32d, GroupNorm
+ *       statistics). The host side takes this route above a flop threshold (spider_amd/ops.py: A32_DUP_MIN_FLOP).
  *   spider_conv2d_small_cin_f32in_* / spider_conv2d_small_cout_f32in_*: conv_in on the fp32 NHWC latents (y32: optional fp32 master of
  *       its output) and conv_out on the fp32 GroupNorm + SiLU output.  spider_latent_to_nhwc_f32: fp32 NCHW latents -> fp32 NHWC. */
 int spider_gemm_a32_bf16(const float* A32, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int lda,
@@ -330,6 +336,9 @@ int spider_conv_nhwc_a32_bf16(const float* x32, const void* w, void* y, const vo
 int spider_groupnorm_f32in_nhwc_bf16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
                                      float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
 int spider_split_hilo_f32_bf16(const float* x, void* hi, void* lo, long n, void* stream);
+int spider_row_split_f32_bf16(const float* x32, const void* gamma, const void* beta, void* y2, long M, int K, float eps, void* stream);
+int spider_groupnorm_f32in_split_nhwc_bf16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta,
+                                            void* y2, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
 int spider_conv2d_small_cin_f32in_bf16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
                                        int Cin, int Cout, int ks, void* stream);
 int spider_conv2d_small_cout_f32in_bf16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,
@@ -421,6 +430,9 @@ int spider_conv_nhwc_a32_f16(const float* x32, const void* w, void* y, const voi
 int spider_groupnorm_f32in_nhwc_f16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta, void* y,
                                      float* y32, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
 int spider_split_hilo_f32_f16(const float* x, void* hi, void* lo, long n, void* stream);
+int spider_row_split_f32_f16(const float* x32, const void* gamma, const void* beta, void* y2, long M, int K, float eps, void* stream);
+int spider_groupnorm_f32in_split_nhwc_f16(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta,
+                                            void* y2, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream);
 int spider_conv2d_small_cin_f32in_f16(const float* x32, const void* w, const void* bias, void* y, float* y32, int B, int H, int W,
                                        int Cin, int Cout, int ks, void* stream);
 int spider_conv2d_small_cout_f32in_f16(const float* x32, const void* w, const void* bias, float* y32, int B, int H, int W, int Cin,

@@ -279,6 +279,10 @@ def case_a32(r, g):
     must sit at fp32-accumulation distance from the reference although W is 16-bit: the A operand carries ~22 bits."""
     dt = r.choice(DTS)
     kind = r.choice(["gemm", "ln", "ln_geglu", "conv", "gn"])
+    # route: the a32 kernels, or "split once, doubled K" (marked weight + the flop threshold at 0 for this call)
+    dup = r.random() < 0.5
+    ops.A32_DUP_MIN_FLOP, ops.A32_DUP_MIN_M = (0.0 if dup else float("inf")), 0
+    mk = ops.mark_weight if dup else (lambda t: t)
     if kind == "gn":
         B, HW, C = r.choice([1, 2, 3]), r.choice([16, 60, 64, 256, 1000, 4096]), r.choice([32, 64, 320, 640, 1280])
         x = torch.randn(B, HW, C, generator=g) * 2 + 0.5
@@ -296,37 +300,37 @@ def case_a32(r, g):
         up = (2 * H, 2 * W) if (ks == 3 and stride == 1 and r.random() < 0.3) else None
         x = torch.randn(B, H, W, Cin, generator=g)
         w, b = rnd(g, Cout, ks, ks, Cin, scale=(ks * ks * Cin) ** -0.5, dt=dt), rnd(g, Cout, dt=dt)
-        y, y32 = ops.conv_a32(x.to(dev), w.to(dev), bias=b.to(dev), stride=stride, pad=(ks // 2, ks // 2), up_size=up, want32=True)
+        y, y32 = ops.conv_a32(x.to(dev), mk(w.to(dev)), bias=b.to(dev), stride=stride, pad=(ks // 2, ks // 2), up_size=up, want32=True)
         xi = x.permute(0, 3, 1, 2)
         if up:
             xi = F.interpolate(xi, size=up, mode="nearest")
         ref = F.conv2d(xi, w.float().permute(0, 3, 1, 2), b.float(), stride=stride, padding=ks // 2).permute(0, 2, 3, 1)
         e, why = err(y, ref)
         e2, why2 = err(y32, ref)
-        return f"a32 conv dt={dt} B={B} {H}x{W} Cin={Cin} Cout={Cout} ks={ks} s={stride} up={up}", max(e, 30 * e2), why or why2, dt
+        return f"a32 conv dt={dt} dup={dup} B={B} {H}x{W} Cin={Cin} Cout={Cout} ks={ks} s={stride} up={up}", max(e, 30 * e2), why or why2, dt
     M, N, K = r.choice([16, 64, 100, 512, 2048, 8192]), r.choice([8, 64, 320, 640, 1280, 2560]), r.choice([64, 320, 640, 1280])
     A = torch.randn(M, K, generator=g) * 1.5 + r.choice([0.0, 2.0])
     W = rnd(g, N, K, scale=K ** -0.5, dt=dt)
     b = rnd(g, N, dt=dt)
     if kind == "gemm":
         r32 = torch.randn(M, N, generator=g)
-        y, y32 = ops.gemm_a32(A.to(dev), W.to(dev), bias=b.to(dev), res32=r32.to(dev), want32=True)
+        y, y32 = ops.gemm_a32(A.to(dev), mk(W.to(dev)), bias=b.to(dev), res32=r32.to(dev), want32=True)
         ref = A @ W.float().T + b.float() + r32
         e, why = err(y, ref)
         e2, why2 = err(y32, ref)
-        return f"a32 gemm dt={dt} M={M} N={N} K={K}", max(e, 30 * e2), why or why2, dt
+        return f"a32 gemm dt={dt} dup={dup} M={M} N={N} K={K}", max(e, 30 * e2), why or why2, dt
     ga, be = rnd(g, K, dt=dt) * 0.1 + 1, rnd(g, K, dt=dt) * 0.1
     geglu = kind == "ln_geglu"
     if geglu and N % 8:
         return None
-    fold = ops.fold_layernorm_exact(W.to(dev), ga.to(dev), be.to(dev), b.to(dev))
+    fold = ops.fold_layernorm_exact(mk(W.to(dev)), ga.to(dev), be.to(dev), b.to(dev))
     y = ops.gemm_ln_a32(A.to(dev), *fold, act="geglu_exact" if geglu else None)
     ref = F.layer_norm(A, (K,), ga.float(), be.float(), 1e-5) @ W.float().T + b.float()
     if geglu:
         v, gt = ref.chunk(2, -1)
         ref = v * F.gelu(gt)
     e, why = err(y, ref)
-    return f"a32 {kind} dt={dt} M={M} N={N} K={K}", e, why, dt
+    return f"a32 {kind} dt={dt} dup={dup} M={M} N={N} K={K}", e, why, dt
 
 
 def main():

@@ -114,7 +114,7 @@ template <bool SILU, bool X32 = false>
 __global__ void gn_apply_kernel(const h16_t* __restrict__ x, const float* __restrict__ partial,
                                 const h16_t* __restrict__ gamma, const h16_t* __restrict__ beta,
                                 h16_t* __restrict__ y, int HW, int C, int G, int nchunk,
-                                float eps, int pix_per_block, int KP, float* __restrict__ y32 = nullptr) {
+                                float eps, int pix_per_block, int KP, float* __restrict__ y32 = nullptr, int ysplit = 0) {
     // Block = (C/8)*KP threads like pass 1: a thread owns one 8-channel vector for all its pixels, so the per-channel
     // scale a_c = rstd_g * gamma_c and shift b_c = beta_c - mean_g * a_c live in 16 registers and the inner loop is one fma
     // (+ SiLU) per element -- no per-element group lookup (an integer division by a runtime C/G and two LDS reads before).
@@ -201,7 +201,18 @@ __global__ void gn_apply_kernel(const h16_t* __restrict__ x, const float* __rest
                     *reinterpret_cast<f32x4*>(y32b + (size_t)pp * C) = f32x4{o[0], o[1], o[2], o[3]};
                     *reinterpret_cast<f32x4*>(y32b + (size_t)pp * C + 4) = f32x4{o[4], o[5], o[6], o[7]};
                 }
-                if (y) {
+                if (y && ysplit) {
+                    // operand-split form: y is [B, HW, 2C], channels [0, C) the rounded value, [C, 2C) the rounded remainder
+                    h16_t* ys = y + ((size_t)b * HW + pp) * 2 * C + v * 8;
+                    uint32_t hh[4], ll[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hh[j] = pack_h16x2(o[2 * j], o[2 * j + 1]);
+                        ll[j] = pack_h16x2(o[2 * j] - h16lo_to_f32(hh[j]), o[2 * j + 1] - h16hi_to_f32(hh[j]));
+                    }
+                    *reinterpret_cast<u32x4*>(ys) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+                    *reinterpret_cast<u32x4*>(ys + C) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+                } else if (y) {
                     u32x4 ov;
                     ov.x = pack_h16x2(o[0], o[1]); ov.y = pack_h16x2(o[2], o[3]);
                     ov.z = pack_h16x2(o[4], o[5]); ov.w = pack_h16x2(o[6], o[7]);
@@ -529,6 +540,86 @@ __global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict
         }
         *reinterpret_cast<u32x4*>(hi + idx * 8) = u32x4{h[0], h[1], h[2], h[3]};
         *reinterpret_cast<u32x4*>(lo + idx * 8) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+// Operand split by rows (ABI v4; DESIGN.md section 4, "split once, doubled K"): x [M, K] fp32 -> y [M, 2K] 16-bit with
+// y[m, 0:K] = round16(v) and y[m, K:2K] = round16(v - round16(v)), v = x (LN = false) or LayerNorm(x) * gamma + beta with fp32
+// two-pass statistics (LN = true). A GEMM / conv over y against the weight repeated along K ([W | W]) then accumulates
+// hi . W + lo . W in its fp32 accumulator -- the hi / lo product of spider_gemm_a32 / spider_gemm_ln_a32 at the speed of the 16-bit
+// tile kernels. One wave per row, 8 elements per lane and trip (NIT trips cover K <= 512 NIT), the row held in registers.
+template <int NIT, bool LN>
+__global__ __launch_bounds__(256) void row_split_kernel(const float* __restrict__ x, const h16_t* __restrict__ gamma,
+                                                        const h16_t* __restrict__ beta, h16_t* __restrict__ y, long M, int K, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+        const float* xr = x + (size_t)m * K;
+        float v[NIT][8];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+            if (c < K) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c), b = *reinterpret_cast<const f32x4*>(xr + c + 4);
+                v[it][0] = a[0]; v[it][1] = a[1]; v[it][2] = a[2]; v[it][3] = a[3];
+                v[it][4] = b[0]; v[it][5] = b[1]; v[it][6] = b[2]; v[it][7] = b[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[it][j] = 0.f;
+            }
+        }
+        if (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[it][j];
+            const float mu = wave_sum(s) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const bool ok = (it * 64 + lane) * 8 < K;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[it][j] - mu;
+                    q += ok ? d * d : 0.f;
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)K + eps);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 8;
+                if (c < K) {
+                    const u32x4 gq = *reinterpret_cast<const u32x4*>(gamma + c);
+                    const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+                    uint32_t bw[4] = {0u, 0u, 0u, 0u};
+                    if (beta) {
+                        const u32x4 bq = *reinterpret_cast<const u32x4*>(beta + c);
+                        bw[0] = bq.x; bw[1] = bq.y; bw[2] = bq.z; bw[3] = bq.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float ga = (j & 1) ? h16hi_to_f32(gw[j >> 1]) : h16lo_to_f32(gw[j >> 1]);
+                        const float be = (j & 1) ? h16hi_to_f32(bw[j >> 1]) : h16lo_to_f32(bw[j >> 1]);
+                        v[it][j] = fmaf((v[it][j] - mu) * rstd, ga, be);
+                    }
+                }
+            }
+        }
+        h16_t* yr = y + (size_t)m * 2 * K;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 8;
+            if (c < K) {
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = pack_h16x2(v[it][2 * j], v[it][2 * j + 1]);
+                    l[j] = pack_h16x2(v[it][2 * j] - h16lo_to_f32(h[j]), v[it][2 * j + 1] - h16hi_to_f32(h[j]));
+                }
+                *reinterpret_cast<u32x4*>(yr + c) = u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(yr + K + c) = u32x4{l[0], l[1], l[2], l[3]};
+            }
+        }
     }
 }
 
@@ -1075,6 +1166,60 @@ int SPIDER_FN(spider_act)(const void* x, void* y, long n, int act, void* stream)
 int SPIDER_FN(spider_split_hilo_f32)(const float* x, void* hi, void* lo, long n, void* stream) {
     SPIDER_CHECK(n > 0 && n % 8 == 0 && x && hi && lo, "split_hilo: n must be a positive multiple of 8");
     split_hilo_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>(x, (h16_t*)hi, (h16_t*)lo, (size_t)n / 8);
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// x32 [M, K] fp32 -> y2 [M, 2K] 16-bit = [round16(v) | round16(v - round16(v))], v = x32 (gamma == NULL) or
+// LayerNorm(x32) * gamma (+ beta) (gamma [K], beta [K] or NULL, 16-bit). K % 8 == 0, K <= 8192.
+int SPIDER_FN(spider_row_split_f32)(const float* x32, const void* gamma, const void* beta, void* y2, long M, int K, float eps, void* stream) {
+    SPIDER_CHECK(M > 0 && K > 0 && K % 8 == 0 && K <= 8192 && x32 && y2, "row_split: K must be a multiple of 8 and <= 8192");
+    SPIDER_CHECK(gamma || !beta, "row_split: beta without gamma");
+    const long want = (M + 3) / 4;
+    const int grid = (int)(want < 4096 ? want : 4096);
+    const h16_t *g = (const h16_t*)gamma, *b = (const h16_t*)beta;
+    h16_t* y = (h16_t*)y2;
+    hipStream_t st = (hipStream_t)stream;
+#define SPIDER_ROW_SPLIT(NIT)                                                                                   \
+    if (gamma) row_split_kernel<NIT, true><<<grid, 256, 0, st>>>(x32, g, b, y, M, K, eps);                      \
+    else row_split_kernel<NIT, false><<<grid, 256, 0, st>>>(x32, g, b, y, M, K, eps)
+    if (K <= 512) { SPIDER_ROW_SPLIT(1); }
+    else if (K <= 1024) { SPIDER_ROW_SPLIT(2); }
+    else if (K <= 2048) { SPIDER_ROW_SPLIT(4); }
+    else if (K <= 4096) { SPIDER_ROW_SPLIT(8); }
+    else { SPIDER_ROW_SPLIT(16); }
+#undef SPIDER_ROW_SPLIT
+    SPIDER_LAUNCH_OK();
+    return 0;
+}
+
+// GroupNorm (+ SiLU) of the fp32 tensor x32 [B, HW, C] written in the operand-split form y2 [B, HW, 2C] (see spider_row_split_f32);
+// statistics as spider_groupnorm_f32in_nhwc (partial, or a pass over x32 into ws).
+int SPIDER_FN(spider_groupnorm_f32in_split_nhwc)(const float* x32, const float* partial, int nchunk, const void* gamma, const void* beta,
+                                                 void* y2, float* ws, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+    SPIDER_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64 && 256 % G == 0, "groupnorm_f32in_split: G must divide 256 and be <= 64");
+    SPIDER_CHECK(C % 8 == 0 && C % G == 0 && C <= 8192 && x32 && y2, "groupnorm_f32in_split: C % 8, C % G; x32 and y2 are required");
+    const int cv = C / 8;
+    int KP = 256 / cv;
+    if (KP < 1) KP = 1;
+    const int threads = cv * KP;
+    SPIDER_CHECK(threads <= 1024 && (threads >= 128 || threads >= 2 * G), "groupnorm_f32in_split: unsupported channel count for the block layout");
+    if (!partial) {
+        SPIDER_CHECK(ws, "groupnorm_f32in_split: ws is required without partial statistics");
+        nchunk = gn_nchunk(HW);
+        gn_stats_kernel<true><<<dim3(nchunk, B), threads, (size_t)2 * KP * C * sizeof(float), (hipStream_t)stream>>>(
+            (const h16_t*)x32, ws, HW, C, G, nchunk, KP, nullptr, C, nullptr);
+        SPIDER_LAUNCH_OK();
+        partial = ws;
+    }
+    SPIDER_CHECK(nchunk > 0, "groupnorm_f32in_split: nchunk");
+    int ppb = 4 * KP;
+    while ((long)B * ((HW + ppb - 1) / ppb) > 1024 && ppb < 64 * KP) ppb += 4 * KP;
+    dim3 g2((HW + ppb - 1) / ppb, B);
+    if (silu) gn_apply_kernel<true, true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x32, partial, (const h16_t*)gamma,
+                                                                             (const h16_t*)beta, (h16_t*)y2, HW, C, G, nchunk, eps, ppb, KP, nullptr, 1);
+    else gn_apply_kernel<false, true><<<g2, threads, 0, (hipStream_t)stream>>>((const h16_t*)x32, partial, (const h16_t*)gamma,
+                                                                          (const h16_t*)beta, (h16_t*)y2, HW, C, G, nchunk, eps, ppb, KP, nullptr, 1);
     SPIDER_LAUNCH_OK();
     return 0;
 }

@@ -88,6 +88,8 @@ SIGNATURES = {
     "spider_conv_nhwc_a32_bf16": (_i, [_vp] * 6 + [_i] * 13 + [_f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_groupnorm_f32in_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_split_hilo_f32_bf16": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "spider_row_split_f32_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "spider_groupnorm_f32in_split_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_conv2d_small_cin_f32in_bf16": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "spider_conv2d_small_cout_f32in_bf16": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
     "spider_latent_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -103,7 +105,7 @@ F16_OPS = (
     "spider_axpby", "spider_mean_tokens", "spider_moe_combine", "spider_col2im1d_f32", "spider_l2_normalize_rows",
     "spider_conv2d_small_cin", "spider_conv2d_small_cout", "spider_latent_to_nhwc", "spider_softmax_rows_f32",
     "spider_gemm_a32", "spider_gemm_ln_a32", "spider_gemm_gn_in_a32", "spider_conv_nhwc_a32", "spider_groupnorm_f32in_nhwc", "spider_conv2d_small_cin_f32in",
-    "spider_conv2d_small_cout_f32in", "spider_split_hilo_f32",
+    "spider_conv2d_small_cout_f32in", "spider_split_hilo_f32", "spider_row_split_f32", "spider_groupnorm_f32in_split_nhwc",
 )
 for _n in F16_OPS:
     SIGNATURES[_n + "_f16"] = SIGNATURES[_n + "_bf16"]

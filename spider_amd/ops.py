@@ -742,8 +742,74 @@ def attention_cache(q, k_cache, v_cache, Lk, scale=None, causal=True, kv_off=Non
 # The A operand (or the NHWC image) is an fp32 tensor -- the master of the residual stream, or a GroupNorm output kept in fp32 -- and
 # is split into hi / lo 16-bit halves inside the kernel (two MFMAs per K step): include/spider_hip.h, DESIGN.md section 4. The
 # 16-bit format of the call is that of W.
+# "Split once, doubled K": above A32_DUP_MIN_FLOP the operand is written ONCE in the operand-split form [round16(v) | round16(v -
+# round16(v))] ([M, 2K]; v = the fp32 tensor, its LayerNorm or its GroupNorm) and the 16-bit tile kernels run over it against the
+# weight repeated along K ([W | W], built once per marked weight): the same hi . W + lo . W sum in the fp32 accumulator as the a32
+# kernels form with two MFMAs per K step on register-staged tiles, at the speed of the LDS-DMA / 256^2 kernels and with all of their
+# epilogues (GEGLU, rowbias, res32 / c32d, GroupNorm statistics).
+A32_DUP_MIN_FLOP = float(_os.environ.get("SPIDER_A32_DUP_GF", "4")) * 1e9
+A32_DUP_MIN_M = int(_os.environ.get("SPIDER_A32_DUP_MIN_M", "0"))      # rows below which the a32 kernels keep the call ([W | W] doubles the weight bytes)
+
+
+def _dup_ok(M: int, N: int, K: int) -> bool:
+    return 2.0 * M * N * K >= A32_DUP_MIN_FLOP and M >= A32_DUP_MIN_M and K % 8 == 0
+
+
+def _wdup(W: torch.Tensor):
+    """[W | W] along the last axis of a marked weight ([N, K] -> [N, 2K]; OHWI [Cout, kh, kw, Cin] -> [Cout, kh, kw, 2 Cin]), built on
+    first use outside stream capture and kept with the tensor; None for unmarked tensors (slices, activations as W)."""
+    if not getattr(W, "_spider_weight", False):
+        return None
+    t = getattr(W, "_spider_dup", None)
+    tag = (W._version, W.data_ptr())
+    if t is None or getattr(W, "_spider_dup_tag", None) != tag:
+        if torch.cuda.is_current_stream_capturing():
+            if t is not None:
+                raise RuntimeError("a marked weight was modified in place and is first used again under stream capture")
+            return None
+        t = mark_weight(torch.cat([W, W], -1).contiguous())
+        W._spider_dup, W._spider_dup_tag = t, tag
+    return t
+
+
+def row_split(x32, dtype, gamma=None, beta=None, eps=1e-5):
+    """x32 [..., K] fp32 -> [..., 2K] 16-bit = [hi | lo] of x32 itself (gamma None) or of LayerNorm(x32) * gamma + beta (fp32 statistics)"""
+    _chk(x32, torch.float32, "x32")
+    K = x32.shape[-1]
+    y = torch.empty(*x32.shape[:-1], 2 * K, dtype=dtype, device=x32.device)
+    _, sfx = _h16(y)
+    if gamma is not None:
+        _chk(gamma, dtype, "gamma")
+    if beta is not None:
+        _chk(beta, dtype, "beta")
+    _lib.call(f"spider_row_split_f32_{sfx}", _p(x32), _p(gamma), _p(beta), _p(y), x32.numel() // K, K, float(eps), _stream())
+    return y
+
+
+def groupnorm_f32in_split(x32, gamma, beta, groups=32, eps=1e-5, silu=False, partial: Optional["GnPartial"] = None):
+    """GroupNorm (+ SiLU) of the fp32 tensor x32 [B, ..., C] in the operand-split form [B, ..., 2C]"""
+    dt, sfx = _h16(gamma)
+    _chk(x32, torch.float32, "x32"); _chk(gamma, dt, "gamma"); _chk(beta, dt, "beta")
+    B, Cn = x32.shape[0], x32.shape[-1]
+    HW = x32.numel() // (B * Cn)
+    y = torch.empty(*x32.shape[:-1], 2 * Cn, dtype=dt, device=x32.device)
+    ws, pt, nch = None, None, 0
+    if partial is not None:
+        assert partial.groups == groups and tuple(partial.t.shape) == (B, partial.nchunk, groups, 2)
+        pt, nch = partial.t, partial.nchunk
+    else:
+        ws = torch.empty(B * groupnorm_nchunk(HW) * groups * 2, dtype=torch.float32, device=x32.device)
+    _lib.call(f"spider_groupnorm_f32in_split_nhwc_{sfx}", _p(x32), _p(pt), nch, _p(gamma), _p(beta), _p(y), _p(ws), B, HW, Cn, groups,
+              float(eps), int(silu), _stream())
+    return y
+
+
 def gemm_a32(A32, W, bias=None, res=None, out_scale=1.0, res32=None, want32=False):
     dt, sfx = _h16(W)
+    if _dup_ok(A32.numel() // W.shape[1], W.shape[0], W.shape[1]):
+        W2 = _wdup(W)
+        if W2 is not None:
+            return gemm(row_split(A32, dt), W2, bias=bias, res=res, out_scale=out_scale, res32=res32, want32=want32)
     _chk(A32, torch.float32, "A32"); _chk(W, dt, "W")
     N, K = W.shape
     assert A32.shape[-1] == K, f"gemm_a32: A[..., {A32.shape[-1]}] vs W[{N},{K}]"
@@ -765,13 +831,20 @@ def fold_layernorm_exact(W, gamma, beta, bias=None):
     colbias = W32 @ beta.float()
     if bias is not None:
         colbias = colbias + bias.float()
-    return W, gamma.to(W.dtype).contiguous(), colsum, colbias.contiguous()
+    return (W, gamma.to(W.dtype).contiguous(), colsum, colbias.contiguous(), beta.to(W.dtype).contiguous(),
+            None if bias is None else bias.to(W.dtype).contiguous())
 
 
-def gemm_ln_a32(A32, W, gamma, colsum, colbias, act=None, eps=1e-5):
+def gemm_ln_a32(A32, W, gamma, colsum, colbias, beta=None, bias=None, act=None, eps=1e-5):
     """LayerNorm(A32) @ W^T + bias (+ GEGLU) on the fp32 rows A32 [..., K]: statistics in fp32, gamma applied to A before the hi / lo
-    split, W exact (no re-rounded W * gamma). (W, gamma, colsum, colbias) = fold_layernorm_exact(W, gamma, beta, bias)."""
+    split, W exact (no re-rounded W * gamma). (W, gamma, colsum, colbias, beta, bias) = fold_layernorm_exact(W, gamma, beta, bias);
+    beta / bias (the LayerNorm's shift and the projection's bias as 16-bit vectors) serve the split-once route of large calls, which
+    applies the LayerNorm exactly as written -- (x - mean) rstd gamma + beta in fp32 -- before the split."""
     dt, sfx = _h16(W)
+    if beta is not None and _dup_ok(A32.numel() // W.shape[1], W.shape[0], W.shape[1]):
+        W2 = _wdup(W)
+        if W2 is not None:
+            return gemm(row_split(A32, dt, gamma, beta, eps), W2, bias=bias, act=act)
     _chk(A32, torch.float32, "A32"); _chk(W, dt, "W"); _chk(gamma, dt, "gamma")
     _chk(colsum, torch.float32, "colsum"); _chk(colbias, torch.float32, "colbias")
     N, K = W.shape
@@ -792,6 +865,10 @@ def gemm_gn_in_a32(A32, W, part: "GnPartial", gamma, beta, HW: int, eps: float, 
     _chk(A32, torch.float32, "A32"); _chk(W, dt, "W")
     N, K = W.shape
     M = A32.numel() // K
+    if _dup_ok(M, N, K):
+        W2 = _wdup(W)
+        if W2 is not None:
+            return gemm(groupnorm_f32in_split(A32, gamma, beta, part.groups, eps, False, partial=part), W2, bias=bias, want32=want32)
     out = torch.empty(*A32.shape[:-1], N, dtype=dt, device=A32.device)
     o32 = torch.empty(out.shape, dtype=torch.float32, device=A32.device) if want32 else None
     wt = _tiled(W, M)
@@ -810,9 +887,16 @@ def conv_a32(x32, w, bias=None, res=None, rowbias=None, stride=1, pad=(0, 0), di
     Hs, Ws = up_size if up_size is not None else (H, Wd)
     Ho = (Hs + 2 * pad[0] - dil * (kh - 1) - 1) // stride + 1
     Wo = (Ws + 2 * pad[1] - dil * (kw - 1) - 1) // stride + 1
+    if _dup_ok(B * Ho * Wo, Cout, kh * kw * Cin) and Cin % 8 == 0:
+        # large conv (the UNet's samplers, shortcuts and every conv of the video UNet): the in-kernel hi / lo split lives on the
+        # register-staged tiles, 4-5x slower than the LDS-DMA / 256^2 kernels at this size -- split once into [hi | lo] channels and run
+        # the fast conv over 2 Cin channels against [W | W]
+        w2 = _wdup(w)
+        if w2 is not None:
+            return conv_ex(row_split(x32, dt), w2, bias=bias, res=res, rowbias=rowbias, stride=stride, pad=pad, dil=dil, up_size=up_size,
+                           out_scale=out_scale, res32=res32, want32=want32)
     if 2.0 * B * Ho * Wo * Cout * kh * kw * Cin >= A32_SPLIT_MIN_FLOP and x32.numel() % 8 == 0 and rowbias is None and res is None and out_scale == 1.0:
-        # large conv (the UNet's down- / upsamplers at 64^2 / 32^2): the in-kernel hi / lo split lives on the register-staged tiles,
-        # 4-5x slower than the LDS-DMA / 256^2 kernels at this size -- split once, run the fast conv on each half, sum in fp32
+        # (unmarked weight: no [W | W] copy is kept) split once, run the fast conv on each half, sum in fp32
         hi, lo = split_hilo(x32, dt)
         kw_ = dict(stride=stride, pad=pad, dil=dil, up_size=up_size)
         _, y32 = conv_ex(hi, w, bias=bias, res32=res32, want32=True, **kw_)

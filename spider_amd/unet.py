@@ -465,11 +465,11 @@ class UNetEngine:
         """attn2's projection of the block input: y is the norm2 output (ln_input=False) or the un-normalised residual stream
         (ln_input=True: norm2 folded into the GEMM). y32 (precise = 2): the stream's fp32 master, exact-weight form."""
         if ln_input and y32 is not None and (b + ".attn2") in self.lnx:
-            W_, g_, cs, cb = self.lnx[b + ".attn2"]
+            W_, g_, cs, cb, be_, bi_ = self.lnx[b + ".attn2"]
             C = y.shape[-1]
             if not self.self_cross and W_.shape[0] != C:
-                W_, cs, cb = W_[:C], cs[:C], cb[:C]
-            return ops.gemm_ln_a32(y32, W_, g_, cs, cb)
+                W_, cs, cb, bi_ = W_[:C], cs[:C], cb[:C], (None if bi_ is None else bi_[:C])
+            return ops.gemm_ln_a32(y32, W_, g_, cs, cb, be_, bi_)
         if ln_input:
             Wf, cs, cb = self.ln[b + ".attn2"]
             C = y.shape[-1]
