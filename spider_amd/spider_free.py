@@ -424,6 +424,15 @@ class SpiderFreeInfer:
             raise err
         return self._unbatch(box["res"])
 
+    def reset_warm(self):
+        """Forget which pass geometries have run: call after swapping or reloading an engine behind the decoders / the model (a new
+        engine has no hipGraphs yet, and a capture must not happen beside another thread's launches). The next passes of every
+        geometry run one after the other on the calling thread again, as the first ones did."""
+        if self._pending is not None or self._prefilled is not None:
+            raise RuntimeError("reset_warm() with requests in flight: flush() first")
+        self._warm.clear()
+        self._last_dec = None
+
     @torch.no_grad()
     def flush(self):
         """Drain one request: the decoder pass of the oldest request in flight (nothing left to overlap it with); with depth 3 a

@@ -318,3 +318,24 @@ def test_failed_decoder_pass_does_not_lose_the_next_request():
         assert nxt is not None and nxt.text_ids[0] == 13
     finally:
         pipe.__class__.__call__ = orig
+
+
+def test_reset_warm_after_an_engine_swap_runs_the_next_passes_alone():
+    """a host that swaps the engine behind a pipeline (bench.py's precise-mode leg) says so: the new engine has no graphs, its first
+    decoder pass must not be enqueued beside another thread's LLM pass"""
+    infer, pipe, thinker = make()
+    infer.processor.prompt_len = 4
+    reqs = [{"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)} for i in range(6)]
+    main = threading.current_thread().name
+    for r in reqs[:3]:
+        infer.submit(inputs=r)
+    assert pipe.calls[-1][0] == "spider-decoder-enqueue"                       # steady state: overlapped
+    with pytest.raises(RuntimeError, match="in flight"):
+        infer.reset_warm()
+    assert infer.flush() is not None and infer.flush() is None
+    infer.reset_warm()
+    n = len(pipe.calls)
+    assert infer.submit(inputs=reqs[3]) is None
+    assert infer.submit(inputs=reqs[4]) is not None and pipe.calls[n][0] == main    # first decoder pass after the reset: calling thread
+    assert infer.submit(inputs=reqs[5]) is not None and pipe.calls[n + 1][0] == "spider-decoder-enqueue"
+    assert infer.flush() is not None
