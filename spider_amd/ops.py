@@ -772,6 +772,9 @@ def _wdup(W: torch.Tensor):
     return t
 
 
+dup_weight = _wdup
+
+
 def row_split(x32, dtype, gamma=None, beta=None, eps=1e-5):
     """x32 [..., K] fp32 -> [..., 2K] 16-bit = [hi | lo] of x32 itself (gamma None) or of LayerNorm(x32) * gamma + beta (fp32 statistics)"""
     _chk(x32, torch.float32, "x32")

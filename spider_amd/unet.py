@@ -525,7 +525,10 @@ class UNetEngine:
             b = f"{n}.transformer_blocks.{d}"
             fuse = self.fuse_ln
             if self.self_attn_hook is not None and self.self_attn_hook.wants(b + ".attn1"):
-                y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
+                if self.precise_ln:     # [hi | lo] of the fp32 LayerNorm of the stream's master: the hook projects it against [W | W]
+                    y = ops.row_split(h32, self.dtype, w[b + ".norm1.weight"], w[b + ".norm1.bias"], 1e-5)
+                else:
+                    y = ops.layernorm(h, w[b + ".norm1.weight"], w[b + ".norm1.bias"])
                 o = self.self_attn_hook(self, b + ".attn1", y, heads)
             elif fuse and self.precise_ln:      # the fp32 token stream, exact weight
                 qkv = ops.gemm_ln_a32(h32, *self.lnx[b + ".attn1"])
@@ -620,9 +623,10 @@ class UNetEngine:
                 skip = skips.pop()
                 hh = h
                 if self.freeu is not None and i < 2:
-                    if self.precise:
-                        raise NotImplementedError("UNetEngine(precise=True) with FreeU: the story decoder runs the stream32 mode")
-                    hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
+                    if self.precise:      # on the fp32 masters: the scaled half and the filtered skip are never rounded to 16 bits
+                        hh, skip = _apply_freeu32(i, hh, skip, *self.freeu)
+                    else:
+                        hh, skip = _apply_freeu(i, hh, skip, *self.freeu)
                 h = self._resnet(f"up_blocks.{i}.resnets.{j}", (hh, skip), out_gn=cfg.up_attn[i])
                 if cfg.up_attn[i]:
                     h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, rheads[i], rdepth[i])
@@ -685,6 +689,19 @@ def _apply_freeu(res_idx, hidden, skip, s1, s2, b1, b2):
     b, s = (b1, s1) if res_idx == 0 else (b2, s2)
     hidden = torch.cat([(hidden[..., :n].float() * b).to(hidden.dtype), hidden[..., n:]], -1).contiguous()
     return hidden, _fourier_filter(skip, 1, s)
+
+
+def _apply_freeu32(res_idx, hidden, skip, s1, s2, b1, b2):
+    """FreeU in the precise modes: the same two edits on the fp32 masters (`_s32`) of the up-block input and of the skip feature;
+    the 16-bit tensors returned are their shadows (the precise resnet reads the masters only)."""
+    h32, k32 = hidden._s32, skip._s32
+    n = h32.shape[-1] // 2
+    b, s = (b1, s1) if res_idx == 0 else (b2, s2)
+    h32 = torch.cat([h32[..., :n] * b, h32[..., n:]], -1).contiguous()
+    k32 = _fourier_filter(k32, 1, s)
+    hs, ks = h32.to(hidden.dtype), k32.to(skip.dtype)
+    hs._s32, ks._s32 = h32, k32
+    return hs, ks
 
 
 def _param_shapes(cfg: UNetConfig) -> dict:

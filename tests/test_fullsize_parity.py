@@ -313,7 +313,11 @@ def test_sdxl_full_50_step_ddim_loop_latents_match_oracle_fixture(dev, golden_di
     _free()
 
 
-def test_story_sdxl_fullsize_write_then_read_matches_oracle_fixture(dev, golden_dir):
+STORY_BOUND = {0: 2.2e-3, 2: 1.0e-3}      # f16 + fp32 stream (the mode init_story_generation loads): measured 1.52 / 1.66e-3; precise=2: north_star's bound
+
+
+@pytest.mark.parametrize("precise", [0, 2])
+def test_story_sdxl_fullsize_write_then_read_matches_oracle_fixture(dev, golden_dir, precise):
     """BASELINE configs[2]'s actual arithmetic at a BASELINE size (VERDICT r4 missing #2): SDXL UNet at the 64^2 latent, CFG batch 8,
     FreeU(0.6, 0.4, 1.1, 1.2), consistent self-attention on the 36 up-block processors in its masked branch at cur_step = 5 -- the WRITE
     evaluation (Comic_Generation.py:94-118, 440), then the READ evaluation at CFG batch 2 against the bank it left (:104-109) --
@@ -332,7 +336,8 @@ def test_story_sdxl_fullsize_write_then_read_matches_oracle_fixture(dev, golden_
     assert abs(float(inp["write"]["x"].double().sum()) - float(fx["x_write_sum"])) < 1e-6
     assert abs(float(inp["read"]["x"].double().sum()) - float(fx["x_read_sum"])) < 1e-6
     ocfg = UNetCfg.sdxl()
-    eng = UNetEngine(UNetConfig(**ocfg.__dict__), random_unet_weights(ocfg, seed=int(fx["weights_seed"])), dev, dtype=torch.float16, stream32=True)
+    eng = UNetEngine(UNetConfig(**ocfg.__dict__), random_unet_weights(ocfg, seed=int(fx["weights_seed"])), dev, dtype=torch.float16, stream32=True,
+                     precise=precise)
     eng.freeu = tuple(float(v) for v in fx["freeu"])
     ui = iter(inp["uniforms"])
     st = StoryState(total_count=ConsistentSelfAttention.count_processors(eng), height=mk.HH, width=mk.WW, coin=lambda: 0.95,
@@ -345,14 +350,15 @@ def test_story_sdxl_fullsize_write_then_read_matches_oracle_fixture(dev, golden_
         c = inp[phase]
         st.write, st.cur_step, st.attn_count = phase == "write", int(fx["step"]), 0
         eng.prepare(torch.tensor([int(c["t"])]), c["enc"].to(dev), dict(text_embeds=c["text_embeds"], time_ids=c["time_ids"]))
-        e = eng.step(c["x"].permute(0, 2, 3, 1).contiguous().to(dev).half(), 0)
+        xin = c["x"].permute(0, 2, 3, 1).contiguous().to(dev)
+        e = eng.step(xin if precise else xin.half(), 0)          # precise: the un-rounded fp32 latents, as unet.denoise hands them over
         rels[phase] = _rel(e.permute(0, 3, 1, 2), torch.from_numpy(fx[phase]))
     eff = float(fx["consistent_effect"])
-    print(f"MEASURED fullsize story sdxl (CFG 8, FreeU, consistent SA) f16+stream32 write={rels['write']:.5f} read={rels['read']:.5f} "
+    print(f"MEASURED fullsize story sdxl (CFG 8, FreeU, consistent SA) f16+stream32 precise={precise} write={rels['write']:.5f} read={rels['read']:.5f} "
           f"(the masked attention moves the write evaluation by {eff:.3f})")
     assert eff > 10 * max(rels.values()), "the fixture must tell the consistent path from plain attention"
     for k, v in rels.items():
-        assert v < 2.2e-3, (k, v)          # the plain SDXL evaluation in this mode measures 1.50 - 1.56e-3 (+ the masked attention sites)
+        assert v < STORY_BOUND[precise], (k, v)          # the plain SDXL evaluation measures 1.50 - 1.56e-3 at level 0 (+ the masked attention sites)
     del eng
     _free()
 
