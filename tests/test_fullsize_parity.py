@@ -80,7 +80,7 @@ def test_sd15_unet_step_fullsize_matches_oracle(dev, sd15_case, dtype, stream32)
 
 PRECISE_BOUND = 1.0e-3          # north_star's bound itself
 # measured on MI355X (round 5), one evaluation / whole loop: SD-v1.5 5.4e-4 / 5.7e-4 (level 1), 4.0e-4 (level 2); SDXL 1.27e-3 (level 1:
-# its error sits in the 70 transformer blocks), 7.7e-4 / 6.1e-4 (level 2); zeroscope 8.0e-4 (level 1), 5.7e-4 / 7.9e-4 (level 2)
+# its error sits in the 70 transformer blocks), 7.7e-4 / 6.5e-4 (level 2); zeroscope 8.0e-4 (level 1), 5.7e-4 / 8.0e-4 (level 2)
 SDXL_PRECISE_BOUND = {1: 1.55e-3, 2: PRECISE_BOUND}
 ZS_PRECISE_BOUND = {1: 1.25e-3, 2: PRECISE_BOUND}
 
