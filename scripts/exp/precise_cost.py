@@ -1,6 +1,6 @@
 """Round 5: what the precise modes cost -- ms per graph-replayed evaluation of each diffusion UNet at its BASELINE size, f16, for
 stream32 / precise=1 / precise=2 (UNetEngine / UNet3DEngine). Alternating rounds in one process, median of 5."""
-import sys, time
+import os, sys, time
 import torch
 from spider_amd.unet import UNetConfig, UNetEngine
 from spider_amd.unet3d import UNet3DConfig, UNet3DEngine
@@ -9,7 +9,10 @@ dev = torch.device("cuda:0")
 which = sys.argv[1:] or ["sd15", "sdxl", "zeroscope"]
 
 
-def bench(make, prep, xs, modes=(0, 1, 2)):
+MODES = tuple(int(m) for m in os.environ.get("PRECISE_MODES", "0,1,2").split(","))      # (a subset: quick A/B of one mode)
+
+
+def bench(make, prep, xs, modes=MODES):
     engs = {}
     for m in modes:
         e = make(m)
@@ -51,5 +54,5 @@ for name in which:
         x32 = torch.randn(2 * 16, 40, 72, 4, generator=g, device=dev)
         r = bench(lambda m: UNet3DEngine.random_init(cfg, dev, seed=1, dtype=torch.float16, stream32=True, precise=m),
                   lambda e: e.prepare(torch.tensor([500]), enc, frames=16), {False: x32.half(), True: x32})
-    print(f"{name:10s} ms per evaluation: stream32 {r[0]:.3f}   precise=1 {r[1]:.3f} ({r[1] / r[0]:.2f}x)   precise=2 {r[2]:.3f} ({r[2] / r[0]:.2f}x)", flush=True)
+    print(f"{name:10s} ms per evaluation: " + "   ".join((f"stream32 {r[m]:.3f}" if m == 0 else f"precise={m} {r[m]:.3f}" + (f" ({r[m] / r[0]:.2f}x)" if 0 in r else "")) for m in MODES), flush=True)
     torch.cuda.empty_cache()

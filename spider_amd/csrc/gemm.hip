@@ -69,6 +69,7 @@ struct GemmArgs {
     // 5 vector instructions instead of ~25 in the issue slot between two barriers of the LDS-DMA kernels.
     int hbits;
     int dbg;   // tuning aid (SPIDER_GEMM_DBG): 1 = DMA only, 2 = compute only (results are garbage)
+    int epi_lds;   // LDS-DMA kernel: the block's output tile goes through LDS and leaves in row order (epilogue_lds below)
     // tile order: 0 = m fastest (neighbouring blocks share a W tile: LLM prefill, W >> A), 1 = n fastest (they share the A tile:
     // the UNet's 8192-row activations against 320..2560 output columns -- with m fastest every column tile re-streamed all of A
     // through its XCD's 4 MiB L2: FETCH_SIZE 58 MB per GEGLU projection whose operands are 7 MB)
@@ -954,6 +955,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Row-order epilogue of the LDS-DMA kernel (splits == 1, EPI <= 1, no producer statistics). In the accumulator layout a lane owns 4
+// (8 after the pair exchange) consecutive columns of 16 different rows: one store instruction of a wave touches 16 rows with 64 B
+// (16-bit output) or 4 x 16 B at a 32-byte stride (the fp32 master c32d / the fp32 residual res32) in each -- every 128-byte line of
+// the output is written in pieces by several instructions. On the store-heavy linears of the tall maps (92160 x 320 x 320 + res32 +
+// c32d: 354 MB of HBM traffic for 19 GFLOP) that pattern, not the K loop, sets the time: 2.9 TB/s whatever the tile. Here the block
+// stages its BM x BN fp32 tile in the (now free) operand ring, half the rows at a time, and the 512 threads walk it in row order --
+// consecutive lanes hold consecutive 16-byte chunks of a row, so a wave's access is 1 KiB (fp32) / 512 B (16-bit) of contiguous bytes.
+// Staging image: row stride BN + 4 floats (656 / 528 / 272 B = 144 / 16 / 16 mod 256: the 16 rows of a 16-lane group fall into 16
+// distinct 16-byte bank slots for ds_write_b128; the row-order reads are linear).
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int MT, int NT, bool ACT>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[MT][NT], char* smem, int m0, int n0, int wm, int wn) {
+    constexpr int LDT = BN + 4, HR = BM / 2, CH = BN / 4;
+    float* T = reinterpret_cast<float*>(smem);
+    const EpiRsrc er = make_epi_rsrc(p);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                      // pass 0: every wave has finished its fragment reads of the ring; pass 1: the rows are out
+        if ((wm >> 1) == pass) {
+            float* tw = T + ((wm & 1) * (BM / 4) + r16) * LDT + wn * (BN / 2) + 4 * g;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(tw + i * 16 * LDT + j * 16) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (HR * CH + 511) / 512; ++it) {
+            const int idx = it * 512 + tid;
+            if ((HR * CH) % 512 != 0 && idx >= HR * CH) break;
+            const int row = idx / CH, c4 = idx - row * CH;
+            const int m = m0 + pass * HR + row, n = n0 + c4 * 4;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(T + row * LDT + c4 * 4);
+            float v[4] = {q[0], q[1], q[2], q[3]};
+            uint32_t rb_row = 0;
+            if (p.rowbias) rb_row = (uint32_t)((m < p.M ? m : 0) / p.rows_per_group) * (uint32_t)p.N * 2u;
+            epilogue_fast<ACT>(p, er, m, n, rb_row, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the large problems: 128 x BN x 64 tiles (BN = 160 or 128), 512 threads = 8 waves (4 along M x 2
 // along N, wave tile 32 x BN/2), ONE block per CU. Operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`,
 // no VGPR staging, no ds_write pass) into a ring of NS stages; the prefetch of tiles kt+1 .. kt+NS-1 stays in flight
@@ -975,8 +1020,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// NS = 2 (one K tile of look-ahead, 72 KiB of LDS at 128 x 160): TWO blocks per CU. For the short-K, store-heavy linears of the
+// 16-frame video maps (92160 x 320 x 320 with an fp32 residual read and an fp32 master written beside the 16-bit output: 354 MB of HBM
+// traffic for 19 GFLOP) a block is prologue + 5 K tiles + a long epilogue; a second resident block runs its loads / MFMAs under the
+// first one's epilogue stores.
 template <int BN, int NS, bool CONV, int EPI, int BM = 128, bool GN = false>
-__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_dma_kernel(GemmArgs p) {
     // BM = 128: wave tile 32 x BN/2. BM = 64 (wave tile 16 x BN/2): twice the row tiles for problems whose 128-row tiling leaves
     // the chip half empty -- the UNet's 3x3 convs at 8192 rows then need no split-K, i.e. no fp32 slab round trip through HBM
     // (42 MB written + re-read per conv against a 5 MB output) and no reduce launch.
@@ -1174,6 +1223,12 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(GemmArgs p) {
     wait_vmcnt<0>();                            // the masked tail DMAs must not outlive the workgroup's LDS allocation
 
     if (!GN) {
+        if constexpr (EPI <= 1) {
+            if (p.epi_lds && p.splits == 1) {           // block-uniform
+                epilogue_lds<BM, BN, MT, NT, EPI == 1>(p, acc, smem, m0, n0, wm, wn);
+                return;
+            }
+        }
         write_out<MT, NT, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), split, lane);
         return;
     }
@@ -2322,6 +2377,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     if (gn_done) *gn_done = 0;
     static const int dbg = env_int("SPIDER_GEMM_DBG");
     a.dbg = dbg;
+    static const int epi_lds_env = getenv("SPIDER_EPI_LDS") ? atoi(getenv("SPIDER_EPI_LDS")) : 1;      // tuning aid: 0 = fragment-order stores, 2 = on every LDS-DMA launch
     if (a.w_tiled == 2) {
         // weight-stationary streaming conv: strips of 32 columns x K splits of whole 32-channel blocks, ~200-256 blocks of 8 waves
         const int WK = a.M <= 128 ? 8 : 2;
@@ -2383,7 +2439,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     // SPIDER_GEMM_TILE = 160 / 161 (4-stage ring) / 129 (128 x 128 DMA tile): force the LDS-DMA kernel (tuning aid)
     static const int nfast_env = getenv("SPIDER_GEMM_NFAST") ? atoi(getenv("SPIDER_GEMM_NFAST")) : -1;
     a.n_fast = nfast_env >= 0 ? nfast_env : (a.M > ncols ? 1 : 0);
-    int dma_bn = (force_tile == 160 || force_tile == 161) ? 160 : (force_tile == 129 ? 128 : (force_tile == 65 ? 64 : 0));
+    int dma_bn = (force_tile == 160 || force_tile == 161 || force_tile == 162) ? 160 : (force_tile == 129 ? 128 : (force_tile == 65 ? 64 : 0));
+    bool dma_ns2 = force_tile == 162;          // 2-stage ring, two blocks per CU (linears only)
     // Measured on MI355X (scripts/bench_gemm.py with GEMM_CFGS): with >= 2048 rows and >= 16 K tiles the LDS-DMA kernel wins
     // (UNet convs at 64^2 / 32^2: 33 vs 46 us, 48 vs 70, 32 vs 43, 47 vs 64; at 16^2 with 8 K splits 30 vs 41, 48 vs 63); below that the register-staged
     // tiles (more, smaller blocks) stay ahead, and at M = 1536 (LLM prefill) the two tie. Split K to ~256 blocks = 1 per CU.
@@ -2470,21 +2527,38 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
                            (!a.ln_colsum || (a.ws && ln_rows_bytes <= (size_t)ws_bytes && a.act == 0));
         const float epi = a.geglu ? 2.2f : 0.f;
         const float ln_pass = a.ln_colsum ? 3.f + (float)((double)a.M * a.K * 2.0 / 5.0e6) : 0.f;   // ln_row_stats_kernel: one read of A
+        // fp32 residual stream (res32 read / c32d written beside the 16-bit output): 4 + 4 extra bytes per output element leave in the
+        // block's epilogue -- ~6 us per stream and 128 x 160 tile in fragment order (fitted: 92160 x 320 x 320 + both streams 126 us
+        // on the LDS-DMA kernel against 49 us plain). Candidate 4 = the LDS-DMA kernel with a 2-stage ring, TWO blocks per CU and the
+        // row-order epilogue through LDS (epilogue_lds): fitted on scripts/exp/lin_tiles.py (13 shapes), 9 us + 9 us per stream per
+        // block, 1.06 us per K tile with two blocks sharing the CU; linears whose N fills 160-wide tiles only.
+        static const int ns2_env = getenv("SPIDER_GEMM_NS2") ? atoi(getenv("SPIDER_GEMM_NS2")) : 1;
+        const int nstream = (a.res32 ? 1 : 0) + (a.c32d ? 1 : 0);
+        const bool n160_fit = n160 * 160 * 25 <= a.N * 27;
         struct Cand { int bm, bn, slots; float t0, tk, pre; bool ok; };
-        const Cand cand[4] = {{256, 256, 256, 8.4f + epi, a.conv ? (a.hbits ? 1.47f : 1.67f) : 1.40f, ln_pass, p8_ok},
+        const Cand cand[5] = {{256, 256, 256, 8.4f + epi, a.conv ? (a.hbits ? 1.47f : 1.67f) : 1.40f, ln_pass, p8_ok},
                               {256, 128, 256, 7.0f, a.conv ? 0.98f : 0.78f, 0.f, p8_env && p8h_env && !fused && (!a.conv || a.hbits)},
                               {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
-                              {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true}};
+                              {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true},
+                              {128, 160, 512, 9.0f + 9.0f * (float)nstream, 1.06f, 0.f, ns2_env && !fused && !a.conv && n160_fit && a.N % 4 == 0}};
+        // (the four older candidates are ranked among themselves as they were fitted, without the stream term; candidate 4 then
+        // competes against the winner with the winner's stream cost added)
         int best = -1;
         float best_t = 0.f;
+        auto cost = [&](int i, bool with_stream) {
+            const long tiles_i = (long)((a.M + cand[i].bm - 1) / cand[i].bm) * ((ncols + cand[i].bn - 1) / cand[i].bn);
+            const float stream = (with_stream && i != 4) ? 6.0f * (float)nstream * (float)(cand[i].bm * cand[i].bn) / 20480.f : 0.f;
+            return cand[i].pre + (float)((tiles_i + cand[i].slots - 1) / cand[i].slots) * (cand[i].t0 + stream + (float)nk * cand[i].tk);
+        };
         for (int i = 0; i < 4; ++i) {
             if (!cand[i].ok) continue;
-            const long tiles_i = (long)((a.M + cand[i].bm - 1) / cand[i].bm) * ((ncols + cand[i].bn - 1) / cand[i].bn);
-            const float t = cand[i].pre + (float)((tiles_i + cand[i].slots - 1) / cand[i].slots) * (cand[i].t0 + (float)nk * cand[i].tk);
+            const float t = cost(i, false);
             if (best < 0 || t < best_t) { best = i; best_t = t; }
         }
+        if (cand[4].ok && (best < 0 || cost(4, true) < cost(best, true))) best = 4;
         use_p8 = best == 0; use_p8h = best == 1;
-        dma_bn = best == 2 ? 160 : 0; dma_bm = 128;
+        dma_bn = (best == 2 || best == 4) ? 160 : 0; dma_bm = 128;
+        dma_ns2 = best == 4;
         small = false; splits = 1; p8_splits = 1;
     }
     if (a.gna_part) { use_p8 = use_p8h = false; dma_bn = 0; small = true; splits = 1; }   // GroupNorm-on-A exists on the 64^2 register-staged kernel
@@ -2505,7 +2579,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     if (trace)
         fprintf(stderr, "spider_gemm_dispatch M=%d N=%d K=%d conv=%d(%dx%d s%d ups%d) geglu=%d ln=%d a32=%d -> %s splits=%d\n", a.M, a.N, a.K, a.conv,
                 a.kh, a.kw, a.stride, a.ups, a.geglu, a.ln_colsum != nullptr, a.a32,
-                use_p8h ? "p8h(256x128)" : use_p8 ? "p8(256x256)" : (dma_bn && !a.geglu) ? (dma_bm == 64 ? "dma(64x160)" : "dma(128x160)")
+                use_p8h ? "p8h(256x128)" : use_p8 ? "p8(256x256)" : (dma_bn && !a.geglu) ? (dma_ns2 && !a.conv ? "dma2(128x160, 2 per CU)" : dma_bm == 64 ? "dma(64x160)" : "dma(128x160)")
                                                                    : small ? "reg(64x64)" : "reg(128x128)", a.splits);
     if (use_p8h || (force_tile == 257 && !a.geglu && !a.ln_colsum)) {
         launch_p8h(a, st);
@@ -2522,7 +2596,11 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         // learns the chunking from it); otherwise, with split-K, the reduce below writes 16-row chunks
         if (a.gn_part && a.splits == 1) { a.gn_cr = 64; if (!(dma_bn == 160 && force_tile != 161 && dma_gn_ok(a))) a.gn_part = nullptr; }
         if (gn_done && a.gn_part && a.splits == 1) *gn_done = 64;     // launch_dma takes the GN instantiation
+        // row-order epilogue: pays with two blocks per CU (one's stores under the other's K loop) and fp32 streams to move; with one
+        // block per CU the extra LDS round trip and its four barriers cost more than the coalescing returns (136 vs 126 us)
+        a.epi_lds = epi_lds_env == 2 || (epi_lds_env == 1 && dma_ns2 && !a.conv && (a.res32 || a.c32d));
         if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
+        else if (dma_ns2 && !a.conv) launch_dma<160, 2>(a, tdma, st);
         else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
         else if (dma_bn == 160 && dma_bm == 64) launch_dma<160, 4, 64>(a, tdma, st);
         else if (dma_bn == 160) launch_dma<160, 3>(a, tdma, st);
