@@ -44,6 +44,12 @@ for case in cases:
         got = out[1] if kind else out.float()
         rel = float((got - ref).norm() / ref.norm())
         assert rel < (2e-5 if kind else 1e-3), (name, rel)
+    if kind in ("geglu", "geglu4"):
+        y = torch.nn.functional.layer_norm(A.float(), (K,)) @ W.float().T + b.float()
+        v, gt = y.chunk(2, -1)
+        ref = v * torch.nn.functional.gelu(gt)
+        rel = float((out.float() - ref).norm() / ref.norm())
+        assert rel < 4e-3, (name, rel)
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
         for _ in range(10):
