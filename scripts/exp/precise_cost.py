@@ -50,8 +50,9 @@ for name in which:
                   lambda e: e.prepare(torch.tensor([500]), enc, added), {False: x32.half(), True: x32})
     else:
         cfg = UNet3DConfig.zeroscope()
-        enc = torch.randn(2, 77, cfg.cross_dim, generator=g, device=dev).half()
-        x32 = torch.randn(2 * 16, 40, 72, 4, generator=g, device=dev)
+        caps = int(os.environ.get("VIDEO_CAPS", "1"))          # captions per call (SpiderDecoder.generate_batch batches them)
+        enc = torch.randn(2 * caps, 77, cfg.cross_dim, generator=g, device=dev).half()
+        x32 = torch.randn(2 * caps * 16, 40, 72, 4, generator=g, device=dev)
         r = bench(lambda m: UNet3DEngine.random_init(cfg, dev, seed=1, dtype=torch.float16, stream32=True, precise=m),
                   lambda e: e.prepare(torch.tensor([500]), enc, frames=16), {False: x32.half(), True: x32})
     print(f"{name:10s} ms per evaluation: " + "   ".join((f"stream32 {r[m]:.3f}" if m == 0 else f"precise={m} {r[m]:.3f}" + (f" ({r[m] / r[0]:.2f}x)" if 0 in r else "")) for m in MODES), flush=True)
