@@ -871,3 +871,47 @@ def test_wstream_graph_replay_is_bit_identical(dev, monkeypatch):
         gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+# ------------------------------------------------------------------------------------------ tall store-heavy linears (round 5)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,streams,extras", [
+    # (shapes the cost model sends to the two-blocks-per-CU kernel: checked with SPIDER_GEMM_TRACE=1, gpurun_out/r05_tall_dispatch.txt)
+    (92160, 320, 320, "both", True),         # the zeroscope shape: + bias + rowbias + activation + out_scale, row-order epilogue through LDS
+    (92160 + 40, 320, 640, "both", False),   # ragged last row tile (rows past M are masked in the row-order pass)
+    (65536, 320, 320, "res32", False),       # SD-v1.5 at CFG batch 16
+    (32768, 320, 1280, "c32d", False),
+    (65536, 640, 640, "both", False),        # 4 column tiles
+    (92160, 320, 320, "none", True),         # no fp32 stream: fragment-order stores on the same kernel
+    # (and neighbours that stay on the older kernels)
+    (16384, 320, 320, "both", False),
+    (20000, 480, 192, "both", False),        # K not a multiple of 64 (zero-filled tail chunks), 3 column tiles
+])
+def test_tall_linears_on_the_two_blocks_per_cu_kernel(ops, dev, dt, M, N, K, streams, extras):
+    """gemm_dma_kernel<160, 2> + epilogue_lds (csrc/gemm.hip): chosen by the tall-problem cost model for >= 16384 rows and N in 160-wide
+    tiles. fp32 output (c32d) at accumulation distance from the fp64 reference; the 16-bit output is that value rounded once."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt)
+    b = torch.randn(N, generator=g).to(dt)
+    kw, ref = {}, A.double() @ W.double().T + b.double()
+    if extras:
+        G = 16
+        rb = torch.randn(G, N, generator=g).to(dt)
+        kw = dict(rowbias=rb.to(dev), rows_per_group=M // G, act="silu", out_scale=0.5)
+        ref = F.silu(ref + rb.double().repeat_interleave(M // G, 0))
+    r32 = torch.randn(M, N, generator=g)
+    if streams in ("both", "res32"):
+        kw["res32"] = r32.to(dev)
+        ref = ref + r32.double()
+    if extras:
+        ref = ref * 0.5
+    want32 = streams in ("both", "c32d")
+    out = ops.gemm(A.to(dev), W.to(dev), bias=b.to(dev), want32=want32, **kw)
+    y, y32 = (out if want32 else (out, None))
+    ulp = 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
+    rel = lambda t: float((t.double().cpu() - ref).norm() / ref.norm())
+    assert rel(y) < ulp, (rel(y), ulp)
+    if y32 is not None:
+        assert rel(y32) < 3e-6, rel(y32)                                   # fp32 accumulation over K <= 1280
+        assert torch.equal(y.cpu(), y32.cpu().to(dt))                      # C is c32d rounded once
