@@ -2310,7 +2310,7 @@ void launch_dma(const GemmArgs& a, int tiles, hipStream_t st) {
     dim3 grid(tiles, a.splits);
     const bool fast_ok = a.C && !a.C32 && a.N % 4 == 0 && a.c_bytes != 0;
     const int epi = !fast_ok ? 3 : (a.act ? 1 : 0);
-    if constexpr (BN == 160 && (NS == 3 || (NS == 4 && BM == 64))) {
+    if constexpr (BN == 160 && (NS == 2 || NS == 3 || (NS == 4 && BM == 64))) {
         if (dma_gn_ok(a)) { launch_dma_gn<BN, NS, BM>(a, grid, st); return; }
     }
     if (a.conv) {
@@ -2531,7 +2531,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         // block's epilogue -- ~6 us per stream and 128 x 160 tile in fragment order (fitted: 92160 x 320 x 320 + both streams 126 us
         // on the LDS-DMA kernel against 49 us plain). Candidate 4 = the LDS-DMA kernel with a 2-stage ring, TWO blocks per CU and the
         // row-order epilogue through LDS (epilogue_lds): fitted on scripts/exp/lin_tiles.py (13 shapes), 9 us + 9 us per stream per
-        // block, 1.06 us per K tile with two blocks sharing the CU; linears whose N fills 160-wide tiles only.
+        // block, 1.06 us per K tile with two blocks sharing the CU (convs 1.2: scripts/exp/conv_tiles.py, tconv_tiles.py -- 92160 x 320
+        // 3 x 3: 253 -> 207 us, (3,1,1): 120 -> 91, 65536 x 320 3 x 3: 148 -> 126); N must fill 160-wide tiles.
         static const int ns2_env = getenv("SPIDER_GEMM_NS2") ? atoi(getenv("SPIDER_GEMM_NS2")) : 1;
         const int nstream = (a.res32 ? 1 : 0) + (a.c32d ? 1 : 0);
         const bool n160_fit = n160 * 160 * 25 <= a.N * 27;
@@ -2540,7 +2541,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
                               {256, 128, 256, 7.0f, a.conv ? 0.98f : 0.78f, 0.f, p8_env && p8h_env && !fused && (!a.conv || a.hbits)},
                               {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
                               {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true},
-                              {128, 160, 512, 9.0f + 9.0f * (float)nstream, 1.06f, 0.f, ns2_env && !fused && !a.conv && n160_fit && a.N % 4 == 0}};
+                              {128, 160, 512, 9.0f + 9.0f * (float)nstream, a.conv ? 1.2f : 1.06f, 0.f, ns2_env && !fused && n160_fit && a.N % 4 == 0}};
         // (the four older candidates are ranked among themselves as they were fitted, without the stream term; candidate 4 then
         // competes against the winner with the winner's stream cost added)
         int best = -1;
@@ -2579,7 +2580,7 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
     if (trace)
         fprintf(stderr, "spider_gemm_dispatch M=%d N=%d K=%d conv=%d(%dx%d s%d ups%d) geglu=%d ln=%d a32=%d -> %s splits=%d\n", a.M, a.N, a.K, a.conv,
                 a.kh, a.kw, a.stride, a.ups, a.geglu, a.ln_colsum != nullptr, a.a32,
-                use_p8h ? "p8h(256x128)" : use_p8 ? "p8(256x256)" : (dma_bn && !a.geglu) ? (dma_ns2 && !a.conv ? "dma2(128x160, 2 per CU)" : dma_bm == 64 ? "dma(64x160)" : "dma(128x160)")
+                use_p8h ? "p8h(256x128)" : use_p8 ? "p8(256x256)" : (dma_bn && !a.geglu) ? (dma_ns2 ? "dma2(128x160, 2 per CU)" : dma_bm == 64 ? "dma(64x160)" : "dma(128x160)")
                                                                    : small ? "reg(64x64)" : "reg(128x128)", a.splits);
     if (use_p8h || (force_tile == 257 && !a.geglu && !a.ln_colsum)) {
         launch_p8h(a, st);
@@ -2598,9 +2599,10 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         if (gn_done && a.gn_part && a.splits == 1) *gn_done = 64;     // launch_dma takes the GN instantiation
         // row-order epilogue: pays with two blocks per CU (one's stores under the other's K loop) and fp32 streams to move; with one
         // block per CU the extra LDS round trip and its four barriers cost more than the coalescing returns (136 vs 126 us)
-        a.epi_lds = epi_lds_env == 2 || (epi_lds_env == 1 && dma_ns2 && !a.conv && (a.res32 || a.c32d));
+        const bool ns2 = dma_ns2;
+        a.epi_lds = epi_lds_env == 2 || (epi_lds_env == 1 && ns2 && (a.res32 || a.c32d));
         if (dma_bn == 64) launch_dma<64, 6>(a, tdma, st);
-        else if (dma_ns2 && !a.conv) launch_dma<160, 2>(a, tdma, st);
+        else if (ns2) launch_dma<160, 2>(a, tdma, st);
         else if (force_tile == 161) launch_dma<160, 4>(a, tdma, st);
         else if (dma_bn == 160 && dma_bm == 64) launch_dma<160, 4, 64>(a, tdma, st);
         else if (dma_bn == 160) launch_dma<160, 3>(a, tdma, st);
