@@ -8,7 +8,9 @@ dev = torch.device("cuda:0")
 tile = os.environ.get("SPIDER_GEMM_TILE", "auto")
 streams = os.environ.get("STREAMS", "0") != "0"
 g = torch.Generator(device=dev).manual_seed(0)
-for B, H, W, Cin, Cout in ((32, 40, 72, 320, 320), (32, 40, 72, 640, 320), (32, 20, 36, 640, 640), (32, 20, 36, 1280, 640), (16, 64, 64, 320, 320), (16, 32, 32, 640, 640)):
+SHAPES = {"v3d": ((32, 40, 72, 320, 320), (32, 40, 72, 640, 320), (32, 20, 36, 640, 640), (32, 20, 36, 1280, 640), (16, 64, 64, 320, 320), (16, 32, 32, 640, 640)),
+          "sdxl": ((8, 96, 96, 320, 320), (8, 96, 96, 640, 320), (8, 48, 48, 640, 640), (8, 48, 48, 1280, 640), (8, 24, 24, 1280, 1280), (4, 64, 64, 320, 320))}
+for B, H, W, Cin, Cout in SHAPES[os.environ.get("CONV_SHAPES", "v3d")] + ((32, 40, 72, 320, 320), )[:0]:
     x = torch.randn(B, H, W, Cin, device=dev, generator=g).half()
     w = (torch.randn(Cout, 3, 3, Cin, device=dev, generator=g) * (9 * Cin) ** -0.5).half()
     b = torch.randn(Cout, device=dev, generator=g).half()

@@ -2536,12 +2536,17 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         static const int ns2_env = getenv("SPIDER_GEMM_NS2") ? atoi(getenv("SPIDER_GEMM_NS2")) : 1;
         const int nstream = (a.res32 ? 1 : 0) + (a.c32d ? 1 : 0);
         const bool n160_fit = n160 * 160 * 25 <= a.N * 27;
+        // wider convs (N = 640): measured - 11 % (16384 rows: 512 tiles, one full round), - 5 % (23040: 1.4 rounds), + 24 % (18432: 1.125
+        // rounds -- the 64 blocks past the full round cost a block time of their own): only with a full or well-filled last round
+        const long ns2_tiles = (long)((a.M + 127) / 128) * n160;
+        const bool ns2_tail_ok = ns2_tiles % 512 == 0 || ns2_tiles % 512 >= 205;
         struct Cand { int bm, bn, slots; float t0, tk, pre; bool ok; };
         const Cand cand[5] = {{256, 256, 256, 8.4f + epi, a.conv ? (a.hbits ? 1.47f : 1.67f) : 1.40f, ln_pass, p8_ok},
                               {256, 128, 256, 7.0f, a.conv ? 0.98f : 0.78f, 0.f, p8_env && p8h_env && !fused && (!a.conv || a.hbits)},
                               {128, 160, 256, 5.5f, 0.68f, 0.f, !fused},
                               {128, 128, 512, 5.7f + epi, 1.0f, 0.f, true},
-                              {128, 160, 512, 9.0f + 9.0f * (float)nstream, a.conv ? 1.2f : 1.06f, 0.f, ns2_env && !fused && n160_fit && a.N % 4 == 0}};
+                              {128, 160, 512, 9.0f + 9.0f * (float)nstream, a.conv ? 1.2f : 1.06f, 0.f,
+                               ns2_env && !fused && n160_fit && a.N % 4 == 0 && (!a.conv || n160 <= 2 || ns2_tail_ok)}};
         // (the four older candidates are ranked among themselves as they were fitted, without the stream term; candidate 4 then
         // competes against the winner with the winner's stream cost added)
         int best = -1;
@@ -2549,7 +2554,11 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         auto cost = [&](int i, bool with_stream) {
             const long tiles_i = (long)((a.M + cand[i].bm - 1) / cand[i].bm) * ((ncols + cand[i].bn - 1) / cand[i].bn);
             const float stream = (with_stream && i != 4) ? 6.0f * (float)nstream * (float)(cand[i].bm * cand[i].bn) / 20480.f : 0.f;
-            return cand[i].pre + (float)((tiles_i + cand[i].slots - 1) / cand[i].slots) * (cand[i].t0 + stream + (float)nk * cand[i].tk);
+            float rounds = (float)((tiles_i + cand[i].slots - 1) / cand[i].slots);
+            // two blocks per CU: the blocks of a partial last round have their CU to themselves and finish early -- whole rounds
+            // over-charge it (73728 x 320 3 x 3: 2.25 rounds, 179 us against 206 on the one-block kernel; charged 3 it loses on paper)
+            if (i == 4) rounds = 0.5f * (rounds + (float)tiles_i / (float)cand[i].slots);
+            return cand[i].pre + rounds * (cand[i].t0 + stream + (float)nk * cand[i].tk);
         };
         for (int i = 0; i < 4; ++i) {
             if (!cand[i].ok) continue;
