@@ -7,7 +7,7 @@ tile = os.environ.get("SPIDER_GEMM_TILE", "auto")
 M = int(os.environ.get("LIN_M", "92160"))
 g = torch.Generator(device=dev).manual_seed(0)
 EXTRA = os.environ.get("LIN_EXTRA", "0") != "0"
-cases = [("attn out / proj 320->320 + res32 + c32d", 320, 320, "res32"), ("plain 320->320", 320, 320, None),
+cases = [("attn out / proj 320->320 + res32 + c32d", 320, 320, "res32"), ("plain 320->320", 320, 320, None), ("plain 320->960 (qkv without the LN fold)", 960, 320, None),
          ("ln qkv 320->960", 960, 320, "ln"), ("ff out 1280->320 + res32 + c32d", 320, 1280, "res32"), ("ln geglu 320->2x1280", 2560, 320, "geglu"),
          ("640: attn out 640->640 + res32", 640, 640, "res32q"), ("640: ln geglu 640->2x2560", 5120, 640, "geglu4")]
 if EXTRA:      # (rows, N, K, fp32 streams): the other residual / plain linears of the video and batched image UNets
