@@ -280,7 +280,9 @@ class Responder:
             res = self.infer.submit(inputs=self.request(B))
         self.overlap_ms = self.infer.last_pass_ms or None
         self.stage = self.decoder.stage_ms_device()
-        self.step_log.append({**(self.infer.last_pass_ms or {}), **self.infer.host_ms})
+        ms = torch.cuda.memory_stats(self.dev)       # segments the caching allocator took from / gave back to the driver so far
+        self.step_log.append({**(self.infer.last_pass_ms or {}), **self.infer.host_ms,
+                              "device_allocs": ms.get("num_device_alloc", 0), "device_frees": ms.get("num_device_free", 0)})
         return self.pack(res, B)
 
 
@@ -853,6 +855,10 @@ def step_statistics(resp):
     steps, so one odd step cannot describe the run."""
     walls, log = getattr(resp, "step_wall_ms", []), list(getattr(resp, "step_log", []))
     out = {"step_wall_ms": _dist4(walls)}
+    if log and len(log) == len(walls) and len(walls) <= 32:      # every timed step: wall, the two device spans, host time of generate
+        out["steps"] = [[round(w, 1), r.get("llm_pass_ms"), r.get("decoder_pass_ms"), r.get("llm_generate_host_ms"), r.get("device_allocs"),
+                         r.get("device_frees")] for w, r in zip(walls, log)]
+        out["steps_columns"] = ["wall_ms", "llm_pass_ms", "decoder_pass_ms", "llm_generate_host_ms", "device_allocs_so_far", "device_frees_so_far"]
     keys = sorted({k for r in log for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)})
     out["per_step_median"] = {k: _dist4([r[k] for r in log if k in r])["median"] for k in keys}
     if log and len(log) == len(walls):
