@@ -438,7 +438,7 @@ def measure_roofline(resp, device):
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode_hbm.json")
         if os.path.exists(pm) and bytes_alg == 271633408:
             try:
@@ -460,7 +460,7 @@ def measure_roofline(resp, device):
 def _unet_pmc_traffic(kernel_prefix):
     """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r0N_pmc_unet_hbm.json:
     averages over every launch of that kernel in the UNet step, not only the roofline shape -- stated in `traffic_source`)."""
-    for tag in ("r04", "r03", "r02"):          # newest committed counter pass first
+    for tag in ("r05", "r04", "r03", "r02"):          # newest committed counter pass first
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_unet_hbm.json")
         try:
             for k in json.load(open(pm))["kernels"]:
