@@ -9,7 +9,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 EXTRA = os.environ.get("LIN_EXTRA", "0") != "0"
 cases = [("attn out / proj 320->320 + res32 + c32d", 320, 320, "res32"), ("plain 320->320", 320, 320, None), ("plain 320->960 (qkv without the LN fold)", 960, 320, None),
          ("ln qkv 320->960", 960, 320, "ln"), ("ff out 1280->320 + res32 + c32d", 320, 1280, "res32"), ("ln geglu 320->2x1280", 2560, 320, "geglu"),
-         ("640: attn out 640->640 + res32", 640, 640, "res32q"), ("640: ln geglu 640->2x2560", 5120, 640, "geglu4")]
+         ("640: attn out 640->640 + res32", 640, 640, "res32q"), ("640: ln geglu 640->2x2560", 5120, 640, "geglu4"), ("640: ln qkv 640->1920", 1920, 640, "lnq")]
 if EXTRA:      # (rows, N, K, fp32 streams): the other residual / plain linears of the video and batched image UNets
     cases = [(f"{K}->{N} rows {r}" + (" + res32 + c32d" if f else ""), N, K, ("res32x" if f else "plainx"), r)
              for r, N, K, f in ((92160, 320, 1280, False), (92160, 320, 640, True), (23040, 640, 640, False), (23040, 640, 2560, True),
@@ -17,7 +17,8 @@ if EXTRA:      # (rows, N, K, fp32 streams): the other residual / plain linears 
                                 (65536, 320, 1280, True), (16384, 640, 640, True), (16384, 640, 2560, True), (8192, 320, 320, True), (8192, 320, 1280, True))]
 for case in cases:
     name, N, K, kind = case[:4]
-    m = M // 4 if kind in ("res32q", "geglu4") else (case[4] if len(case) > 4 else M)
+    m = M // 4 if kind in ("res32q", "geglu4", "lnq") else (case[4] if len(case) > 4 else M)
+    if kind == "lnq": kind = "ln"
     if kind == "res32x": kind = "res32"
     if kind == "plainx": kind = None
     A = torch.randn(m, K, device=dev, generator=g).half()
@@ -44,6 +45,10 @@ for case in cases:
         got = out[1] if kind else out.float()
         rel = float((got - ref).norm() / ref.norm())
         assert rel < (2e-5 if kind else 1e-3), (name, rel)
+    if kind == "ln":
+        ref = torch.nn.functional.layer_norm(A.float(), (K,)) @ W.float().T
+        rel = float((out.float() - ref).norm() / ref.norm())
+        assert rel < 2e-3, (name, rel)
     if kind in ("geglu", "geglu4"):
         y = torch.nn.functional.layer_norm(A.float(), (K,)) @ W.float().T + b.float()
         v, gt = y.chunk(2, -1)
