@@ -15,7 +15,10 @@ if EXTRA:      # (rows, N, K, fp32 streams): the other residual / plain linears 
              for r, N, K, f in ((92160, 320, 1280, False), (92160, 320, 640, True), (23040, 640, 640, False), (23040, 640, 2560, True),
                                 (23040, 640, 1280, True), (5760, 1280, 1280, True), (5760, 1280, 5120, True), (65536, 320, 320, True),
                                 (65536, 320, 1280, True), (16384, 640, 640, True), (16384, 640, 2560, True), (8192, 320, 320, True), (8192, 320, 1280, True))]
+ONLY = os.environ.get("LIN_ONLY")          # substring of a case name: run only the cases that contain it (counter passes)
 for case in cases:
+    if ONLY and ONLY not in case[0]:
+        continue
     name, N, K, kind = case[:4]
     m = M // 4 if kind in ("res32q", "geglu4", "lnq") else (case[4] if len(case) > 4 else M)
     if kind == "lnq": kind = "ln"
@@ -34,7 +37,7 @@ for case in cases:
         byt = m * K * 2 + m * N * 2
     elif kind in ("geglu", "geglu4"):
         fold = ops.fold_layernorm(W, torch.ones(K, device=dev).half(), torch.zeros(K, device=dev).half(), b)
-        f = lambda: ops.gemm_ln(A, *fold, act="geglu")
+        f = lambda: ops.gemm_ln(A, *fold, act=os.environ.get("GEGLU_ACT", "geglu"))
         byt = m * K * 2 + m * (N // 2) * 2
     else:
         f = lambda: ops.gemm(A, W, bias=b)
