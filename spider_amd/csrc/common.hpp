@@ -173,6 +173,7 @@ inline void raise_dynamic_lds(F* fn, int bytes, unsigned& done_mask) {
 
 // ---- error plumbing shared by the C-ABI translation units ----
 extern "C" void spider_set_error(const char* msg);
+extern "C" int g_spider_ws_inlaunch;      // capi.cpp: split-K combine form of the streaming conv (spider_set_ws_inlaunch)
 #define SPIDER_CHECK(cond, msg)            \
     do {                                   \
         if (!(cond)) {                     \

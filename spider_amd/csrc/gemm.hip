@@ -2397,8 +2397,8 @@ int launch(GemmArgs a, long ws_bytes, void* stream, int* gn_done = nullptr) {
         a.kt_per_split = 0;
         // in-launch combine by the last-arriving block of a strip: its arrival counters are the 4096 bytes BEHIND the declared
         // workspace (zero when idle; contract of w_tiled = 2, see spider_hip.h)
-        static const int inl_env = getenv("SPIDER_WS_INLAUNCH") ? atoi(getenv("SPIDER_WS_INLAUNCH")) : 1;
-        a.ws_cnt = (inl_env && S > 1 && S <= 8 && strips <= 1024) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.ws) + ws_bytes) : nullptr;
+        if (g_spider_ws_inlaunch < 0) g_spider_ws_inlaunch = getenv("SPIDER_WS_INLAUNCH") ? (atoi(getenv("SPIDER_WS_INLAUNCH")) != 0) : 1;
+        a.ws_cnt = (g_spider_ws_inlaunch && S > 1 && S <= 8 && strips <= 1024) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a.ws) + ws_bytes) : nullptr;
         dim3 grid(strips, S);
         if (a.M <= 128) launch_ws_inst<1, 8, false>(a, grid, st);
         else if (a.ups) launch_ws_inst<4, 2, true>(a, grid, st);

@@ -46,7 +46,9 @@ class workspace_scope:
     """`with ops.workspace_scope("llm"): ...` -- calls (and graph captures) inside the block use a split-K workspace of their own.
     Reuse of a workspace is stream-ordered, so work that runs on two streams AT ONCE must not share one: bench.py's two-stream
     schedule puts the LLM pass and the diffusion decoder in different scopes. A captured graph keeps the
-    workspace of the scope it was captured in."""
+    workspace of the scope it was captured in. The same holds for the WS_TAIL bytes behind a workspace (arrival counters of the
+    streaming conv's in-launch split-K combine: zero whenever no launch of that scope is in flight; two launches that overlapped on
+    one workspace would mix their tickets and their partial slabs)."""
 
     def __init__(self, name: str):
         self.name = name
@@ -141,6 +143,17 @@ def prebuild_tiled(weights, max_rows: int = 64 << 20) -> int:
 WS_ENABLE = _os.environ.get("SPIDER_WS", "1") != "0"      # tuning aid: 0 = the tile kernels serve every conv
 WS_INLAUNCH = _os.environ.get("SPIDER_WS_INLAUNCH", "1") != "0"
 WS_MAX_M = int(_os.environ.get("SPIDER_WS_MAX_M", "128"))   # output pixels up to which the streaming kernel is used (it exists up to 512)
+
+
+def set_ws_inlaunch(on: bool) -> bool:
+    """Switch the split-K combine form of the streaming conv at run time (library + this module's mirror of it, which decides whether
+    the producer-statistics entry point is used): True = inside the launch, False = partial slabs + reduce kernel. -> previous form.
+    Both forms sum the slabs in split order (bit-identical outputs); tests compare them in one process."""
+    global WS_INLAUNCH
+    prev = WS_INLAUNCH
+    _lib.load().spider_set_ws_inlaunch(int(bool(on)))
+    WS_INLAUNCH = bool(on)
+    return prev
 
 
 def repack_fm_conv(W: torch.Tensor) -> torch.Tensor:

@@ -111,7 +111,10 @@ class SpiderFreeInfer:
         for m in messages:
             c = m.get("content") if isinstance(m, dict) else None
             if isinstance(c, (list, tuple)):
-                n += sum(1 for it in c if isinstance(it, dict) and (it.get("type") == "image" or "image" in it))
+                # qwen_omni_utils.extract_vision_info takes an item as an image when it carries an "image" / "image_url" key or says so
+                # in its "type"
+                n += sum(1 for it in c if isinstance(it, dict) and
+                         ("image" in it or "image_url" in it or it.get("type") in ("image", "image_url")))
         return n
 
     def build_inputs_batch(self, conversations: List) -> dict:
@@ -129,10 +132,13 @@ class SpiderFreeInfer:
             tok.padding_side = "left"
         inputs = dict(self.processor(text=texts, audios=audios, images=images, videos=videos, return_tensors="pt", padding=True))
         # `images` is the flat list over all conversations: row i owns the next _n_images(conversation i) of them
+        counts = [self._n_images(conv) for conv in conversations]
+        if images is not None and sum(counts) != len(images):
+            raise ValueError(f"the conversations hold {sum(counts)} image items but process_mm_info returned {len(images)} images: "
+                             "rows and images would drift apart")
         per_row, k = [], 0
-        for conv in conversations:
-            n = self._n_images(conv)
-            per_row.append(images[k] if (images and n > 0 and k < len(images)) else None)
+        for n in counts:
+            per_row.append(images[k] if (images and n > 0) else None)
             k += n
         inputs["_images"] = per_row
         return inputs
@@ -249,10 +255,14 @@ class SpiderFreeInfer:
         """would this LLM pass capture a hipGraph (tower per grid_thw / audio lengths, decode step per row count) -- i.e. must it run
         alone? The engines answer from their own caches (values, evictions and resets included); a thinker without `would_capture`
         falls back to the shapes seen before."""
+        if lkey not in self._warm:           # never run by THIS caller (or reset_warm() since): alone, whatever the engines hold
+            return True
         wc = getattr(self.model, "would_capture", None)
         if wc is None:
-            return lkey not in self._warm
+            return False
+        # the key the real pass uses: generate(**inputs, **generate_kwargs) -- output_hidden_states / return_logits pick the decode graph
         kw = {k: v for k, v in inputs.items() if not k.startswith("_")}
+        kw.update({k: v for k, v in self.generate_kwargs.items() if k not in ("cache_set", "decode")})
         return bool(wc(cache_set=cache_set, decode=decode, **kw))
 
     def _dec_key(self, pending):
@@ -322,16 +332,18 @@ class SpiderFreeInfer:
             self._warm.add(lkey)
             self.last_pass_ms = {}
             return self._unbatch(out)
-        out, newpend, err = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
-        self._pending = newpend                       # the NEW request's LLM result survives a failed decoder pass of the old one
-        if err is not None:
-            raise err
+        out, newpend, err, lerr = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
+        # the old request's decoder pass has run (or failed) either way: it must never be decoded again. The NEW request's LLM result
+        # survives a failed decoder pass of the old one; a failed LLM pass leaves the pipeline empty.
+        self._pending = newpend
+        self._raise_step_errors(lerr, err, out)
         return self._unbatch(out)
 
     def _overlap(self, on_u, on_l):
         """run on_u() on the decoder stream from a helper host thread and on_l() on the LLM stream from this thread; both finished
-        (device included) on return. -> (result of on_u, result of on_l, the helper thread's exception or None): a failed decoder pass
-        must not lose the LLM result computed beside it -- the caller stores the new state first, then raises. The LLM pass's ~22 k launches fill its hardware queue, so its
+        (device included) on return. -> (result of on_u, result of on_l, the helper thread's exception or None, this thread's exception
+        or None): a failed pass must not lose the result computed beside it, and must not leave a request in the pipeline that has
+        already been decoded -- the caller stores the new state first, then raises. The LLM pass's ~22 k launches fill its hardware queue, so its
         enqueue blocks the enqueueing thread for most of the pass: that is why the decoder pass has a thread of its own. (On a CPU
         device the two passes are simply two host threads: host-logic tests.)"""
         dev = self.device
@@ -366,15 +378,33 @@ class SpiderFreeInfer:
                 mark(2, sL)
                 box["l"] = on_l()
                 mark(3, sL)
+        except BaseException as e:                  # handed back like the helper's: the caller advances its state, then raises
+            box["lerr"] = e
         finally:
             th.join()
             if gpu:                                   # nothing of this step is in flight when we return, error or not
                 sU.synchronize()
                 sL.synchronize()
         self.last_pass_ms = {"overlapped": True}
-        if gpu and "err" not in box:
+        if gpu and "err" not in box and "lerr" not in box:
             self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
-        return box.get("u"), box.get("l"), box.get("err")
+        return box.get("u"), box.get("l"), box.get("err"), box.get("lerr")
+
+    def _raise_step_errors(self, lerr, err, out=None):
+        """raise what a step's two passes raised, AFTER the caller has advanced the pipeline state: this thread's exception first (the
+        helper's chained onto it), else the helper's. A result that was computed beside the failure rides on the exception
+        (`.spider_result`) instead of being lost."""
+        first = lerr if lerr is not None else err
+        if first is None:
+            return
+        if lerr is not None and err is not None and lerr.__cause__ is None:
+            lerr.__cause__ = err
+        if out is not None and err is None:
+            try:
+                first.spider_result = self._unbatch(out)
+            except Exception:
+                pass
+        raise first
 
     # ------------------------------------------------------------------ depth 3: the prompt pass rides on the decoder stream
     def _submit3(self, inputs: dict):
@@ -415,13 +445,21 @@ class SpiderFreeInfer:
             box["res"] = self.decoder_pass(*pend)
             return self.prefill_pass(inputs, cset)
 
-        newpre, newpend, err = self._overlap(on_u, lambda: self.decode_pass(pre[0], pre[1]))
-        self._pending = newpend
-        if newpre is None:          # the helper failed before / inside the new request's prompt pass: run it here, nothing is lost
-            newpre = self.prefill_pass(inputs, cset)
-        self._prefilled = (*newpre, lkey, cset, B_new)
-        if err is not None:
-            raise err
+        newpre, newpend, err, lerr = self._overlap(on_u, lambda: self.decode_pass(pre[0], pre[1]))
+        # both old requests have been consumed by this step (decoded / adopted into set 0 and run): drop them before anything below can
+        # raise, or a later flush() / submit() would decode the adopted request again from a KV set that has been overwritten
+        self._pending, self._prefilled = newpend, None
+        if newpre is None and lerr is None:   # the helper failed before / inside the new request's prompt pass: run it here
+            try:
+                newpre = self.prefill_pass(inputs, cset)
+            except BaseException as e:
+                if err is not None and e.__cause__ is None:
+                    e.__cause__ = err
+                raise
+        if newpre is not None:
+            self._prefilled = (*newpre, lkey, cset, B_new)
+            self._warm.add(lkey)
+        self._raise_step_errors(lerr, err, box.get("res"))
         return self._unbatch(box["res"])
 
     def reset_warm(self):

@@ -70,6 +70,63 @@ def test_gemv(ops, dev, B, N, K):
               rel_to_std=True)
 
 
+@pytest.mark.parametrize("blocks", [512, 100, 2048])
+@pytest.mark.parametrize("N,K", [(4608, 3584), (3584, 18944), (3584, 3584), (4096, 4096), (4096, 14336), (1000, 2048), (1030, 5120), (300, 8192),
+                                 (500, 1000), (2048, 11264)])
+def test_gemv_row_streaming_form(ops, dev, N, K, blocks):
+    """Round 6: the row-streaming form of the single-sequence GEMV (~`blocks` workgroups of 4 waves; every wave streams a contiguous
+    range of rows behind its own buffer descriptor through two register sets). Same contract as the short-block form: plain, + bias +
+    residual, fused RMSNorm prologue, row counts that leave ragged last waves / workgroups, every instantiated K (and one that is not:
+    K = 1000 stays on the short-block form); repeats are bit-identical; the per-lane dot-product order is the short-block form's, so
+    the outputs agree up to a flipped bf16 rounding."""
+    from oracle.llama import rmsnorm
+    from spider_amd import lib as slib
+    W, x = rnd(N, K, seed=1, scale=0.05), rnd(1, K, seed=2)
+    bias, res, nw = rnd(N, seed=3), rnd(1, N, seed=4), (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
+    ref = x.float() @ W.float().T
+    Wd, xd = W.to(dev), x.to(dev)
+    prev = slib.load().spider_set_gemv_stream(0)
+    try:
+        old = ops.gemv(Wd, xd, bias=bias.to(dev), res=res.to(dev)).float()
+        slib.load().spider_set_gemv_stream(blocks)
+        a = ops.gemv(Wd, xd)
+        close(a, ref, 1e-2, 1e-2, "gemv rs", rel_to_std=True)
+        assert torch.equal(a, ops.gemv(Wd, xd)), "fixed summation order: repeats are bit-identical"
+        b_ = ops.gemv(Wd, xd, bias=bias.to(dev), res=res.to(dev))
+        close(b_, ref + bias.float() + res.float(), 1.5e-2, 1e-2, "gemv slab + bias + res", rel_to_std=True)
+        assert float((b_.float() - old).abs().max()) <= 2 ** -6 * float(old.abs().max()), "slab form vs short-block form: bf16 rounding of the same sums"
+        xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
+        close(ops.gemv(Wd, xd, norm_w=nw.to(dev), eps=1e-5), xn @ W.float().T, 2e-2, 1e-2, "gemv slab + norm", rel_to_std=True)
+    finally:
+        slib.load().spider_set_gemv_stream(0 if prev < 0 else prev)
+
+
+@pytest.mark.parametrize("blocks", [512, 77])
+@pytest.mark.parametrize("I,K", [(18944, 3584), (14336, 4096), (1000, 2048), (1001, 5120), (300, 1032)])
+def test_gemv_swiglu_row_streaming_form(ops, dev, I, K, blocks):
+    from oracle.llama import rmsnorm
+    from spider_amd import lib as slib
+    W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(1, K, seed=2)
+    nw = (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
+    g, u = x.float() @ W[:I].float().T, x.float() @ W[I:].float().T
+    prev = slib.load().spider_set_gemv_stream(0)
+    try:
+        old_n = ops.gemv_swiglu(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5).float()       # short-block form
+        slib.load().spider_set_gemv_stream(blocks)
+        a = ops.gemv_swiglu(W.to(dev), x.to(dev))
+        close(a, F.silu(g) * u, 1.5e-2, 2e-2, "gemv_swiglu slab", rel_to_std=True)
+        assert torch.equal(a, ops.gemv_swiglu(W.to(dev), x.to(dev)))
+        new_n = ops.gemv_swiglu(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5).float()
+        # same roundings (gate, up, silu(gate) to bf16) on sums that differ by fp32 summation order only: a flipped bf16 rounding of the
+        # gate or the up value moves the product by 2^-8 of its size
+        assert float((new_n - old_n).abs().max()) <= 2 ** -6 * float(old_n.abs().max()), "slab form vs short-block form, fused RMSNorm"
+        xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
+        gn, un = xn @ W[:I].float().T, xn @ W[I:].float().T
+        close(new_n, F.silu(gn) * un, 3e-2, 3e-2, "gemv_swiglu slab + norm", rel_to_std=True)
+    finally:
+        slib.load().spider_set_gemv_stream(0 if prev < 0 else prev)
+
+
 @pytest.mark.parametrize("B,I,K", [(1, 18944, 3584), (4, 300, 512), (8, 64, 4096)])
 def test_gemv_swiglu(ops, dev, B, I, K):
     W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(B, K, seed=2)
@@ -403,12 +460,12 @@ def test_latent_plumbing(ops, dev):
 
 @pytest.mark.parametrize("B,n_q,n_kv,T,nsplit,beg", [(1, 28, 4, 1537, 32, 0), (2, 32, 8, 300, 8, 0), (3, 8, 8, 1, 4, 0),
                                                     (2, 4, 2, 130, 5, 17), (1, 7, 1, 6, 1, 0), (1, 28, 4, 2000, 32, 0)])
-@pytest.mark.parametrize("inline", ["0", "1"])
+@pytest.mark.parametrize("inline", ["0", "1", "2"])
 def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg, inline, monkeypatch):
     """One-launch RoPE + KV append + split-KV attention + cross-block combine == the three separate kernels
     (bit-identical cache rows, outputs equal up to fp32 summation order), repeated to exercise the self-resetting
-    ticket counters the way hipGraph replays do. inline = 1: the combine by the last-arriving block of the same launch
-    (write-through partial stores + ticket); 0: by attn_combine_kernel."""
+    ticket counters the way hipGraph replays do. inline = 1 / 2: the combine by the last-arriving block of the same launch
+    (write-through partial stores + ticket; 1: acq_rel ticket, 2: relaxed ticket + sc1 loads, no fence); 0: by attn_combine_kernel."""
     from oracle.llama import LlamaCfg, rope_table
     from spider_amd import lib as slib
     prev = slib.load().spider_set_attn_inline(int(inline))
@@ -438,6 +495,96 @@ def test_attn_decode_fused(ops, dev, B, n_q, n_kv, T, nsplit, beg, inline, monke
         ops.attn_decode_fused(qkv, pos, cs, kc0.clone(), vc0.clone(), kv_end, kv_beg, cnt, n_q, nsplit, ws, out2)
         assert torch.equal(out, out2), "the merge order is fixed: repeats are bit-identical whichever block arrives last"
     slib.load().spider_set_attn_inline(0 if prev < 0 else prev)
+
+
+def _busy_stream(dev, ms: float = 60.0):
+    """a side stream that keeps HBM and every CU's memory queue busy for roughly `ms`: hand-offs must hold under load, not on an idle chip"""
+    side = torch.cuda.Stream()
+    big = torch.zeros(256 << 20, dtype=torch.float32, device=dev)          # 1 GiB: every pass goes to HBM
+    with torch.cuda.stream(side):
+        for _ in range(int(ms / 0.45) + 1):
+            big.add_(1.0)
+    return side, big
+
+
+@pytest.mark.parametrize("nsplit,n_q,n_kv,T", [(64, 28, 4, 1600), (32, 28, 4, 1600), (16, 32, 8, 900)])
+def test_attn_decode_fused_fence_free_combine_under_load(ops, dev, nsplit, n_q, n_kv, T):
+    """Form 2 of the in-launch split-KV combine has no release / acquire fence (write-through partials, drained, a relaxed ticket, sc1
+    loads in the reducer). Its failure mode is silent: stale partials of the PREVIOUS launch summed into this one. So: 8 different
+    query rows, each answered once on a quiet chip, then the 8 launched back to back 40 times (the workspace lines of launch i are L2 /
+    L1 resident from launch i - 1) while a second stream streams 1 GiB passes; every output word must equal the quiet answer and the
+    ticket counters must be zero at the end."""
+    from oracle.llama import LlamaCfg, rope_table
+    from spider_amd import lib as slib
+    prev = slib.load().spider_set_attn_inline(2)
+    try:
+        B, d, Tmax = 1, 128, T + 8
+        cs = rope_table(LlamaCfg(head_dim=d, rope_theta=1e6), Tmax + 8).to(dev)
+        kc, vc = rnd(B, n_kv, Tmax, d, seed=21).to(dev), rnd(B, n_kv, Tmax, d, seed=22).to(dev)
+        kv_end = torch.tensor([T], dtype=torch.int32, device=dev)
+        kv_beg = torch.zeros(B, dtype=torch.int32, device=dev)
+        pos = (kv_end - 1).to(torch.int32)
+        cnt = torch.zeros(B * n_kv, dtype=torch.int32, device=dev)
+        ws = (torch.empty(B * n_q * nsplit * d, dtype=torch.float32, device=dev), torch.empty(B * n_q * nsplit * 2, dtype=torch.float32, device=dev))
+        qkvs = [rnd(B, (n_q + 2 * n_kv) * d, seed=40 + i).to(dev) for i in range(8)]
+        quiet = []
+        for qkv in qkvs:
+            o = torch.empty(B, n_q * d, dtype=BF, device=dev)
+            ops.attn_decode_fused(qkv, pos, cs, kc, vc, kv_end, kv_beg, cnt, n_q, nsplit, ws, o)
+            torch.cuda.synchronize()
+            quiet.append(o)
+        assert not torch.equal(quiet[0], quiet[1])
+        side, big = _busy_stream(dev)
+        outs = [[torch.empty(B, n_q * d, dtype=BF, device=dev) for _ in qkvs] for _ in range(40)]
+        for rep in range(40):
+            for i, qkv in enumerate(qkvs):
+                ops.attn_decode_fused(qkv, pos, cs, kc, vc, kv_end, kv_beg, cnt, n_q, nsplit, ws, outs[rep][i])
+        torch.cuda.synchronize()
+        bad = sum(int(not torch.equal(outs[rep][i], quiet[i])) for rep in range(40) for i in range(8))
+        assert bad == 0, f"{bad} of 320 launches under load differ from the quiet-chip answer"
+        assert int(cnt.abs().sum()) == 0
+    finally:
+        slib.load().spider_set_attn_inline(0 if prev < 0 else prev)
+
+
+def test_wstream_inlaunch_combine_stress_under_load(ops, dev, monkeypatch):
+    """advisor (round 5): the in-launch split-K combine of the streaming conv (sc1 slab stores, drained, ONE relaxed counter add, sc1
+    slab loads; no fence) had one eager run + three replays of one shape as its evidence. Here: four shapes (128- and 512-pixel forms,
+    2560 -> 1280 included), each captured in a hipGraph of 8 launches over 4 different inputs, replayed 250 times (2000 launches per
+    shape) while a second stream streams 1 GiB passes; every replay's outputs must be bit-identical to the reduce-kernel form
+    (ops.set_ws_inlaunch(False): same slabs, same order) and the arrival counters must be zero afterwards."""
+    monkeypatch.setattr(ops, "WS_MAX_M", 512)
+    shapes = [(2, 8, 8, 1280, 1280), (2, 8, 8, 2560, 1280), (2, 16, 16, 640, 640), (1, 8, 8, 1920, 1280)]
+    for (B, H, W, Cin, Cout) in shapes:
+        g = torch.Generator(device=dev).manual_seed(Cin + H)
+        xs = [torch.randn(B, H, W, Cin, generator=g, device=dev).half() for _ in range(4)]
+        w = ops.mark_weight((torch.randn(Cout, 3, 3, Cin, generator=g, device=dev) * (1.0 / (3 * Cin ** 0.5))).half())
+        bias = (torch.randn(Cout, generator=g, device=dev) * 0.1).half()
+        prev = ops.set_ws_inlaunch(False)
+        try:
+            want = [ops.conv_ex(x, w, bias=bias, pad=(1, 1)) for x in xs]
+            ops.set_ws_inlaunch(True)
+            got0 = [ops.conv_ex(x, w, bias=bias, pad=(1, 1)) for x in xs]           # eager, also the graph's warm-up
+            torch.cuda.synchronize()
+            assert getattr(w, "_spider_fm", None) is not None, "the streaming kernel's weight copy was not built: wrong path"
+            for a, b_ in zip(got0, want):
+                assert torch.equal(a, b_), "in-launch combine and reduce kernel sum the same slabs in the same order"
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                outs = [ops.conv_ex(xs[i % 4], w, bias=bias, pad=(1, 1)) for i in range(8)]
+            side, big = _busy_stream(dev, 120.0)
+            bad = 0
+            for rep in range(250):
+                gr.replay()
+                if rep % 25 == 24:           # (comparisons are enqueued behind the replay on the same stream)
+                    bad += sum(int(not torch.equal(outs[i], want[i % 4])) for i in range(8))
+            torch.cuda.synchronize()
+            bad += sum(int(not torch.equal(outs[i], want[i % 4])) for i in range(8))
+            assert bad == 0, f"shape {(B, H, W, Cin, Cout)}: {bad} outputs differ from the reduce-kernel form"
+            cntv = ops._workspace(xs[0].device)[ops.WS_BYTES // 4:]
+            assert int(cntv.view(torch.int32).abs().sum()) == 0, "arrival counters must be zero between calls"
+        finally:
+            ops.set_ws_inlaunch(prev)
 
 
 def test_gemm_256_tile_repeatable_under_load(ops, dev):
@@ -851,8 +998,7 @@ def test_wstream_conv_matches_reference_and_tile_path(dev, B, H, W, Cin, Cout, u
             cr = (Ho * Wo) // part.nchunk
             want = _group_sums(o2.cpu(), 32, cr)
             assert float((part.t.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
-    # the in-launch combine and the reduce kernel sum the same slabs in the same order
-    monkeypatch.setenv("SPIDER_WS_INLAUNCH", "1")
+    # (the in-launch combine against the reduce kernel, bit for bit and under load: test_wstream_inlaunch_combine_stress_under_load)
     cnt = ops._workspace(x.device)[ops.WS_BYTES // 4:]
     assert int(cnt.view(torch.int32).abs().sum()) == 0, "arrival counters must be zero between calls"
 

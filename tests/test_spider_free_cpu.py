@@ -339,3 +339,82 @@ def test_reset_warm_after_an_engine_swap_runs_the_next_passes_alone():
     assert infer.submit(inputs=reqs[4]) is not None and pipe.calls[n][0] == main    # first decoder pass after the reset: calling thread
     assert infer.submit(inputs=reqs[5]) is not None and pipe.calls[n + 1][0] == "spider-decoder-enqueue"
     assert infer.flush() is not None
+
+
+def _mk(i):
+    return {"input_ids": torch.full((1, 4), 10 + i), "attention_mask": torch.ones(1, 4, dtype=torch.long)}
+
+
+def test_cold_check_uses_the_generate_kwargs_the_real_pass_uses():
+    """advisor (round 5): generate(**inputs, **generate_kwargs) picks the decode graph by output_hidden_states / return_logits; the
+    coldness check must ask for THAT graph, and a key this caller has never run (or reset_warm() since) is cold whatever the engine says"""
+    infer, pipe, thinker = make()
+    infer.generate_kwargs = dict(output_hidden_states=True, spk="Chelsie")
+    infer.processor.prompt_len = 4
+    seen = []
+    thinker.would_capture = lambda cache_set=0, decode=True, **kw: (seen.append(kw), False)[1]
+    dec_threads = []
+    orig_dec = infer.decoder_pass
+    infer.decoder_pass = lambda *a: (dec_threads.append(threading.current_thread().name), orig_dec(*a))[1]
+    infer.submit(inputs=_mk(0))
+    infer.submit(inputs=_mk(1))               # the decoder geometry has not run yet: alone
+    infer.submit(inputs=_mk(2))
+    assert dec_threads[-1] == "spider-decoder-enqueue"
+    assert seen and all(kw.get("output_hidden_states") is True and kw.get("spk") == "Chelsie" and "_images" not in kw for kw in seen)
+    infer.flush()
+    infer.reset_warm()                        # the engine still answers "warm": the caller's own record decides
+    infer.submit(inputs=_mk(3))
+    infer.submit(inputs=_mk(4))
+    assert dec_threads[-1] != "spider-decoder-enqueue"
+    infer.flush()
+
+
+def test_failed_llm_pass_leaves_no_decoded_request_in_the_pipeline():
+    """advisor (round 5): the LLM pass of request k+1 raises beside the decoder pass of request k -> k must not come back a second
+    time, the helper's result rides on the exception, and the pipeline is empty afterwards"""
+    infer, pipe, thinker = make()
+    infer.processor.prompt_len = 4
+    for i in range(3):
+        infer.submit(inputs=_mk(i))
+    orig = thinker.generate
+    thinker.generate = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("llm blew up"))
+    n = len(pipe.calls)
+    with pytest.raises(RuntimeError, match="llm blew up") as ei:
+        infer.submit(inputs=_mk(3))
+    assert len(pipe.calls) == n + 1 and ei.value.spider_result.text_ids[0] == 12      # request 2 was decoded once, result not lost
+    thinker.generate = orig
+    assert infer.flush() is None and len(pipe.calls) == n + 1                           # ... and never again
+    assert infer.submit(inputs=_mk(4)) is None                                          # the pipeline restarts empty
+
+
+def test_depth3_failed_prompt_pass_retry_does_not_replay_the_adopted_request():
+    pipe, thinker = FakePipe(), FakeThinker3()
+    dinf = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": pipe}, device="cpu")})
+    proc = SyntheticOmniProcessor(vocab=500, tags=("IMAGE",), head=3)
+    infer = SpiderFreeInfer(thinker, proc, dinf, device="cpu", depth=3)
+    infer.processor.prompt_len = 4
+    for i in range(5):
+        infer.submit(inputs=_mk(i))
+    assert pipe.calls[-1][0] == "spider-decoder-enqueue"                                # steady state
+    orig = thinker.prefill_begin
+    thinker.prefill_begin = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("prompt pass blew up"))
+    n_dec = len(thinker.dec)
+    with pytest.raises(RuntimeError, match="prompt pass blew up"):
+        infer.submit(inputs=_mk(5))          # helper fails inside the new prompt pass; the retry on the calling thread fails too
+    thinker.prefill_begin = orig
+    assert infer._prefilled is None and len(thinker.dec) == n_dec + 1                   # the adopted request ran its decode loop once
+    out = infer.flush()                      # its decoder pass
+    assert out is not None and infer.flush() is None and len(thinker.dec) == n_dec + 1
+
+
+def test_image_url_items_count_as_images_and_a_drift_is_refused():
+    infer, pipe, _ = make()
+    convs = [[{"role": "user", "content": [{"type": "image_url", "image_url": "http://x/a.png"}, {"type": "text", "text": "a"}]}],
+             [{"role": "user", "content": [{"type": "text", "text": "b"}]}],
+             [{"role": "user", "content": [{"image_url": "http://x/c.png"}, {"type": "image", "image": "c2"}]}]]
+    assert [SpiderFreeInfer._n_images(c) for c in convs] == [1, 0, 2]
+    infer.process_mm_info = lambda conversations, use_audio_in_video: (None, ["A", "C", "C2"], None)
+    assert infer.build_inputs_batch(convs)["_images"] == ["A", None, "C"]
+    infer.process_mm_info = lambda conversations, use_audio_in_video: (None, ["A", "C"], None)
+    with pytest.raises(ValueError, match="drift"):
+        infer.build_inputs_batch(convs)
