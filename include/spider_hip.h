@@ -95,11 +95,6 @@ int spider_attn_decode_fused_bf16(const void* qkv, const int* pos, const float* 
  * block; 1: acq_rel ticket, 2: write-through partials + relaxed ticket + sc1 loads, no fence), 0 = in the separate combine launch
  * (SPIDER_ATTN_INLINE is read once, at the first call). Returns the previous setting. */
 int spider_set_attn_inline(int on);
-/* Form of the single-sequence GEMVs (spider_gemv_bf16 / spider_gemv_swiglu_bf16 at B = 1, K a multiple of 512 from the instantiated
- * set): blocks > 0 = the row-streaming form with about `blocks` workgroups of 4 waves per launch (every wave streams a contiguous range
- * of weight rows through two register sets), 0 = the short-block form (N / 4 workgroups, one row per wave). SPIDER_GEMV_RS is read at
- * the first call. Returns the previous setting (-1: not read yet). */
-int spider_set_gemv_stream(int blocks);
 /* Tuning / test aid: split-K combine of the weight-stationary streaming conv (w_tiled = 2): 1 = inside the launch by the last-arriving
  * block of a strip (default), 0 = partial slabs + the reduce kernel (SPIDER_WS_INLAUNCH is read at the first such launch). Both forms sum
  * the slabs in split order: bit-identical outputs. The arrival counters live in the 4096 bytes behind the declared workspace: ONE stream

@@ -11,8 +11,6 @@
 // transposed); KV cache [B, n_kv, T_max, d] bf16. All reductions accumulate in fp32.
 #include "common.hpp"
 #include <stdlib.h>
-#include <type_traits>
-#include <utility>
 
 using namespace spider;
 
@@ -309,162 +307,6 @@ __global__ __launch_bounds__(NWB * 64) void gemv_kernel(const bf16_t* __restrict
             }
         }
     }
-}
-
-// ----------------------------------------------------------------------------------------------
-// Row-streaming GEMV (round 6), one sequence, K = CPR * 512: the contract of gemv_kernel<1, ., GATEUP, true> with a lighter shape on
-// the chip. gemv_kernel launches N / 4 short workgroups (1152 ... 9472 per projection): every one stages the activation vector
-// (+ RMSNorm) for ONE weight row per wave, and its ~70-VGPR waves fill every SIMD 7 deep -- beside the diffusion stream's workgroups
-// (2 waves per SIMD x ~110 VGPRs + 110 KiB of LDS) each side waits for the other to drain. Here a launch is ~512 workgroups of 4 waves
-// and every wave STREAMS: it owns RW consecutive weight rows (GATEUP: RW gate rows + the RW up rows) = one contiguous byte range behind
-// a buffer descriptor of its own, so loads past its range cost nothing and return zeros (no tail branches, the vmcnt count stays
-// exact). The range is walked in segments of <= 8 one-KiB chunks through TWO register sets: a set is refilled with the segment two
-// ahead as soon as it has been consumed (8 ... 16 sixteen-byte loads in flight per lane, across row boundaries). Every index in the
-// unrolled body is a compile-time constant: the unit of unrolling is two row slots (two rows, or a gate row + its up row), which
-// makes the number of segments per unit even and the register-set parity static. Activations: staged ONCE per workgroup in LDS
-// (RMSNorm folded in), then held in registers for the whole launch when CPR <= 8 (K <= 4096), read per segment from LDS otherwise.
-// A row's result never leaves the wave: wave_sum, lane 0 applies the epilogue and stores (no partials, no second barrier).
-// ----------------------------------------------------------------------------------------------
-template <class F, int... S>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
-template <int N_, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N_>{}); }
-
-template <bool GATEUP, int CPR>
-__global__ __launch_bounds__(256) void gemv_rs_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
-                                                      bf16_t* __restrict__ out, const bf16_t* __restrict__ bias,
-                                                      const bf16_t* __restrict__ res, const bf16_t* __restrict__ norm_w,
-                                                      float eps, int N, int RW) {
-    constexpr int NW = 4, K = CPR * 512;
-    constexpr int NSEG = (CPR + 7) / 8, SEGU = 2 * NSEG;
-    constexpr bool XREG = CPR <= 8;
-    constexpr uint32_t ROWB = (uint32_t)K * 2u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-    __shared__ float red[NW];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = (blockIdx.x * NW + wave) * RW;                 // first row (GATEUP: first gate / up pair) of this wave
-    const int nval = max(0, min(RW, N - n0));                     // rows of it that exist
-    const int nb = min(n0, N - 1);                                // (a wave past the end gets an empty range on a valid base)
-    const __amdgpu_buffer_rsrc_t s0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W) + (size_t)nb * K, 0, (uint32_t)nval * ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t s1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W) + (size_t)(GATEUP ? N + nb : nb) * K, 0, (uint32_t)nval * ROWB, 0x00020000);
-    const uint32_t loff = (uint32_t)lane * 16u;
-
-    // lane l keeps row n0 + l's epilogue operands and, in the end, its result: no memory operation inside the streaming loop (a bias or
-    // residual load there would be waited for with vmcnt(0), i.e. drain the whole weight ring once per row), one coalesced store after it
-    // (requested first: they return before the weight stream's first loads)
-    float my_out = 0.f;
-    uint16_t my_bias_h = 0, my_res_h = 0;
-    if (!GATEUP && lane < nval) {
-        if (bias) my_bias_h = bias[n0 + lane];
-        if (res) my_res_h = res[n0 + lane];
-    }
-    const bool has_res = res != nullptr;
-    u32x4 buf[2][8];
-    // segment s (compile-time) of unit `unit` -> register set bi: row slot t = s / NSEG, chunks [8 sg, 8 sg + cnt) of that row
-    auto issue = [&](auto bi_c, int unit, auto s_c) {
-        constexpr int bi = decltype(bi_c)::value, sq = decltype(s_c)::value;
-        constexpr int t = sq / NSEG, sg = sq % NSEG, kc0 = sg * 8, cnt = (CPR - kc0) < 8 ? (CPR - kc0) : 8;
-        const uint32_t rowoff = GATEUP ? (uint32_t)unit * ROWB : (uint32_t)(2 * unit + t) * ROWB;
-#pragma unroll
-        for (int u = 0; u < cnt; ++u) {
-            const uint32_t so = rowoff + (uint32_t)(kc0 + u) * 1024u;
-            buf[bi][u] = __builtin_bit_cast(u32x4, (GATEUP && t == 1) ? __builtin_amdgcn_raw_buffer_load_b128(s1, loff, so, 2)
-                                                                       : __builtin_amdgcn_raw_buffer_load_b128(s0, loff, so, 2));
-        }
-    };
-    issue(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});      // in flight under the activation prologue
-    issue(std::integral_constant<int, 1>{}, 0, std::integral_constant<int, 1>{});
-
-    {   // activations -> LDS (bf16), RMSNorm folded in
-        constexpr int nv = K / 8;
-        const u32x4* xv = reinterpret_cast<const u32x4*>(x);
-        u32x4* sv = reinterpret_cast<u32x4*>(xs);
-        if (norm_w) {
-            float ss = 0.f;
-            for (int i = threadIdx.x; i < nv; i += NW * 64) {
-                u32x4 a = xv[i];
-                uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float lo = bf16lo_to_f32(aw[j]), hi = bf16hi_to_f32(aw[j]);
-                    ss += lo * lo + hi * hi;
-                }
-            }
-            const float rs = rsqrtf(block_sum<NW>(ss, red) / (float)K + eps);
-            const u32x4* wv = reinterpret_cast<const u32x4*>(norm_w);
-            for (int i = threadIdx.x; i < nv; i += NW * 64) {
-                u32x4 a = xv[i], wq = wv[i];
-                uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ww[4] = {wq.x, wq.y, wq.z, wq.w}, o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float lo = bf16_to_f32(f32_to_bf16(bf16lo_to_f32(aw[j]) * rs)) * bf16lo_to_f32(ww[j]);
-                    float hi = bf16_to_f32(f32_to_bf16(bf16hi_to_f32(aw[j]) * rs)) * bf16hi_to_f32(ww[j]);
-                    o[j] = pack_bf16x2(lo, hi);
-                }
-                u32x4 ov;
-                ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-                sv[i] = ov;
-            }
-        } else {
-            for (int i = threadIdx.x; i < nv; i += NW * 64) sv[i] = xv[i];
-        }
-    }
-    __syncthreads();
-    if (nval == 0) return;
-    u32x4 xr[XREG ? CPR : 1];
-    if (XREG) {
-#pragma unroll
-        for (int kc = 0; kc < CPR; ++kc) xr[kc] = *reinterpret_cast<const u32x4*>(xs + kc * 512 + lane * 8);
-    }
-
-    const float my_bias = bf16_to_f32(my_bias_h), my_res = bf16_to_f32(my_res_h);
-    float acc = 0.f, gsum = 0.f;
-    auto consume = [&](auto bi_c, int unit, auto s_c) {
-        constexpr int bi = decltype(bi_c)::value, sq = decltype(s_c)::value;
-        constexpr int t = sq / NSEG, sg = sq % NSEG, kc0 = sg * 8, cnt = (CPR - kc0) < 8 ? (CPR - kc0) : 8;
-        u32x4 xq[8];
-#pragma unroll
-        for (int u = 0; u < cnt; ++u) xq[u] = XREG ? xr[XREG ? kc0 + u : 0] : *reinterpret_cast<const u32x4*>(xs + (kc0 + u) * 512 + lane * 8);
-#pragma unroll
-        for (int u = 0; u < cnt; ++u) {
-            acc = dot2_bf16(buf[bi][u].x, xq[u].x, acc);
-            acc = dot2_bf16(buf[bi][u].y, xq[u].y, acc);
-            acc = dot2_bf16(buf[bi][u].z, xq[u].z, acc);
-            acc = dot2_bf16(buf[bi][u].w, xq[u].w, acc);
-        }
-        if (sg == NSEG - 1) {                                    // (compile-time) the row slot is complete: every lane holds the sum
-            const float tot = wave_sum(acc);
-            acc = 0.f;
-            if (GATEUP) {
-                if (t == 0) gsum = tot;
-                else {
-                    const float g = bf16_to_f32(f32_to_bf16(gsum));
-                    const float uu = bf16_to_f32(f32_to_bf16(tot));
-                    const float a = bf16_to_f32(f32_to_bf16(silu_f(g)));
-                    my_out = (lane == unit) ? a * uu : my_out;
-                }
-            } else {
-                float v = tot + my_bias;
-                v = has_res ? bf16_to_f32(f32_to_bf16(v)) + my_res : v;
-                my_out = (lane == 2 * unit + t) ? v : my_out;
-            }
-        }
-    };
-    const int nunits = GATEUP ? RW : (RW + 1) / 2;
-    for (int unit = 0; unit < nunits; ++unit) {
-        // (a fold over the compile-time segment index: every register-set and chunk index below is a constant)
-        static_for<SEGU>([&](auto sc) {
-            constexpr int S = decltype(sc)::value;
-            consume(std::integral_constant<int, (S & 1)>{}, unit, sc);
-            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks every refill below both consumes: the ring would drain)
-            if constexpr (S + 2 < SEGU) issue(std::integral_constant<int, (S & 1)>{}, unit, std::integral_constant<int, S + 2>{});
-            else issue(std::integral_constant<int, (S & 1)>{}, unit + 1, std::integral_constant<int, S + 2 - SEGU>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-    if (lane < nval) out[n0 + lane] = f32_to_bf16(my_out);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1420,7 +1262,6 @@ __global__ __launch_bounds__(NW * 64) void skinny_fm_kernel(const bf16_t* __rest
     }
 }
 
-#define SPIDER_GEMV_RS_DEFAULT 0
 #define GEMV_ARGS (const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w, eps, N, K, hoist
 // wide8: 8 waves per block share one LDS copy of the activations (long-K projections: the 38 KB copy of a K = 18944 vector per
 // 4-row block is 25 % of the block's weight bytes and caps the resident waves per CU)
@@ -1429,14 +1270,6 @@ __global__ __launch_bounds__(NW * 64) void skinny_fm_kernel(const bf16_t* __rest
         if (wide8) gemv_kernel<NB_, R_, GU_, XL_, 8><<<(N + 8 * R_ - 1) / (8 * R_), 512, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(GEMV_ARGS); \
         else gemv_kernel<NB_, R_, GU_, XL_, 4><<<grid, 256, XL_ ? (size_t)NB_ * K * 2 : 0, (hipStream_t)stream>>>(GEMV_ARGS); \
     } while (0)
-
-// workgroups of the row-streaming GEMV form (SPIDER_GEMV_RS: 0 = the short-block gemv_kernel serves every call; n > 0 = about n
-// workgroups of 4 streaming waves per launch); spider_set_gemv_stream() switches at run time (tests, tuning)
-static int g_gemv_rs = -1;
-static int gemv_rs_blocks() {
-    if (g_gemv_rs < 0) { const char* e = getenv("SPIDER_GEMV_RS"); g_gemv_rs = e ? atoi(e) : SPIDER_GEMV_RS_DEFAULT; if (g_gemv_rs < 0) g_gemv_rs = 0; }
-    return g_gemv_rs;
-}
 
 static int gemv_env_r() {
     static const int v = [] { const char* e = getenv("SPIDER_GEMV_R"); return e ? atoi(e) : 0; }();
@@ -1448,33 +1281,6 @@ static int gemv_dispatch(const void* W, const void* x, void* out, const void* bi
                          const void* norm_w, float eps, int N, int K, void* stream) {
     // tuning aid: SPIDER_GEMV_XLDS_MAX = largest activation footprint (bytes) staged in LDS; beyond it the waves read x through L2
     // (a 38 KB LDS block -- the down projection -- cannot share a CU with a 110-147 KB workgroup of the diffusion stream)
-    if (NB == 1 && gemv_rs_blocks() > 0 && K % 512 == 0 && N >= 256) {
-        // row-streaming form: ~gemv_rs_blocks() workgroups of 4 waves, each wave streaming RW consecutive rows (pairs for gate / up)
-        int RW = (N + 4 * gemv_rs_blocks() - 1) / (4 * gemv_rs_blocks());
-        if (!GU) RW = (RW + 1) / 2 * 2;                                   // two rows per unrolled unit
-        if (RW > 64) RW = 64;
-        const int grid_s = (N + 4 * RW - 1) / (4 * RW);
-#define RS_LAUNCH(CPR_)                                                                                                   \
-    gemv_rs_kernel<GU, CPR_><<<grid_s, 256, (size_t)K * 2, (hipStream_t)stream>>>((const bf16_t*)W, (const bf16_t*)x, (bf16_t*)out, \
-        (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w, eps, N, RW)
-        bool done = true;
-        switch (K / 512) {
-            case 4: RS_LAUNCH(4); break;       // 2048 (Qwen2.5-Omni-3B thinker)
-            case 7: RS_LAUNCH(7); break;       // 3584 (Qwen2.5-7B hidden)
-            case 8: RS_LAUNCH(8); break;       // 4096 (Llama-8B hidden)
-            case 10: RS_LAUNCH(10); break;     // 5120
-            case 16: RS_LAUNCH(16); break;     // 8192
-            case 22: RS_LAUNCH(22); break;     // 11264 (Qwen2.5-Omni-3B intermediate = 11008 -> not a multiple; kept for 11264)
-            case 28: RS_LAUNCH(28); break;     // 14336 (Llama-8B intermediate)
-            case 37: RS_LAUNCH(37); break;     // 18944 (Qwen2.5-7B intermediate)
-            default: done = false;
-        }
-#undef RS_LAUNCH
-        if (done) {
-            SPIDER_LAUNCH_OK();
-            return 0;
-        }
-    }
     static const size_t xlds_max = [] { const char* e = getenv("SPIDER_GEMV_XLDS_MAX"); return e ? (size_t)atol(e) : (size_t)64 * 1024; }();
     const bool xlds = (size_t)NB * K * 2 <= xlds_max || norm_w != nullptr;
     if (!xlds) SPIDER_CHECK(norm_w == nullptr, "gemv: fused RMSNorm needs batch*K*2 <= 64 KiB");
@@ -1546,13 +1352,6 @@ extern "C" {
 int spider_set_attn_inline(int on) {
     const int prev = g_attn_inline;
     g_attn_inline = on < 0 ? 0 : (on > 2 ? 2 : on);
-    return prev;
-}
-
-// workgroups per launch of the row-streaming single-sequence GEMV (0 = off: short-block form); returns the previous setting
-int spider_set_gemv_stream(int blocks) {
-    const int prev = g_gemv_rs;
-    g_gemv_rs = blocks < 0 ? 0 : blocks;
     return prev;
 }
 

@@ -44,7 +44,6 @@ SIGNATURES = {
     "spider_attn_decode_fused_bf16": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     "spider_set_attn_inline": (_i, [_i]),
     "spider_set_ws_inlaunch": (_i, [_i]),
-    "spider_set_gemv_stream": (_i, [_i]),
     "spider_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _l, _vp]),
     "spider_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _l, _vp]),
     "spider_xattn_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),

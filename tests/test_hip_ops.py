@@ -70,63 +70,6 @@ def test_gemv(ops, dev, B, N, K):
               rel_to_std=True)
 
 
-@pytest.mark.parametrize("blocks", [512, 100, 2048])
-@pytest.mark.parametrize("N,K", [(4608, 3584), (3584, 18944), (3584, 3584), (4096, 4096), (4096, 14336), (1000, 2048), (1030, 5120), (300, 8192),
-                                 (500, 1000), (2048, 11264)])
-def test_gemv_row_streaming_form(ops, dev, N, K, blocks):
-    """Round 6: the row-streaming form of the single-sequence GEMV (~`blocks` workgroups of 4 waves; every wave streams a contiguous
-    range of rows behind its own buffer descriptor through two register sets). Same contract as the short-block form: plain, + bias +
-    residual, fused RMSNorm prologue, row counts that leave ragged last waves / workgroups, every instantiated K (and one that is not:
-    K = 1000 stays on the short-block form); repeats are bit-identical; the per-lane dot-product order is the short-block form's, so
-    the outputs agree up to a flipped bf16 rounding."""
-    from oracle.llama import rmsnorm
-    from spider_amd import lib as slib
-    W, x = rnd(N, K, seed=1, scale=0.05), rnd(1, K, seed=2)
-    bias, res, nw = rnd(N, seed=3), rnd(1, N, seed=4), (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
-    ref = x.float() @ W.float().T
-    Wd, xd = W.to(dev), x.to(dev)
-    prev = slib.load().spider_set_gemv_stream(0)
-    try:
-        old = ops.gemv(Wd, xd, bias=bias.to(dev), res=res.to(dev)).float()
-        slib.load().spider_set_gemv_stream(blocks)
-        a = ops.gemv(Wd, xd)
-        close(a, ref, 1e-2, 1e-2, "gemv rs", rel_to_std=True)
-        assert torch.equal(a, ops.gemv(Wd, xd)), "fixed summation order: repeats are bit-identical"
-        b_ = ops.gemv(Wd, xd, bias=bias.to(dev), res=res.to(dev))
-        close(b_, ref + bias.float() + res.float(), 1.5e-2, 1e-2, "gemv slab + bias + res", rel_to_std=True)
-        assert float((b_.float() - old).abs().max()) <= 2 ** -6 * float(old.abs().max()), "slab form vs short-block form: bf16 rounding of the same sums"
-        xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
-        close(ops.gemv(Wd, xd, norm_w=nw.to(dev), eps=1e-5), xn @ W.float().T, 2e-2, 1e-2, "gemv slab + norm", rel_to_std=True)
-    finally:
-        slib.load().spider_set_gemv_stream(0 if prev < 0 else prev)
-
-
-@pytest.mark.parametrize("blocks", [512, 77])
-@pytest.mark.parametrize("I,K", [(18944, 3584), (14336, 4096), (1000, 2048), (1001, 5120), (300, 1032)])
-def test_gemv_swiglu_row_streaming_form(ops, dev, I, K, blocks):
-    from oracle.llama import rmsnorm
-    from spider_amd import lib as slib
-    W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(1, K, seed=2)
-    nw = (1 + 0.1 * rnd(K, seed=5).float()).to(BF)
-    g, u = x.float() @ W[:I].float().T, x.float() @ W[I:].float().T
-    prev = slib.load().spider_set_gemv_stream(0)
-    try:
-        old_n = ops.gemv_swiglu(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5).float()       # short-block form
-        slib.load().spider_set_gemv_stream(blocks)
-        a = ops.gemv_swiglu(W.to(dev), x.to(dev))
-        close(a, F.silu(g) * u, 1.5e-2, 2e-2, "gemv_swiglu slab", rel_to_std=True)
-        assert torch.equal(a, ops.gemv_swiglu(W.to(dev), x.to(dev)))
-        new_n = ops.gemv_swiglu(W.to(dev), x.to(dev), norm_w=nw.to(dev), eps=1e-5).float()
-        # same roundings (gate, up, silu(gate) to bf16) on sums that differ by fp32 summation order only: a flipped bf16 rounding of the
-        # gate or the up value moves the product by 2^-8 of its size
-        assert float((new_n - old_n).abs().max()) <= 2 ** -6 * float(old_n.abs().max()), "slab form vs short-block form, fused RMSNorm"
-        xn = rmsnorm(x.float(), nw.float(), 1e-5).to(BF).float()
-        gn, un = xn @ W[:I].float().T, xn @ W[I:].float().T
-        close(new_n, F.silu(gn) * un, 3e-2, 3e-2, "gemv_swiglu slab + norm", rel_to_std=True)
-    finally:
-        slib.load().spider_set_gemv_stream(0 if prev < 0 else prev)
-
-
 @pytest.mark.parametrize("B,I,K", [(1, 18944, 3584), (4, 300, 512), (8, 64, 4096)])
 def test_gemv_swiglu(ops, dev, B, I, K):
     W, x = rnd(2 * I, K, seed=1, scale=0.05), rnd(B, K, seed=2)
