@@ -36,6 +36,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL between the ranks of one node needs dmabuf IPC on this driver stack (legacy IPC fails with `hipIpcGetMemHandle: invalid argument`);
+# set before the HIP runtime loads, also when a launcher (torchrun) starts this file without the variable
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -438,7 +441,7 @@ def measure_roofline(resp, device):
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction); only
     # valid for the shapes it was collected on
     traffic, src = None, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode_hbm.json")
         if os.path.exists(pm) and bytes_alg == 271633408:
             try:
@@ -460,7 +463,7 @@ def measure_roofline(resp, device):
 def _unet_pmc_traffic(kernel_prefix):
     """HBM bytes per launch (read + write) of a UNet kernel from the committed counter pass (profiles/r0N_pmc_unet_hbm.json:
     averages over every launch of that kernel in the UNet step, not only the roofline shape -- stated in `traffic_source`)."""
-    for tag in ("r05", "r04", "r03", "r02"):          # newest committed counter pass first
+    for tag in ("r06", "r05", "r04", "r03", "r02"):          # newest committed counter pass first
         pm = os.path.join(ROOT, "profiles", f"{tag}_pmc_unet_hbm.json")
         try:
             for k in json.load(open(pm))["kernels"]:
@@ -1122,6 +1125,9 @@ def text_image_extras(args, resp, device):
     extra["roofline_unet_conv"] = measure_mfma_roofline(device)
     extra["roofline_unet_attention"] = measure_attention_roofline(device)
     extra["unet_step_mfma_frac"] = round(extra["unet_tflops_per_s"] / 2500.0, 4)
+    extra["mfma_peak_note"] = ("every MFMA 'frac' is against the nominal 2.5 PFLOP/s (2.4 GHz); MI355X_MICROARCH.md (DVFS give-back, item 1) records "
+                               "1.90-1.95 GHz under a saturated bf16 GEMM on random operands (1,247 TFLOP/s vs 1,483 on zeros), i.e. ~0.50 of "
+                               "nominal is the real-data ceiling of a matrix-core-bound loop on this part")
     return extra
 
 

@@ -1,7 +1,7 @@
 """Long fp32 ORACLE loops, run once in the build container, so that the GPU suite can compare full denoising loops without spending
 its time budget on CPU work:
 
-    python tests/golden/make_oracle_loops.py [sd15] [audioldm] [sdxl] [zeroscope]    # 8 cores: ~2, ~2, ~5, ~45 minutes
+    python tests/golden/make_oracle_loops.py [sd15] [audioldm] [sdxl] [zeroscope] [zeroscope8]    # 8 cores: ~2, ~2, ~5, ~45, ~3 minutes
 
   oracle_loop_sd15_pndm40.npz      SD-v1.5 UNet (UNetCfg.sd15(), weights seed 0), [1, 4, 64, 64] latent, 40 PNDM steps = 41 evaluations,
                            guidance 7.5 (configs[1]; custom_sd.py:627-652): latents in / out.
@@ -17,6 +17,9 @@ its time budget on CPU work:
   oracle_loop_zeroscope40_f16.npz  zeroscope UNet3D (oracle.unet3d.UNet3DCfg.zeroscope(), weights random_unet3d_weights(seed=6)),
                            CFG batch 2 on the [1, 4, 16, 40, 72] latent of configs[3] / [4], 40 DDIM steps, guidance 9.0
                            (spider_decoder.py:122-143, custom_vd.py:664-697): checksums of the seeded inputs and the fp32 latents after 1, 20, 40 steps.
+
+  oracle_step_zeroscope_8frames.npz  ONE evaluation of the same UNet3D at 8 frames ([2, 4, 8, 40, 72], timestep 701): the fp32 output
+                           (target `zeroscope8`, not part of the default list).
 
 These vectors are produced by the CPU RESTATEMENT (oracle/unet.py), not by the reference: diffusers is absent from the image
 (SURVEY.md section 8c), so they pin the HIP engine to the oracle over a whole loop -- the quantity north_star names -- and leave the
@@ -145,6 +148,30 @@ def zeroscope_loop(frames=16, steps=40, guidance=9.0, keep=(1, 20)):
                         frames=frames, weights_seed=6, **kept)
 
 
+def zeroscope8_inputs(frames=8):
+    """the seeded inputs of the single-evaluation fixture at 8 frames (the GPU test rebuilds them and checks the checksums)"""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 4, frames, 40, 72, generator=g).bfloat16().float()
+    enc = torch.randn(2, 77, 1024, generator=g).bfloat16().float()
+    return x, enc
+
+
+@torch.no_grad()
+def zeroscope8_step(frames=8, t=701):
+    """ONE fp32 oracle evaluation of the zeroscope UNet3D at 8 frames of 40 x 72 (weights seed 6, timestep 701, CFG batch 2): the live
+    oracle took 50-65 s of the GPU suite's time budget per run (round 6: the suite was at 704 of the driver's 900 s)."""
+    from oracle.unet3d import UNet3DCfg, UNet3DOracle, random_unet3d_weights
+    ocfg = UNet3DCfg.zeroscope()
+    w = random_unet3d_weights(ocfg, seed=6)
+    x, enc = zeroscope8_inputs(frames)
+    assert enc.shape[-1] == ocfg.cross_dim
+    t0 = time.time()
+    ref = UNet3DOracle(ocfg, w).forward(x, torch.tensor(t), enc)
+    print(f"zeroscope8: one evaluation in {time.time() - t0:.0f} s", flush=True)
+    np.savez(os.path.join(OUT, "oracle_step_zeroscope_8frames.npz"), ref=ref.numpy().astype(np.float32), weights_seed=6, t=t, frames=frames,
+             x_sum=float(x.double().sum()), enc_sum=float(enc.double().sum()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", os.cpu_count() or 8)))
     which = sys.argv[1:] or ["sd15", "audioldm", "sdxl", "zeroscope"]
@@ -156,3 +183,5 @@ if __name__ == "__main__":
         sdxl_loop()
     if "zeroscope" in which:
         zeroscope_loop()
+    if "zeroscope8" in which:
+        zeroscope8_step()
