@@ -399,7 +399,7 @@ class SpiderFreeInfer:
             return
         if lerr is not None and err is not None and lerr.__cause__ is None:
             lerr.__cause__ = err
-        if out is not None and err is None:
+        if out is not None:
             try:
                 first.spider_result = self._unbatch(out)
             except Exception:
