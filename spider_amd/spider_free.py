@@ -326,11 +326,19 @@ class SpiderFreeInfer:
         pending = self._pending
         dkey = self._dec_key(pending)
         if self._llm_cold(inputs, lkey) or dkey != self._last_dec or self.mode == "spider_story_free_qwen":
-            out = self.decoder_pass(*pending)
-            self._last_dec = dkey
-            self._pending = self.llm_pass(inputs)
-            self._warm.add(lkey)
+            # one pass after the other on this thread, with the state rules of the overlapped step: the old request leaves the pipeline
+            # whether its decoder pass succeeds or not (a request that fails deterministically must not wedge every later submit, and a
+            # request that has been decoded must never be decoded again), the new request's LLM pass runs either way, errors are raised last
+            self._pending = None
             self.last_pass_ms = {}
+            out, err = self._try(lambda: self.decoder_pass(*pending))
+            if err is None:
+                self._last_dec = dkey
+            newpend, lerr = self._try(lambda: self.llm_pass(inputs))
+            if lerr is None:
+                self._pending = newpend
+                self._warm.add(lkey)
+            self._raise_step_errors(lerr, err, out)
             return self._unbatch(out)
         out, newpend, err, lerr = self._overlap(lambda: self.decoder_pass(*pending), lambda: self.llm_pass(inputs))
         # the old request's decoder pass has run (or failed) either way: it must never be decoded again. The NEW request's LLM result
@@ -390,6 +398,14 @@ class SpiderFreeInfer:
             self.last_pass_ms = {"decoder_pass_ms": round(ev[0].elapsed_time(ev[1]), 1), "llm_pass_ms": round(ev[2].elapsed_time(ev[3]), 1)}
         return box.get("u"), box.get("l"), box.get("err"), box.get("lerr")
 
+    @staticmethod
+    def _try(fn):
+        """-> (fn(), None) or (None, the exception it raised): the passes of a step run to the end before anything is raised"""
+        try:
+            return fn(), None
+        except BaseException as e:
+            return None, e
+
     def _raise_step_errors(self, lerr, err, out=None):
         """raise what a step's two passes raised, AFTER the caller has advanced the pipeline state: this thread's exception first (the
         helper's chained onto it), else the helper's. A result that was computed beside the failure rides on the exception
@@ -427,16 +443,28 @@ class SpiderFreeInfer:
         warm = (pre is not None and pend is not None and not self._llm_cold(inputs, lkey, cset, decode=False) and dgk in self._warm and
                 dkey == self._last_dec and self.mode != "spider_story_free_qwen")
         if not warm:                                 # some graph of this step does not exist yet: one pass after the other, one thread
-            out = None
-            if pend is not None:
-                out = self.decoder_pass(*pend)
-                self._last_dec = dkey
-            self._pending = self.decode_pass(pre[0], pre[1]) if pre is not None else None
-            if dgk is not None:
-                self._warm.add(dgk)
-            self._prefilled = (*self.prefill_pass(inputs, cset), lkey, cset, B_new)
-            self._warm.add(lkey)
+            # (state rules of the overlapped step: both old requests leave their slots before their passes run -- a decoded or adopted
+            # request is never run again, a request that fails deterministically cannot wedge the pipeline -- every pass runs, errors last)
+            self._pending, self._prefilled = None, None
             self.last_pass_ms = {}
+            out = err = lerr = perr = None
+            if pend is not None:
+                out, err = self._try(lambda: self.decoder_pass(*pend))
+                if err is None:
+                    self._last_dec = dkey
+            if pre is not None:
+                newpend, lerr = self._try(lambda: self.decode_pass(pre[0], pre[1]))
+                if lerr is None:
+                    self._pending = newpend
+                    self._warm.add(dgk)
+            newpre, perr = self._try(lambda: self.prefill_pass(inputs, cset))
+            if perr is None:
+                self._prefilled = (*newpre, lkey, cset, B_new)
+                self._warm.add(lkey)
+            first = lerr if lerr is not None else perr
+            if first is not None and perr is not None and first is not perr and first.__cause__ is None:
+                first.__cause__ = perr
+            self._raise_step_errors(first, err, out)
             return None if out is None else self._unbatch(out)
 
         box = {}
