@@ -504,3 +504,45 @@ def test_pipeline_state_machine_under_random_failures(depth, seed):
     # failure hit the step that carried it (its result rides on the exception when it was computed): nothing else may vanish
     near = fail["llm"] | fail["dec"] | fail["img"] | pre_fired
     assert all(i in pre_fired or any(abs(i - b) <= 2 for b in near) for i in lost), (lost, fail, pre_fired)
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+@pytest.mark.parametrize("seed", range(10))
+def test_pipelined_generator_random_request_mixes(depth, seed):
+    """`pipelined(requests, group=n)` over random mixes of conversations (merged into batched requests of up to n rows) and
+    processor-output dicts (passed through; several rows come back as a list): one result per conversation / dict, in request order,
+    every request's LLM work done exactly once, the same responses as the one-request-at-a-time calls."""
+    import random
+    rng = random.Random(77 * depth + seed)
+    pipe, thinker = FakePipe(), (FakeThinker3() if depth == 3 else FakeThinker())
+    dinf = SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": pipe}, device="cpu")})
+    proc = SyntheticOmniProcessor(vocab=500, tags=("IMAGE",), head=3)
+    infer = SpiderFreeInfer(thinker, proc, dinf, device="cpu", depth=depth)
+    ref = SpiderFreeInfer(FakeThinker(), SyntheticOmniProcessor(vocab=500, tags=("IMAGE",), head=3),
+                          SpiderDecoderInfer({"model": dict(type="spider_decoder", pipelines={"IMAGE": FakePipe()}, device="cpu")}), device="cpu")
+    reqs, want = [], []
+    for i in range(rng.randint(1, 14)):
+        conv = [{"role": "user", "content": " ".join([f"w{i}"] * rng.randint(1, 6))}]
+        if rng.random() < 0.3:
+            rows = rng.randint(1, 3)
+            d = ref.build_inputs_batch([conv] * rows) if rows > 1 else ref.build_inputs(conv)
+            reqs.append(dict(d))
+            r = ref.predict(inputs=dict(d))
+            want.append([x.response for x in r] if isinstance(r, list) else r.response)
+        else:
+            reqs.append(conv)
+            want.append(None)                  # (a merged row's tokens depend on its batch's padding: checked by count and order only)
+    group = rng.randint(1, 4)
+    got = list(infer.pipelined(reqs, group=group))
+    assert len(got) == len(reqs)
+    for rq, w, g in zip(reqs, want, got):
+        if isinstance(rq, dict):
+            B = rq["input_ids"].shape[0]
+            assert (isinstance(g, list) and len(g) == B) if B > 1 else not isinstance(g, list)
+            assert ([x.response for x in g] if isinstance(g, list) else g.response) == w
+        else:
+            assert not isinstance(g, list) and g.answers == [g.response] and len(g.predictions["IMAGE"]) == 1
+    n_rows = sum(rq["input_ids"].shape[0] if isinstance(rq, dict) else 1 for rq in reqs)
+    rows_llm = sum(c[1][0] for c in thinker.calls)
+    assert rows_llm == n_rows and sum(len(c[1]) for c in pipe.calls) == n_rows          # every row: one LLM pass, one caption decoded
+    assert infer.flush() is None
