@@ -552,6 +552,57 @@ def test_gemm_256_tile_repeatable_under_load(ops, dev):
     torch.cuda.synchronize()
 
 
+def test_lds_dma_kernels_repeatable_under_load(ops, dev):
+    """Race screen of the LDS-DMA GEMM / conv family (gemm_dma_kernel: `buffer_load ... lds` rings of 2 / 3 / 4 stages with counted
+    vmcnt waits and ONE raw barrier per K tile; 64- and 128-row tiles; split-K slabs + the statistics-producing reduce; the GroupNorm
+    statistics epilogue; the two-blocks-per-CU form with the row-order epilogue through LDS) and of the fused cross-attention
+    sub-block: the shapes the SD-v1.5 / zeroscope engines send there. A DMA tile consumed before it landed, or an epilogue staging
+    buffer reused too early, shows up as a repeat that differs while a second stream shifts the timing of the waves."""
+    import math
+    side = torch.cuda.Stream()
+    junk = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+    H = torch.float16
+    def t(*shape, seed, scale=1.0):
+        return rnd(*shape, seed=seed, scale=scale).to(H).to(dev)
+    x64, w64, b64 = t(2, 64, 64, 320, seed=1), t(320, 3, 3, 320, seed=2, scale=0.02), t(320, seed=3)
+    x64b, w64b = t(2, 64, 64, 640, seed=4), t(320, 3, 3, 640, seed=5, scale=0.015)
+    x32, w32 = t(2, 32, 32, 1280, seed=6), t(640, 3, 3, 1280, seed=7, scale=0.01)
+    x16, w16 = t(2, 16, 16, 1280, seed=8), t(1280, 3, 3, 1280, seed=9, scale=0.01)
+    r64 = torch.randn(2, 64, 64, 320, generator=torch.Generator().manual_seed(10)).to(dev)
+    At, Wt, rt = t(92160, 320, seed=11), t(320, 320, seed=12, scale=0.05), torch.randn(92160, 320, generator=torch.Generator().manual_seed(13)).to(dev)
+    xt, wt3 = t(32, 40, 72, 320, seed=14), t(320, 3, 3, 320, seed=15, scale=0.02)          # zeroscope: 92160 rows, 3 x 3
+    A5, W5 = t(512, 5120, seed=16), t(1280, 5120, seed=17, scale=0.02)                      # 16^2 ff2: long-K linear on the DMA kernel, K splits
+    # fused cross-attention at the 64^2 site
+    B2, n_tok, C, LP = 2, 4096, 320, 80
+    xx = t(B2, n_tok, C, seed=18)
+    mq, mo = t(B2 * 8 * LP, C, seed=19, scale=0.05), t(B2 * C, 8 * LP, seed=20, scale=0.05)
+    mqf, mof = ops.repack_fm16(mq), ops.repack_fm16(mo)
+    c1, c2, bo = torch.zeros(B2 * 8 * LP, device=dev), torch.zeros(B2 * 8 * LP, device=dev), t(C, seed=21)
+    x32s = torch.randn(B2, n_tok, C, generator=torch.Generator().manual_seed(22)).to(dev)
+
+    def flat(o):
+        o = o if isinstance(o, (tuple, list)) else (o,)
+        return [v.t if hasattr(v, "t") and not torch.is_tensor(v) else v for v in o if v is not None]
+    fs = [lambda: ops.conv_ex(x64, w64, bias=b64, pad=(1, 1), gn_groups=32),                         # 64-row tiles, statistics epilogue
+          lambda: ops.conv_ex(x64, w64, bias=b64, pad=(1, 1), res32=r64, want32=True),               # conv2 role: fp32 residual stream
+          lambda: ops.conv_ex(x64b, w64b, pad=(1, 1), gn_groups=32),                                 # 128-row tiles, K splits + reduce
+          lambda: ops.conv_ex(x32, w32, pad=(1, 1), gn_groups=32),
+          lambda: ops.conv_ex(x16, w16, pad=(1, 1), gn_groups=32),                                   # 8 K splits, statistics from the reduce
+          lambda: ops.gemm(At, Wt, res32=rt, want32=True),                                           # two blocks per CU + row-order epilogue
+          lambda: ops.conv_ex(xt, wt3, pad=(1, 1)),                                                  # tall conv on the 2-stage ring
+          lambda: ops.gemm(A5, W5),
+          lambda: ops.xattn_fused(xx, mqf, mof, c1, c2, bo, B2, 8, 77, x32=x32s, want32=True)]
+    for k, f in enumerate(fs):
+        ref = [v.clone() for v in flat(f())]
+        for i in range(25):
+            if i % 2 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            got = flat(f())
+            assert len(got) == len(ref) and all(torch.equal(a, b_) for a, b_ in zip(got, ref)), f"case {k}: repeat {i} differs"
+    torch.cuda.synchronize()
+
+
 def test_attention_kernels_repeatable_under_load(ops, dev):
     """Race screen of the attention kernels that overlap their own loads with compute: the software-pipelined dense flash kernel
     (K / V images re-staged while the previous tile is still being scored: the round-2 advisor found its prologue one barrier
