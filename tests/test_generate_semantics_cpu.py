@@ -74,3 +74,64 @@ def test_generation_config_defaults(tmp_path):
     assert gc["eos_token_id"] == [5, 6] and gc["pad_token_id"] == 9 and gc["max_new_tokens"] == 77
     os.remove(tmp_path / "generation_config.json")
     assert read_generation_config(str(tmp_path))["eos_token_id"] == 2
+
+
+def _hf_greedy_bookkeeping(free, eos, pad, criteria, prompt):
+    """Step-by-step restatement of transformers' greedy `_sample` bookkeeping (the order of its loop body): pad finished rows, append,
+    run the stopping criteria (per-row EOS + the caller's batch-level ones), stop when no row is unfinished."""
+    B, n = free.shape
+    unfinished = torch.ones(B, dtype=torch.long)
+    if eos and pad is None:
+        pad = eos[0]
+    seq = torch.zeros(B, 0, dtype=torch.long)
+    for t in range(n):
+        nxt = free[:, t].clone()
+        if eos:
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+        seq = torch.cat([seq, nxt[:, None]], 1)
+        done = torch.zeros(B, dtype=torch.bool)
+        if eos:
+            done |= torch.isin(nxt, torch.tensor(eos))
+        full = seq if prompt is None else torch.cat([prompt, seq], 1)
+        for sc in criteria or []:
+            if bool(torch.as_tensor(sc(full, None)).all()):
+                done |= True
+        unfinished = unfinished & (~done).long()
+        if int(unfinished.max()) == 0:
+            return seq, t + 1, True
+    return seq, n, False
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_finalize_greedy_random_blocks_against_stepwise_bookkeeping(seed):
+    """finalize_greedy (vectorised, applied after the fact to blocks of tokens) against the step-by-step loop on random token blocks:
+    several EOS ids, pad given or defaulted, rows that never finish, stop words on sequence 0 (also spanning block boundaries), and
+    block-wise checking with `checked` exactly as LlamaEngine's sync_every loop drives it."""
+    import random
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    B, n, V = rng.randint(1, 5), rng.randint(1, 30), rng.choice([4, 8, 30])
+    free = torch.randint(0, V, (B, n), generator=g)
+    eos = rng.choice([None, [rng.randrange(V)], sorted({rng.randrange(V) for _ in range(3)})])
+    pad = rng.choice([None, rng.randrange(V), V + 3])
+    prompt = rng.choice([None, torch.randint(0, V, (B, rng.randint(1, 4)), generator=g)])
+    crit = None
+    if rng.random() < 0.6:
+        L = rng.randint(1, 3)
+        s0 = rng.randrange(0, max(1, n - L + 1))
+        word = free[0, s0:s0 + L].tolist() if rng.random() < 0.7 else [rng.randrange(V) for _ in range(L)]
+        crit = [StoppingCriteriaSub([word])]
+    want, kw, hw = _hf_greedy_bookkeeping(free, eos, pad, crit, prompt)
+    got, k, hit = finalize_greedy(free.clone(), eos, pad, crit, prompt)
+    assert (k, hit) == (kw, hw) and torch.equal(got, want), (seed, got, want)
+    # block-wise, as the decode loop runs it: blocks of `se` tokens, criteria re-run only on the new prefixes
+    se = rng.randint(1, 6)
+    res, checked, kk = None, 0, None
+    for m in range(se, n + se, se):
+        m = min(m, n)
+        tk, kk, h = finalize_greedy(free[:, :m].clone(), eos, pad, crit, prompt, checked + 1)
+        checked = m
+        if h or m == n:
+            res, hh = tk, h
+            break
+    assert hh == hw and kk == kw and torch.equal(res, want), (seed, se, res, want)
